@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+Imports /root/reference through a small shim loader (the container lacks torchvision, path.py,
+scipy.misc.imresize/imread ...), feeds it closed-form inputs/weights from oracle.detgen, and stores
+inputs-by-formula + outputs.  Nothing of the reference's source travels: only numbers.
+
+    python tests/golden/make_goldens.py            # writes tests/golden/*.npz
+
+The committed .npz files are what the CPU test-suite pins the oracle against; the GPU box never
+reads /root/reference.
+"""
+import importlib.util
+import os
+import pathlib
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = pathlib.Path(os.environ.get("DISPNET_REFERENCE", "/root/reference"))
+HERE = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent.parent))
+
+from oracle import detgen  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shim loader
+def _install_shims():
+    # torchvision: layout only (cfg "D" with BN) -- all arithmetic stays torch.nn
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+
+    class _VGG(nn.Module):
+        def __init__(self):
+            super().__init__()
+            cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+            layers, c = [], 3
+            for v in cfg:
+                if v == "M":
+                    layers.append(nn.MaxPool2d(2, 2))
+                else:
+                    layers += [nn.Conv2d(c, v, 3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                    c = v
+            self.features = nn.Sequential(*layers)
+            self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+            # the 123.6 M-parameter classifier is never used by the hot path; keep it tiny here
+            self.classifier = nn.Sequential(nn.Linear(8, 8), nn.ReLU(True), nn.Dropout(), nn.Linear(8, 8),
+                                            nn.ReLU(True), nn.Dropout(), nn.Linear(8, 8))
+
+    tvm.vgg16_bn = lambda pretrained=False, **kw: _VGG()
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    import scipy.misc
+    scipy.misc.imresize = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("imresize stub"))
+    scipy.misc.imread = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("imread stub"))
+    pm = types.ModuleType("path")
+    pm.Path = pathlib.Path
+    sys.modules["path"] = pm
+    if not hasattr(np, "int"):
+        np.int = int
+    sys.path.insert(0, str(REF))
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, str(REF / rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    out = HERE / (name + ".npz")
+    np.savez_compressed(out, **arrays)
+    print("wrote", out.name, "%.1f KB" % (out.stat().st_size / 1024))
+
+
+# --------------------------------------------------------------------------------- sections
+def gold_dispnets(ref_dispnets):
+    """Config 1: DispNetS forward on 2x(3,128,416), train and eval."""
+    net = ref_dispnets.DispNetS(datasets="kitti")
+    detgen.fill_state_dict(net.state_dict(), "dispnets")
+    x = detgen.image_batch(2, 128, 416, "dispnets:x")
+    net.train()
+    outs = net(x)
+    arrays = {}
+    for i, o in enumerate(outs):
+        for k, v in detgen.summarize(o).items():
+            arrays["train%d_%s" % (i, k)] = v
+    arrays["train3_full"] = _np(outs[3])          # coarsest scale in full
+    loss = sum((o * detgen.uniform(tuple(o.shape), "dispnets:g%d" % i, -1, 1)).sum() for i, o in enumerate(outs))
+    loss.backward()
+    for key in ("conv1.0.weight", "conv7.2.weight", "upconv7.0.weight", "iconv3.0.weight", "predict_disp1.0.weight",
+                "iconv1.0.bias"):
+        g = dict(net.named_parameters())[key].grad
+        for k, v in detgen.summarize(g, stride=53).items():
+            arrays["grad:%s:%s" % (key, k)] = v
+    net.eval()
+    with torch.no_grad():
+        e = net(x)
+    for k, v in detgen.summarize(e).items():
+        arrays["eval_%s" % k] = v
+    save("dispnets_cfg1", **arrays)
+
+
+def _vgg_case(ref_vgg, b, h, w, tag, full):
+    net = ref_vgg.Disp_vgg_BN(datasets="kitti")
+    detgen.fill_state_dict(net.state_dict(), "vggbn")
+    x = detgen.image_batch(b, h, w, tag + ":x")
+    gt = detgen.sparse_depth(b, h, w, tag + ":gt", density=0.3 if full else 0.05)
+    return net, x, gt
+
+
+def gold_vgg_bn(ref_vgg, ref_loss):
+    """Disp_vgg_BN fwd (4 outputs), l1-loss backward grads, BN running stats; tiny (full) + config shape."""
+    for tag, (b, h, w), full in (("vggbn_tiny", (2, 64, 96), True), ("vggbn_cfg", (2, 128, 416), False)):
+        net, x, gt = _vgg_case(ref_vgg, b, h, w, tag, full)
+        net.train()
+        disps = net(x)
+        depth = [1 / d for d in disps]
+        loss = ref_loss.l1_loss(gt, depth, "kitti") + 0.1 * ref_loss.smooth_loss(depth)
+        loss.backward()
+        arrays = {"loss": np.float64(loss.item())}
+        for i, o in enumerate(disps):
+            if full:
+                arrays["disp%d" % i] = _np(o)
+            for k, v in detgen.summarize(o).items():
+                arrays["disp%d_%s" % (i, k)] = v
+        params = dict(net.named_parameters())
+        for key in ("features.features.0.weight", "features.features.0.bias", "features.features.1.weight",
+                    "features.features.1.bias", "features.features.40.weight", "features.features.41.weight",
+                    "features.features.17.weight", "upconv4.0.weight", "upconv0.0.weight", "upconv0.0.bias",
+                    "iconv4.0.weight", "iconv2.0.weight", "iconv0.0.weight", "iconv0.0.bias", "disp0.0.weight",
+                    "disp3.0.weight", "disp2.0.bias"):
+            g = params[key].grad
+            if full and g.numel() <= 20000:
+                arrays["grad:%s" % key] = _np(g)
+            for k, v in detgen.summarize(g, stride=53).items():
+                arrays["grad:%s:%s" % (key, k)] = v
+        sd = net.state_dict()
+        for key in ("features.features.1.running_mean", "features.features.1.running_var",
+                    "features.features.41.running_mean", "features.features.41.running_var"):
+            arrays["bn:%s" % key] = _np(sd[key])
+        arrays["bn:nbt"] = _np(sd["features.features.1.num_batches_tracked"])
+        if full:
+            net.eval()
+            with torch.no_grad():
+                arrays["eval_disp0"] = _np(net(x))
+        save(tag, **arrays)
+
+
+def gold_train_step(ref_vgg, ref_loss):
+    """One iteration of (Disp_vgg_BN, L1, b=2, Adam lr 1e-4) as train.py:441-522 does it."""
+    net, x, gt = _vgg_case(ref_vgg, 2, 64, 96, "trainstep", True)
+    net.train()
+    opt = torch.optim.Adam([p for n, p in net.named_parameters() if "classifier" not in n], lr=1e-4, betas=(0.9, 0.999))
+    losses = []
+    for _ in range(2):
+        disps = net(x)
+        depth = [1 / d for d in disps]
+        loss = 1.0 * ref_loss.l1_loss(gt, depth, "kitti") + 0.0 * ref_loss.smooth_loss(depth)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    arrays = {"losses": np.array(losses, dtype=np.float64)}
+    sd = net.state_dict()
+    for key in ("features.features.0.weight", "features.features.1.weight", "features.features.1.running_var",
+                "features.features.40.bias", "upconv4.0.weight", "iconv0.0.weight", "disp0.0.weight", "disp0.0.bias"):
+        for k, v in detgen.summarize(sd[key], stride=31).items():
+            arrays["post:%s:%s" % (key, k)] = v
+    save("trainstep_vggbn_l1", **arrays)
+
+
+def gold_losses(ref_loss):
+    b, h, w = 3, 32, 64
+    gt = detgen.sparse_depth(b, h, w, "loss:gt", density=0.4, lo=0.5, hi=90.0)  # some > 80 -> invalid
+    arrays = {}
+    for ds in ("kitti", "nyu"):
+        for name in ("l1_loss", "l2_loss", "berhu_loss", "Scale_invariant_loss"):
+            if name == "berhu_loss" and ds == "nyu":
+                continue  # NameError in the reference (loss_functions.py:148-159)
+            depth = [detgen.uniform((b, 1, h >> i, w >> i), "loss:pred%d" % i, 1e-4, 95.0).requires_grad_() for i in range(4)]
+            v = getattr(ref_loss, name)(gt, depth, ds)
+            v.backward()
+            arrays["%s:%s" % (name, ds)] = np.float64(v.item())
+            arrays["%s:%s:grad" % (name, ds)] = _np(depth[0].grad)
+    for name in ("Multiscale_L1_loss", "Multiscale_FULL_L1_loss", "Multiscale_L2_loss", "Multiscale_berhu_loss",
+                 "Multiscale_scale_inv_loss"):
+        pools = ("bilinear", "max", "avg") if name == "Multiscale_L1_loss" else (("nearest",) if "FULL" in name else (None,))
+        for pool in pools:
+            depth = [detgen.uniform((b, 1, h >> i, w >> i), "loss:pred%d" % i, 1e-4, 95.0).requires_grad_() for i in range(4)]
+            v = getattr(ref_loss, name)(gt, depth) if pool is None else getattr(ref_loss, name)(gt, depth, pool)
+            v.backward()
+            key = name if pool is None else "%s:%s" % (name, pool)
+            arrays[key] = np.float64(v.item())
+            for i in range(4):
+                arrays["%s:grad%d" % (key, i)] = _np(depth[i].grad)
+    depth = [detgen.uniform((b, 1, h >> i, w >> i), "loss:pred%d" % i, 0.5, 60.0).requires_grad_() for i in range(4)]
+    v = ref_loss.smooth_loss(depth)
+    v.backward()
+    arrays["smooth_loss"] = np.float64(v.item())
+    for i in range(4):
+        arrays["smooth_loss:grad%d" % i] = _np(depth[i].grad)
+    p = detgen.uniform((b, 8, h, w), "loss:ord", 0.0, 1.0).requires_grad_()
+    v = ref_loss.smooth_DORN_loss(p)
+    v.backward()
+    arrays["smooth_DORN_loss"] = np.float64(v.item())
+    arrays["smooth_DORN_loss:grad"] = _np(p.grad)
+    # empty-mask sample -> NaN (mean of empty)
+    gt0 = gt.clone(); gt0[1] = 0
+    depth = [detgen.uniform((b, 1, h, w), "loss:pred0", 1e-4, 95.0)]
+    arrays["l1_loss:empty_sample"] = np.float64(ref_loss.l1_loss(gt0, depth, "kitti").item())
+    # explainability
+    m = [detgen.uniform((b, 2, h >> i, w >> i), "loss:mask%d" % i, 0.05, 0.95).requires_grad_() for i in range(2)]
+    v = ref_loss.explainability_loss(m); v.backward()
+    arrays["explainability_loss"] = np.float64(v.item())
+    arrays["explainability_loss:grad0"] = _np(m[0].grad)
+    save("losses", **arrays)
+
+
+def gold_compute_errors(ref_loss):
+    arrays = {}
+    for ds, (b, h, w), hi in (("kitti", (3, 128, 416), 90.0), ("nyu", (2, 48, 64), 11.0)):
+        gt = detgen.sparse_depth(b, h, w, "err:gt:" + ds, density=0.3, lo=0.5, hi=hi)
+        pred = detgen.uniform((b, h, w), "err:pred:" + ds, 1e-4, hi)
+        arrays["errors:%s" % ds] = np.array(ref_loss.compute_errors(gt, pred, ds), dtype=np.float64)
+        arrays["errors:%s:median" % ds] = np.array(ref_loss.compute_errors(gt, pred, ds, True, True), dtype=np.float64)
+    save("compute_errors", **arrays)
+
+
+def warp_inputs(b, h, w, tag):
+    img = detgen.uniform((b, 3, h, w), tag + ":img", -1, 1)
+    depth = detgen.uniform((b, h, w), tag + ":depth", 2.0, 30.0)
+    pose = detgen.uniform((b, 6), tag + ":pose", -0.05, 0.05)
+    fx, fy, cx, cy = 241.67 * w / 416, 246.28 * h / 128, 204.17 * w / 416, 59.0 * h / 128
+    k = torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float32).repeat(b, 1, 1)
+    return img, depth, pose, k, torch.inverse(k)
+
+
+def gold_warp(ref_warp, ref_loss):
+    arrays = {}
+    b, h, w = 2, 24, 40
+    img, depth, pose, k, kinv = warp_inputs(b, h, w, "warp")
+    arrays["kinv"] = _np(kinv)
+    import torch.nn.functional as F
+    orig = F.grid_sample
+    for ac in (False, True):
+        F.grid_sample = (lambda i, g, padding_mode="zeros", _ac=ac: orig(i, g, padding_mode=padding_mode, align_corners=_ac))
+        ref_warp.F.grid_sample = F.grid_sample
+        for pad in ("zeros", "border"):
+            for rot in ("euler", "quat"):
+                d = depth.clone().requires_grad_(); p = pose.clone().requires_grad_()
+                ref_warp.pixel_coords = None
+                out = ref_warp.inverse_warp(img, d, p, k, kinv, rot, pad)
+                (out * detgen.uniform(tuple(out.shape), "warp:g", -1, 1)).sum().backward()
+                key = "ac%d:%s:%s" % (int(ac), pad, rot)
+                arrays[key] = _np(out)
+                arrays[key + ":gdepth"] = _np(d.grad)
+                arrays[key + ":gpose"] = _np(p.grad)
+    # photometric loss at both align_corners settings (4 scales, 2 refs)
+    b, h, w = 2, 32, 64
+    tgt, _, _, k, kinv = warp_inputs(b, h, w, "photo")
+    refs = [detgen.uniform((b, 3, h, w), "photo:ref%d" % i, -1, 1) for i in range(2)]
+    pose = detgen.uniform((b, 2, 6), "photo:pose", -0.03, 0.03)
+    for ac in (False, True):
+        F.grid_sample = (lambda i, g, padding_mode="zeros", _ac=ac: orig(i, g, padding_mode=padding_mode, align_corners=_ac))
+        ref_warp.F.grid_sample = F.grid_sample
+        for with_mask in (False, True):
+            ref_warp.pixel_coords = None
+            depth = [detgen.uniform((b, 1, h >> i, w >> i), "photo:d%d" % i, 2.0, 30.0).requires_grad_() for i in range(4)]
+            pz = pose.clone().requires_grad_()
+            # training-mode PoseExpNet(output_exp=False) hands over [None]*4 (models/PoseExpNet.py:84-92)
+            mask = [detgen.uniform((b, 2, h >> i, w >> i), "photo:m%d" % i, 0.1, 0.9) for i in range(4)] if with_mask else [None] * 4
+            v = ref_loss.photometric_reconstruction_loss(tgt, refs, k, kinv, depth, mask, pz, "euler", "zeros")
+            v.backward()
+            key = "photo:ac%d:mask%d" % (int(ac), int(with_mask))
+            arrays[key] = np.float64(v.item())
+            arrays[key + ":gpose"] = _np(pz.grad)
+            for i in range(4):
+                arrays[key + ":gdepth%d" % i] = _np(depth[i].grad)
+    F.grid_sample = orig
+    ref_warp.F.grid_sample = orig
+    # QUIRK pin: a bare None mask becomes [None] and zip() truncates the loss to scale 0 only
+    ref_warp.pixel_coords = None
+    depth = [detgen.uniform((b, 1, h >> i, w >> i), "photo:d%d" % i, 2.0, 30.0) for i in range(4)]
+    arrays["photo:bare_none_mask"] = np.float64(
+        ref_loss.photometric_reconstruction_loss(tgt, refs, k, kinv, depth, None, pose, "euler", "zeros").item())
+    save("warp", **arrays)
+
+
+def gold_layers(ref_layers):
+    x = detgen.uniform((2, 3, 20, 28), "ssim:x", 0, 1).requires_grad_()
+    y = detgen.uniform((2, 3, 20, 28), "ssim:y", 0, 1).requires_grad_()
+    s = ref_layers.SSIM()(x, y)
+    (s * detgen.uniform(tuple(s.shape), "ssim:g", -1, 1)).sum().backward()
+    disp = detgen.uniform((2, 1, 20, 28), "esm:disp", 0.1, 5).requires_grad_()
+    img = detgen.uniform((2, 3, 20, 28), "esm:img", 0, 1)
+    e = ref_layers.get_smooth_loss(disp, img); e.backward()
+    save("layers", ssim=_np(s), ssim_gx=_np(x.grad), ssim_gy=_np(y.grad), edge_smooth=np.float64(e.item()),
+         edge_smooth_gdisp=_np(disp.grad))
+
+
+def gold_dorn(ref_dorn, ref_utils, ref_loss):
+    arrays = {}
+    for ds, hi in (("kitti", 85.0), ("nyu", 11.0)):
+        d = detgen.uniform((2, 16, 24), "sid:d:" + ds, 0.0, hi)
+        for kc in (71, 80):
+            lab = ref_utils.get_labels_sid(d, ordinal_c=kc, dataset=ds)
+            arrays["labels:%s:%d" % (ds, kc)] = _np(lab).astype(np.int32)
+            arrays["decode:%s:%d" % (ds, kc)] = _np(ref_utils.get_depth_sid(lab, ordinal_c=kc, dataset=ds))
+    pre = detgen.uniform((2, 2 * 12, 10, 14), "orl:pre", -3, 3).requires_grad_()
+    dec, ordc = ref_dorn.OrdinalRegressionLayer()(pre)
+    arrays["orl:decode"] = _np(dec).astype(np.int64)
+    arrays["orl:ord"] = _np(ordc)
+    gt = detgen.sparse_depth(2, 10, 14, "orl:gt", density=0.6, lo=0.5, hi=90)
+    tgt = ref_utils.get_labels_sid(gt, ordinal_c=12, dataset="kitti")
+    v = ref_loss.DORN_loss(gt, ordc, tgt, "kitti"); v.backward()
+    arrays["dorn_loss"] = np.float64(v.item())
+    arrays["dorn_loss:gpre"] = _np(pre.grad)
+    # eval-mode forward of the full DORN-head net (dropout = identity)
+    net = ref_dorn.Disp_vgg_BN_DORN(datasets="kitti", ordinal_c=8)
+    detgen.fill_state_dict(net.state_dict(), "vggdorn")
+    net.eval()
+    x = detgen.image_batch(1, 64, 96, "vggdorn:x")
+    with torch.no_grad():
+        dec, ordc = net(x)
+    arrays["net:decode"] = _np(dec).astype(np.int64)
+    arrays["net:ord"] = _np(ordc)
+    save("dorn", **arrays)
+
+
+def synthetic_kitti_scene(n_pts=20000):
+    """Synthetic calibration + point cloud in KITTI conventions (values by formula)."""
+    p_rect = np.array([7.215377e+02, 0, 6.095593e+02, 4.485728e+01, 0, 7.215377e+02, 1.728540e+02, 2.163791e-01,
+                       0, 0, 1, 2.745884e-03])
+    r_rect = np.array([9.999239e-01, 9.837760e-03, -7.445048e-03, -9.869795e-03, 9.999421e-01, -4.278459e-03,
+                       7.402527e-03, 4.351614e-03, 9.999631e-01])
+    r = np.array([7.533745e-03, -9.999714e-01, -6.166020e-04, 1.480249e-02, 7.280733e-04, -9.998902e-01,
+                  9.998621e-01, 7.523790e-03, 1.480755e-02])
+    t = np.array([-4.069766e-03, -7.631618e-02, -2.717806e-01])
+    u = detgen.uniform((n_pts, 3), "kitti:pts", 0, 1, dtype=torch.float64).numpy()
+    velo = np.zeros((n_pts, 4), dtype=np.float32)
+    velo[:, 0] = (-2 + 70 * u[:, 0] ** 2).astype(np.float32)       # forward (some behind the camera)
+    velo[:, 1] = (-25 + 50 * u[:, 1]).astype(np.float32)
+    velo[:, 2] = (-2.0 + 3.0 * u[:, 2]).astype(np.float32)
+    velo[:, 3] = 1.0
+    return p_rect, r_rect, r, t, velo
+
+
+def gold_kitti(ref_kitti):
+    p_rect, r_rect, r, t, velo = synthetic_kitti_scene()
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = pathlib.Path(tmp)
+        fmt = lambda a: " ".join("%.6e" % v for v in a)
+        (tmp / "calib_cam_to_cam.txt").write_text(
+            "calib_time: 09-Jan-2012 13:57:47\nR_rect_00: %s\nP_rect_02: %s\n" % (fmt(r_rect), fmt(p_rect)))
+        (tmp / "calib_velo_to_cam.txt").write_text(
+            "calib_time: 15-Mar-2012 11:37:16\nR: %s\nT: %s\n" % (fmt(r), fmt(t)))
+        velo.tofile(str(tmp / "scan.bin"))
+        arrays = {}
+        for shape in ((375, 1242), (120, 400)):
+            depth = ref_kitti.generate_depth_map(tmp, tmp / "scan.bin", shape, cam=2)
+            mask = ref_kitti.generate_mask(depth, 1e-3, 80)
+            yy, xx = np.nonzero(depth)
+            arrays["depth:%dx%d:yx" % shape] = np.stack([yy, xx], 1).astype(np.int32)
+            arrays["depth:%dx%d:val" % shape] = depth[yy, xx]
+            arrays["mask:%dx%d:count" % shape] = np.int64(mask.sum())
+            arrays["mask:%dx%d:rowsum" % shape] = mask.sum(1).astype(np.int32)
+        arrays["sub2ind"] = np.array([ref_kitti.sub2ind((375, 1242), 10.0, 7.0), ref_kitti.sub2ind((120, 400), 119.0, 399.0)])
+    save("kitti_gt", **arrays)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _install_shims()
+    ref_dispnets = _load("ref_dispnets", "models/DispNetS.py")
+    ref_vgg = _load("ref_vgg_bn", "models/Disp_vgg_BN.py")
+    ref_dorn = _load("ref_vgg_bn_dorn", "models/Disp_vgg_BN_DORN.py")
+    ref_warp = _load("inverse_warp", "inverse_warp.py")      # loss_functions imports it by this name
+    ref_loss = _load("ref_loss_functions", "loss_functions.py")
+    ref_layers = _load("ref_layers", "layers.py")
+    ref_utils = _load("ref_utils", "utils.py")
+    ref_kitti = _load("ref_kitti_eval", "kitti_eval/depth_evaluation_utils.py")
+    want = set(sys.argv[1:])
+    sections = {
+        "dispnets": lambda: gold_dispnets(ref_dispnets),
+        "vgg": lambda: gold_vgg_bn(ref_vgg, ref_loss),
+        "trainstep": lambda: gold_train_step(ref_vgg, ref_loss),
+        "losses": lambda: gold_losses(ref_loss),
+        "errors": lambda: gold_compute_errors(ref_loss),
+        "warp": lambda: gold_warp(ref_warp, ref_loss),
+        "layers": lambda: gold_layers(ref_layers),
+        "dorn": lambda: gold_dorn(ref_dorn, ref_utils, ref_loss),
+        "kitti": lambda: gold_kitti(ref_kitti),
+    }
+    for name, fn in sections.items():
+        if not want or name in want:
+            print("==", name)
+            fn()
+
+
+if __name__ == "__main__":
+    main()
