@@ -1,0 +1,122 @@
+"""ctypes binding of libdispnet_hip.so (the C ABI declared in include/dispnet_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails this module raises.
+Nothing here imports torch; callers pass raw device pointers (tensor.data_ptr()) and the raw hipStream_t.
+"""
+import ctypes as C
+import os
+import pathlib
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip.so"))
+
+DN_MAX_OPERANDS = 3
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
+CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
+LOSS_L1, LOSS_L2 = 0, 1
+
+_f32p = C.c_void_p  # device pointers travel as integers
+
+
+class Operand(C.Structure):
+    _fields_ = [("data", _f32p), ("C", C.c_int32), ("up_shift", C.c_int32),
+                ("stride_n", C.c_int64), ("stride_h", C.c_int64), ("stride_w", C.c_int64), ("stride_c", C.c_int64),
+                ("scale", _f32p), ("shift", _f32p)]
+
+
+class Result(C.Structure):
+    _fields_ = [("data", _f32p), ("C", C.c_int32), ("accumulate", C.c_int32),
+                ("stride_n", C.c_int64), ("stride_h", C.c_int64), ("stride_w", C.c_int64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("OH", C.c_int32),
+                ("OW", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("n_in", C.c_int32), ("in_", Operand * DN_MAX_OPERANDS),
+                ("n_out", C.c_int32), ("out", Result * DN_MAX_OPERANDS),
+                ("w_packed", _f32p), ("bias", _f32p), ("act", C.c_int32), ("act_p0", C.c_float), ("act_p1", C.c_float),
+                ("bn_partial", _f32p)]
+
+
+_P = C.POINTER
+_i32, _i64, _f, _d, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/dispnet_hip.h declares (checked by tests/test_abi.py)
+SIGNATURES = {
+    "dn_version": (C.c_int, []),
+    "dn_last_error": (C.c_char_p, []),
+    "dn_device_arch_ok": (C.c_int, []),
+    "dn_conv_packed_weight_elems": (_i64, [_P(ConvDesc)]),
+    "dn_conv_pack_weights": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
+    "dn_conv_bn_partial_rows": (_i32, [_P(ConvDesc)]),
+    "dn_conv2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),
+    "dn_conv2d_dgrad": (C.c_int, [_P(ConvDesc), _vp]),
+    "dn_convT2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),
+    "dn_convT2d_dgrad": (C.c_int, [_P(ConvDesc), _vp]),
+    "dn_conv_wgrad_workspace_bytes": (_sz, [_P(ConvDesc)]),
+    "dn_conv2d_wgrad": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp, _sz, _vp]),
+    "dn_bn_finalize": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "dn_bn_eval_affine": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "dn_bn_relu_pool_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_bn_relu_pool_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_bn_relu_bwd_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "dn_bn_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "dn_reduce_blocks": (_i32, [_i64, _i32]),
+    "dn_act_bwd_reduce": (C.c_int, [_vp, _vp, _i32, _f, _f, _i64, _i32, _vp, _vp]),
+    "dn_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_upsample2x_nearest_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_upsample2x_bilinear_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_upsample2x_bilinear_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_reciprocal_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "dn_reciprocal_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "dn_masked_loss_fwd": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _vp, _vp, _vp]),
+    "dn_masked_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _f, _i32, _vp, _vp]),
+    "dn_smooth_blocks": (_i32, [_i32, _i32, _i32]),
+    "dn_smooth2_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _f, _vp, _vp, _vp]),
+    "dn_smooth2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
+    "dn_compute_errors": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i32, _d, _vp]),
+    "dn_fill": (C.c_int, [_vp, _f, _i64, _vp]),
+    # diagnostic hook (host only)
+    "dn_debug_conv_plan": (C.c_int, [_P(ConvDesc), C.c_int, _P(_i32), C.c_int]),
+}
+
+_lib = None
+
+
+class DispnetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise DispnetHipError(
+            "libdispnet_hip.so not found at %s -- build it with `python supervised_dispnet_amd/csrc/build.py` "
+            "(or __graft_entry__.build()).  The HIP extension is mandatory; there is no CPU/PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().dn_last_error().decode(errors="replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise DispnetHipError("%s failed (%d): %s" % (what or "libdispnet_hip call", rc, last_error()))
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise DispnetHipError("%s failed (%d): %s" % (name, rc, last_error()))

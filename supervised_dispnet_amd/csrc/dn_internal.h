@@ -1,0 +1,85 @@
+// Internal declarations shared by the HIP translation units of libdispnet_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "dispnet_hip.h"
+
+namespace dn {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+static inline hipStream_t as_stream(dn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define DN_REQUIRE(cond, code, ...)      \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::dn::set_error(__VA_ARGS__);      \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------- igemm plan
+constexpr int kMaxTaps = 64;     // 7x7 = 49 taps (single phase); 4 phases of a 4x4/stride-2 = 16
+constexpr int kMaxPhases = 4;
+constexpr int kChunk = 32;       // K elements staged per main-loop step
+
+struct KOperand {                // device view of a dn_operand
+  const float* p;
+  const float* scale;
+  const float* shift;
+  long long sn, sh, sw, sc;
+  int C;
+  int up;
+  int vec;                       // C % 4 == 0 && sc == 1 && 16-byte aligned rows  -> float4 path
+  int ch_off;                    // first channel of this operand inside the concatenated K axis
+};
+
+struct KResult {
+  float* p;
+  long long sn, sh, sw;
+  int C;
+  int n_begin;                   // first global output column of this segment
+  int accumulate;
+  int linear;                    // pixel offset == m * sw (dense, un-phased)  -> no div/mod in the epilogue
+};
+
+struct KPhase {
+  int ntaps;
+  int tap0;                      // first entry in the tap tables
+  int ooy, oox;                  // output pixel = grid * ostride + (ooy, oox)
+  int nchunks;                   // K chunks of this phase (sum over operands of ceil(ntaps*C/32))
+  long long w_off;               // element offset of this phase's [Npad][nchunks*32] block in w_packed
+};
+
+struct IgemmParams {
+  KOperand in[DN_MAX_OPERANDS];
+  KResult out[DN_MAX_OPERANDS];
+  KPhase ph[kMaxPhases];
+  int8_t tdy[kMaxTaps], tdx[kMaxTaps], tr[kMaxTaps], ts[kMaxTaps];
+  int n_in, n_out, nphases;
+  int N, GH, GW, M;              // grid (per phase); M = N*GH*GW
+  int sy, sx;                    // input pixel = grid*s + tap offset
+  int osy, osx;                  // output pixel stride per grid step
+  int IH, IW, OH, OW;
+  int Ntot, Npad;                // output columns (all segments), padded to the N tile
+  int BN;                        // N tile chosen (32 / 64 / 128)
+  int R, S;
+  int n_is_dim0;                 // framework weight layout: [n][c][R][S] (1) or [c][n][R][S] (0)
+  int D0, D1;                    // framework weight dims 0 and 1
+  const float* w;
+  const float* bias;
+  float* bn_partial;
+  int act;
+  float act_p0, act_p1;
+  // weight-gradient use only
+  const float* g;                // dy (or x for conv-transpose) [M][Ntot]
+  float* ws;                     // [splits][Npad][Kp]
+  int splits, m_per_split;
+};
+
+int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p);
+
+}  // namespace dn

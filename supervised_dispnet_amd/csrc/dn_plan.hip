@@ -1,0 +1,289 @@
+// Host-side planning for the implicit-GEMM convolution family: turns a dn_conv_desc into the tap / phase tables
+// the kernels consume.  Pure host logic (also exported through dn_debug_conv_plan for CPU-side tests).
+#include <stdarg.h>
+#include <string.h>
+
+#include "dn_internal.h"
+
+namespace dn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return DN_ERR_LAUNCH;
+  }
+  return DN_OK;
+}
+
+static int pick_bn(int ntot) { return ntot <= 32 ? 32 : (ntot <= 64 ? 64 : 128); }
+
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// floor division for possibly negative numerators
+static int floor_div(int a, int b) {
+  int q = a / b, r = a % b;
+  return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
+}
+
+static void fill_operand(KOperand* k, const dn_operand* o, int ch_off) {
+  k->p = o->data;
+  k->scale = o->scale;
+  k->shift = o->shift;
+  k->sn = o->stride_n;
+  k->sh = o->stride_h;
+  k->sw = o->stride_w;
+  k->sc = o->stride_c;
+  k->C = o->C;
+  k->up = o->up_shift;
+  bool aligned = ((reinterpret_cast<uintptr_t>(o->data) & 15) == 0) && (o->stride_n % 4 == 0) &&
+                 (o->stride_h % 4 == 0) && (o->stride_w % 4 == 0);
+  k->vec = (o->C % 4 == 0 && o->stride_c == 1 && aligned) ? 1 : 0;
+  k->ch_off = ch_off;
+}
+
+int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
+  memset(p, 0, sizeof(*p));
+  DN_REQUIRE(d != nullptr, DN_ERR_BAD_ARG, "null conv descriptor");
+  DN_REQUIRE(d->kind >= DN_CONV_FWD && d->kind <= DN_CONVT_DGRAD, DN_ERR_BAD_ARG, "bad conv kind %d", d->kind);
+  DN_REQUIRE(d->R >= 1 && d->S >= 1 && d->R * d->S <= 49, DN_ERR_UNSUPPORTED, "kernel %dx%d unsupported", d->R, d->S);
+  DN_REQUIRE(d->stride >= 1 && d->stride <= 2, DN_ERR_UNSUPPORTED, "stride %d unsupported", d->stride);
+  DN_REQUIRE(d->n_in >= 1 && d->n_in <= DN_MAX_OPERANDS, DN_ERR_BAD_ARG, "n_in %d", d->n_in);
+  DN_REQUIRE(d->N > 0 && d->IH > 0 && d->IW > 0 && d->OH > 0 && d->OW > 0, DN_ERR_BAD_ARG, "bad sizes");
+  int cin_total = 0;
+  for (int i = 0; i < d->n_in; ++i) {
+    DN_REQUIRE(d->in[i].C > 0 && (d->in[i].up_shift == 0 || d->in[i].up_shift == 1), DN_ERR_BAD_ARG, "operand %d", i);
+    cin_total += d->in[i].C;
+  }
+  p->N = d->N;
+  p->R = d->R;
+  p->S = d->S;
+  p->act = d->act;
+  p->act_p0 = d->act_p0;
+  p->act_p1 = d->act_p1;
+  p->bias = d->bias;
+  p->w = d->w_packed;
+  p->bn_partial = d->bn_partial;
+  const int st = d->stride, pad = d->pad;
+
+  if (for_wgrad) {
+    DN_REQUIRE(d->kind == DN_CONV_FWD || d->kind == DN_CONVT_FWD, DN_ERR_BAD_ARG, "wgrad needs a forward descriptor");
+    p->nphases = 1;
+    p->osy = p->osx = 1;
+    p->sy = p->sx = st;
+    p->n_is_dim0 = 1;
+    int nt = 0;
+    for (int r = 0; r < d->R; ++r)
+      for (int s = 0; s < d->S; ++s) {
+        p->tdy[nt] = (int8_t)(r - pad);
+        p->tdx[nt] = (int8_t)(s - pad);
+        p->tr[nt] = (int8_t)r;
+        p->ts[nt] = (int8_t)s;
+        ++nt;
+      }
+    p->ph[0].ntaps = nt;
+    if (d->kind == DN_CONV_FWD) {
+      // dW[co][ci][r][s] = sum_{oy,ox} dy[oy,ox][co] * x[oy*st - pad + r, ..][ci]
+      int cout = 0;
+      for (int i = 0; i < d->n_out; ++i) cout += d->out[i].C;
+      DN_REQUIRE(cout > 0, DN_ERR_BAD_ARG, "wgrad: forward descriptor has no output channels");
+      p->GH = d->OH;
+      p->GW = d->OW;
+      p->IH = d->IH;
+      p->IW = d->IW;
+      p->Ntot = cout;
+      p->D0 = cout;
+      p->D1 = cin_total;
+      p->n_in = d->n_in;
+      int off = 0;
+      for (int i = 0; i < d->n_in; ++i) {
+        fill_operand(&p->in[i], &d->in[i], off);
+        off += d->in[i].C;
+      }
+    } else {
+      // dWt[ci][co][r][s] = sum_{iy,ix} x[iy,ix][ci] * dy[iy*st - pad + r, ..][co]   (operand filled by caller)
+      DN_REQUIRE(d->n_in == 1 && d->in[0].scale == nullptr && d->in[0].up_shift == 0, DN_ERR_UNSUPPORTED,
+                 "conv-transpose wgrad needs one plain input operand");
+      int cout = 0;
+      for (int i = 0; i < d->n_out; ++i) cout += d->out[i].C;
+      p->GH = d->IH;
+      p->GW = d->IW;
+      p->IH = d->OH;
+      p->IW = d->OW;
+      p->Ntot = cin_total;
+      p->D0 = cin_total;
+      p->D1 = cout;
+      p->n_in = 1;   // the dy operand; data pointer set by the caller
+      p->in[0].C = cout;
+      p->in[0].ch_off = 0;
+    }
+  } else {
+    int ntot = 0;
+    DN_REQUIRE(d->n_out >= 1 && d->n_out <= DN_MAX_OPERANDS, DN_ERR_BAD_ARG, "n_out %d", d->n_out);
+    for (int i = 0; i < d->n_out; ++i) {
+      DN_REQUIRE(d->out[i].C > 0 && d->out[i].data != nullptr, DN_ERR_BAD_ARG, "result %d", i);
+      ntot += d->out[i].C;
+    }
+    p->Ntot = ntot;
+    p->n_in = d->n_in;
+    p->n_out = d->n_out;
+    p->IH = d->IH;
+    p->IW = d->IW;
+    p->OH = d->OH;
+    p->OW = d->OW;
+    int off = 0;
+    for (int i = 0; i < d->n_in; ++i) {
+      fill_operand(&p->in[i], &d->in[i], off);
+      off += d->in[i].C;
+    }
+    const bool gather = (d->kind == DN_CONV_FWD || d->kind == DN_CONVT_DGRAD);
+    if (gather) {
+      p->nphases = 1;
+      p->GH = d->OH;
+      p->GW = d->OW;
+      p->sy = p->sx = st;
+      p->osy = p->osx = 1;
+      p->n_is_dim0 = 1;
+      p->D0 = ntot;
+      p->D1 = cin_total;
+      int nt = 0;
+      for (int r = 0; r < d->R; ++r)
+        for (int s = 0; s < d->S; ++s) {
+          p->tdy[nt] = (int8_t)(r - pad);
+          p->tdx[nt] = (int8_t)(s - pad);
+          p->tr[nt] = (int8_t)r;
+          p->ts[nt] = (int8_t)s;
+          ++nt;
+        }
+      p->ph[0].ntaps = nt;
+    } else {
+      // scatter family: out pixel o = g*st + ph; contributing kernel rows r == (ph + pad) mod st; in pixel = g + (ph+pad-r)/st
+      p->nphases = st * st;
+      p->GH = ceil_div(d->OH, st);
+      p->GW = ceil_div(d->OW, st);
+      p->sy = p->sx = 1;
+      p->osy = p->osx = st;
+      p->n_is_dim0 = 0;
+      p->D0 = cin_total;
+      p->D1 = ntot;
+      int nt = 0;
+      for (int py = 0; py < st; ++py)
+        for (int px = 0; px < st; ++px) {
+          KPhase& ph = p->ph[py * st + px];
+          ph.tap0 = nt;
+          ph.ooy = py;
+          ph.oox = px;
+          for (int r = 0; r < d->R; ++r) {
+            if (((py + pad - r) % st + st) % st != 0) continue;
+            for (int s = 0; s < d->S; ++s) {
+              if (((px + pad - s) % st + st) % st != 0) continue;
+              DN_REQUIRE(nt < kMaxTaps, DN_ERR_UNSUPPORTED, "too many taps");
+              p->tdy[nt] = (int8_t)floor_div(py + pad - r, st);
+              p->tdx[nt] = (int8_t)floor_div(px + pad - s, st);
+              p->tr[nt] = (int8_t)r;
+              p->ts[nt] = (int8_t)s;
+              ++nt;
+            }
+          }
+          ph.ntaps = nt - ph.tap0;
+        }
+    }
+    for (int i = 0; i < d->n_out; ++i) {
+      KResult& r = p->out[i];
+      r.p = d->out[i].data;
+      r.C = d->out[i].C;
+      r.accumulate = d->out[i].accumulate;
+      r.sn = d->out[i].stride_n;
+      r.sh = d->out[i].stride_h;
+      r.sw = d->out[i].stride_w;
+      r.n_begin = (i == 0) ? 0 : p->out[i - 1].n_begin + p->out[i - 1].C;
+      r.linear = (p->nphases == 1 && r.sh == (long long)d->OW * r.sw && r.sn == (long long)d->OH * r.sh) ? 1 : 0;
+    }
+    DN_REQUIRE(d->bn_partial == nullptr || (d->n_out == 1 && p->nphases == 1), DN_ERR_UNSUPPORTED,
+               "bn_partial needs a single un-phased result");
+  }
+  long long m = (long long)p->N * p->GH * p->GW;
+  DN_REQUIRE(m > 0 && m < (1ll << 31), DN_ERR_UNSUPPORTED, "grid too large");
+  p->M = (int)m;
+  p->BN = pick_bn(p->Ntot);
+  p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
+  long long woff = 0;
+  for (int z = 0; z < p->nphases; ++z) {
+    int nch = 0;
+    for (int i = 0; i < p->n_in; ++i) nch += ceil_div(p->ph[z].ntaps * p->in[i].C, kChunk);
+    p->ph[z].nchunks = nch;
+    p->ph[z].w_off = woff;
+    woff += (long long)p->Npad * nch * kChunk;
+  }
+  return DN_OK;
+}
+
+}  // namespace dn
+
+extern "C" {
+
+int dn_version(void) { return 1; }
+
+const char* dn_last_error(void) { return dn::g_err; }
+
+int dn_device_arch_ok(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    dn::set_error("hipGetDevice failed (no HIP device?)");
+    return DN_ERR_LAUNCH;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    dn::set_error("hipGetDeviceProperties failed");
+    return DN_ERR_LAUNCH;
+  }
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d) {
+  dn::IgemmParams p;
+  if (dn::build_plan(d, false, &p) != DN_OK) return -1;
+  const dn::KPhase& last = p.ph[p.nphases - 1];
+  return last.w_off + (int64_t)p.Npad * last.nchunks * dn::kChunk;
+}
+
+int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d) {
+  dn::IgemmParams p;
+  if (dn::build_plan(d, false, &p) != DN_OK) return -1;
+  return (p.M + 127) / 128;
+}
+
+// Test/diagnostic hook (host only, no device work): dump the plan as int32s.
+//  [0]=nphases [1]=GH [2]=GW [3]=sy [4]=osy [5]=Ntot [6]=Npad [7]=BN [8]=n_is_dim0 [9]=D0 [10]=D1 [11]=M
+//  then per phase: ntaps, ooy, oox, nchunks, w_off, followed by ntaps x (dy, dx, r, s)
+int dn_debug_conv_plan(const dn_conv_desc* d, int for_wgrad, int32_t* out, int cap) {
+  dn::IgemmParams p;
+  int rc = dn::build_plan(d, for_wgrad != 0, &p);
+  if (rc != DN_OK) return rc;
+  int n = 0;
+  auto put = [&](long long v) {
+    if (n < cap) out[n] = (int32_t)v;
+    ++n;
+  };
+  put(p.nphases); put(p.GH); put(p.GW); put(p.sy); put(p.osy); put(p.Ntot); put(p.Npad); put(p.BN);
+  put(p.n_is_dim0); put(p.D0); put(p.D1); put(p.M);
+  for (int z = 0; z < p.nphases; ++z) {
+    const dn::KPhase& ph = p.ph[z];
+    put(ph.ntaps); put(ph.ooy); put(ph.oox); put(ph.nchunks); put(ph.w_off);
+    for (int t = 0; t < ph.ntaps; ++t) {
+      put(p.tdy[ph.tap0 + t]); put(p.tdx[ph.tap0 + t]); put(p.tr[ph.tap0 + t]); put(p.ts[ph.tap0 + t]);
+    }
+  }
+  return n;
+}
+
+}  // extern "C"

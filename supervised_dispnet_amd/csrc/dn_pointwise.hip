@@ -1,0 +1,574 @@
+// HBM-bound NHWC kernels around the convolutions: BatchNorm statistics / apply / backward, fused BN+ReLU+MaxPool,
+// activation backward with bias-gradient column sums, 1-channel upsamples, reciprocal, Adam.  gfx950 only.
+// All column reductions are two-stage (per-block partial rows in a caller workspace, then a finalize) so results are
+// deterministic and no float atomics are used.
+#include "dn_internal.h"
+
+namespace dn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kMaxReduceBlocks = 1024;
+
+static inline int ew_blocks(long long n_items) {
+  long long b = (n_items + kThreads - 1) / kThreads;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static inline int reduce_blocks(long long rows, int C) {
+  int V = (C % 4 == 0) ? 4 : 1;
+  int groups = C / V;
+  int tpr = 1;
+  while (tpr < groups && tpr < kThreads) tpr <<= 1;
+  int rpi = kThreads / tpr;
+  long long b = (rows + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
+  if (b > kMaxReduceBlocks) b = kMaxReduceBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------------------------- generic column-reduce skeleton
+// Op::apply<V>(row, c0, acc[V][NACC]) does the element-wise work for channels [c0, c0+V) of `row` and accumulates.
+template <class Op, int V>
+__global__ void __launch_bounds__(kThreads) colreduce_kernel(Op op, long long rows, int C, float* __restrict__ partial) {
+  constexpr int NACC = Op::NACC;
+  const int groups = C / V;
+  int tpr = 1;
+  while (tpr < groups && tpr < kThreads) tpr <<= 1;
+  const int rpi = kThreads / tpr;
+  const int rl = threadIdx.x / tpr, gi = threadIdx.x % tpr;
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long rbeg = blockIdx.x * per;
+  const long long rend = (rbeg + per < rows) ? rbeg + per : rows;
+  __shared__ float red[kThreads * V * NACC];
+  for (int g0 = 0; g0 < groups; g0 += tpr) {
+    const int grp = g0 + gi;
+    float acc[V][NACC];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[v][a] = 0.f;
+    if (grp < groups)
+      for (long long r = rbeg + rl; r < rend; r += rpi) op.template apply<V>(r, grp * V, acc);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) red[(threadIdx.x * V + v) * NACC + a] = acc[v][a];
+    __syncthreads();
+    if (rl == 0 && grp < groups) {
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          float s = 0.f;
+          for (int q = 0; q < rpi; ++q) s += red[((q * tpr + gi) * V + v) * NACC + a];
+          partial[((long long)blockIdx.x * C + grp * V + v) * NACC + a] = s;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+template <class Op>
+static int launch_colreduce(const Op& op, long long rows, int C, float* partial, hipStream_t s, const char* what) {
+  const int blocks = reduce_blocks(rows, C);
+  if (C % 4 == 0)
+    hipLaunchKernelGGL((colreduce_kernel<Op, 4>), dim3(blocks), dim3(kThreads), 0, s, op, rows, C, partial);
+  else
+    hipLaunchKernelGGL((colreduce_kernel<Op, 1>), dim3(blocks), dim3(kThreads), 0, s, op, rows, C, partial);
+  return check_launch(what);
+}
+
+template <int V>
+struct Vec {
+  float v[V];
+};
+template <int V>
+__device__ __forceinline__ Vec<V> ldv(const float* p) {
+  Vec<V> r;
+  if constexpr (V == 4) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = t[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = p[i];
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const Vec<V>& r) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) p[i] = r.v[i];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------- BN statistics
+// one block per channel: fp64 accumulation of the per-tile fp32 partial sums
+__global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                               const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                               float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
+                                                               float* shift) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += kThreads) {
+    s1 += (double)partial[((long long)r * C + c) * 2 + 0];
+    s2 += (double)partial[((long long)r * C + c) * 2 + 1];
+  }
+  __shared__ double red[2][kThreads];
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double macc = red[0][0] / count;
+    double var = red[1][0] / count - macc * macc;   // biased; bias shift does not change it
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)(macc + (conv_bias ? (double)conv_bias[c] : 0.0));
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float invstd = 1.f / sqrtf(rv[c] + eps);
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+
+// --------------------------------------------------------------------------------------- BN + ReLU + MaxPool 2x2
+__global__ void __launch_bounds__(kThreads) bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, int N, int H, int W, int C,
+                                                                    float* __restrict__ pooled, uint8_t* __restrict__ idx) {
+  const int PH = H / 2, PW = W / 2, G = C / 4;
+  const long long total = (long long)N * PH * PW * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int g = (int)(i % G);
+    long long pix = i / G;
+    const int px = (int)(pix % PW);
+    pix /= PW;
+    const int py = (int)(pix % PH), n = (int)(pix / PH);
+    const int c = g * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    const float* base = y + (((long long)n * H + 2 * py) * W + 2 * px) * C + c;
+    f32x4 best;
+    int bi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((long long)(q >> 1) * W + (q & 1)) * C);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = fmaxf(0.f, v[e] * sc[e] + sh[e]);
+        if (q == 0 || a > best[e]) {
+          best[e] = a;
+          bi[e] = q;
+        }
+      }
+    }
+    const long long o = i * 4;
+    *reinterpret_cast<f32x4*>(pooled + o) = best;
+    uchar4 code;
+    code.x = (uint8_t)(bi[0] | (best[0] > 0.f ? 4 : 0));
+    code.y = (uint8_t)(bi[1] | (best[1] > 0.f ? 4 : 0));
+    code.z = (uint8_t)(bi[2] | (best[2] > 0.f ? 4 : 0));
+    code.w = (uint8_t)(bi[3] | (best[3] > 0.f ? 4 : 0));
+    *reinterpret_cast<uchar4*>(idx + o) = code;
+  }
+}
+
+struct PoolBwdOp {
+  static constexpr int NACC = 2;
+  const float* dpooled;
+  const uint8_t* idx;
+  const float* y;
+  const float* mean;
+  const float* invstd;
+  float* dz;
+  int PH, PW, H, W, C;
+  template <int V>
+  __device__ __forceinline__ void apply(long long row, int c0, float (&acc)[V][2]) const {
+    const int px = (int)(row % PW);
+    long long t = row / PW;
+    const int py = (int)(t % PH), n = (int)(t / PH);
+    const Vec<V> dp = ldv<V>(dpooled + row * C + c0);
+    const Vec<V> mu = ldv<V>(mean + c0), is = ldv<V>(invstd + c0);
+    const long long base = (((long long)n * H + 2 * py) * W + 2 * px) * C + c0;
+    Vec<V> out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < V; ++e) out[q].v[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int code = idx[row * C + c0 + e];
+      if (code & 4) {
+        const int q = code & 3;
+        const float g = dp.v[e];
+        const float yv = y[base + ((long long)(q >> 1) * W + (q & 1)) * C + e];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          if (qq == q) out[qq].v[e] = g;
+        acc[e][0] += g;
+        acc[e][1] += g * (yv - mu.v[e]) * is.v[e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stv<V>(dz + base + ((long long)(q >> 1) * W + (q & 1)) * C, out[q]);
+  }
+};
+
+struct BnReluBwdOp {
+  static constexpr int NACC = 2;
+  float* da_dz;
+  const float* y;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  int C;
+  template <int V>
+  __device__ __forceinline__ void apply(long long row, int c0, float (&acc)[V][2]) const {
+    const long long o = row * C + c0;
+    Vec<V> g = ldv<V>(da_dz + o);
+    const Vec<V> yv = ldv<V>(y + o), sc = ldv<V>(scale + c0), sh = ldv<V>(shift + c0), mu = ldv<V>(mean + c0), is = ldv<V>(invstd + c0);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float dz = (yv.v[e] * sc.v[e] + sh.v[e] > 0.f) ? g.v[e] : 0.f;
+      g.v[e] = dz;
+      acc[e][0] += dz;
+      acc[e][1] += dz * (yv.v[e] - mu.v[e]) * is.v[e];
+    }
+    stv<V>(da_dz + o, g);
+  }
+};
+
+struct ActBwdOp {
+  static constexpr int NACC = 1;
+  float* g;
+  const float* y_post;
+  int act;
+  float p0, p1;
+  int C;
+  template <int V>
+  __device__ __forceinline__ void apply(long long row, int c0, float (&acc)[V][1]) const {
+    const long long o = row * C + c0;
+    Vec<V> gv = ldv<V>(g + o);
+    if (act != DN_ACT_NONE) {
+      const Vec<V> yv = ldv<V>(y_post + o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float yp = yv.v[e];
+        float d = 1.f;
+        if (act == DN_ACT_RELU) d = yp > 0.f ? 1.f : 0.f;
+        else if (act == DN_ACT_LEAKY) d = yp > 0.f ? 1.f : p0;
+        else if (act == DN_ACT_ELU) d = yp > 0.f ? 1.f : (yp + 1.f);
+        else if (act == DN_ACT_SIGMOID_AFFINE) {
+          const float sg = (yp - p1) / p0;
+          d = p0 * sg * (1.f - sg);
+        }
+        gv.v[e] *= d;
+      }
+      stv<V>(g + o, gv);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e][0] += gv.v[e];
+  }
+};
+
+// out[c] = sum_rows partial[(row*C + c)*stride + offset]
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, int stride, int offset, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)partial[((long long)r * C + c) * stride + offset];
+  out[c] = (float)s;
+}
+
+__global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(float* __restrict__ dz_dy, const float* __restrict__ y,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, long long rows, int C, float inv_count) {
+  const int G = C / 4;
+  const long long total = rows * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int c = (int)(i % G) * 4;
+    const long long o = i * 4;
+    f32x4 dz = *reinterpret_cast<const f32x4*>(dz_dy + o);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), dg = *reinterpret_cast<const f32x4*>(dgamma + c),
+                db = *reinterpret_cast<const f32x4*>(dbeta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xhat = (yv[e] - mu[e]) * is[e];
+      dz[e] = ga[e] * is[e] * (dz[e] - db[e] * inv_count - xhat * dg[e] * inv_count);
+    }
+    *reinterpret_cast<f32x4*>(dz_dy + o) = dz;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- 1-channel helpers
+__global__ void upsample2x_nearest_bwd_kernel(const float* __restrict__ dfull, int N, int h, int w, float* __restrict__ dlow, int accumulate) {
+  const long long total = (long long)N * h * w;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const long long t = i / w;
+    const int yy = (int)(t % h), n = (int)(t / h);
+    const float* b = dfull + (((long long)n * 2 * h + 2 * yy) * 2 * w + 2 * x);
+    float s = (b[0] + b[1]) + (b[2 * w] + b[2 * w + 1]);
+    if (accumulate) s += dlow[i];
+    dlow[i] = s;
+  }
+}
+
+__device__ __forceinline__ void bilin_src(int o, int in_size, int* i0, int* i1, float* l1) {
+  float src = 0.5f * ((float)o + 0.5f) - 0.5f;   // scale 1/2, align_corners = False
+  if (src < 0.f) src = 0.f;
+  int a = (int)src;
+  if (a > in_size - 1) a = in_size - 1;
+  *i0 = a;
+  *i1 = a + (a < in_size - 1 ? 1 : 0);
+  *l1 = src - (float)a;
+}
+
+__global__ void upsample2x_bilinear_fwd_kernel(const float* __restrict__ low, int N, int h, int w, int OH, int OW, float* __restrict__ out) {
+  const long long total = (long long)N * OH * OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const long long t = i / OW;
+    const int oy = (int)(t % OH), n = (int)(t / OH);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_src(oy, h, &y0, &y1, &ly);
+    bilin_src(ox, w, &x0, &x1, &lx);
+    const float* b = low + (long long)n * h * w;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    out[i] = hy * (hx * b[y0 * w + x0] + lx * b[y0 * w + x1]) + ly * (hx * b[y1 * w + x0] + lx * b[y1 * w + x1]);
+  }
+}
+
+__global__ void upsample2x_bilinear_bwd_kernel(const float* __restrict__ dout, int N, int h, int w, int OH, int OW, float* __restrict__ dlow,
+                                               int accumulate) {
+  const long long total = (long long)N * h * w;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const long long t = i / w;
+    const int yy = (int)(t % h), n = (int)(t / h);
+    const float* g = dout + (long long)n * OH * OW;
+    float s = 0.f;
+    for (int oy = 2 * yy - 2; oy <= 2 * yy + 2; ++oy) {
+      if (oy < 0 || oy >= OH) continue;
+      int y0, y1;
+      float ly;
+      bilin_src(oy, h, &y0, &y1, &ly);
+      float wy = 0.f;
+      if (y0 == yy) wy += 1.f - ly;
+      if (y1 == yy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = 2 * x - 2; ox <= 2 * x + 2; ++ox) {
+        if (ox < 0 || ox >= OW) continue;
+        int x0, x1;
+        float lx;
+        bilin_src(ox, w, &x0, &x1, &lx);
+        float wx = 0.f;
+        if (x0 == x) wx += 1.f - lx;
+        if (x1 == x) wx += lx;
+        if (wx != 0.f) s += wy * wx * g[(long long)oy * OW + ox];
+      }
+    }
+    if (accumulate) s += dlow[i];
+    dlow[i] = s;
+  }
+}
+
+__global__ void reciprocal_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = 1.f / x[i];
+}
+__global__ void reciprocal_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = y[i];
+    dx[i] = -dy[i] * v * v;
+  }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// torch.optim.Adam (single-tensor formulation, amsgrad off): lerp for exp_avg, addcmul for exp_avg_sq,
+// denom = sqrt(v)/sqrt(bc2) + eps, p -= (lr/bc1) * m / denom.
+__global__ void __launch_bounds__(kThreads) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long long n, float beta1, float beta2, float eps,
+                                                        float weight_decay, float step_size, float bc2_sqrt, float grad_scale) {
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+    float gi = g[i] * grad_scale;
+    const float pi = p[i];
+    if (weight_decay != 0.f) gi += weight_decay * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    vi = vi * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+extern "C" {
+
+int32_t dn_reduce_blocks(int64_t rows, int32_t C) { return reduce_blocks(rows, C); }
+
+int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count, const float* conv_bias, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                   float* scale, float* shift, dn_stream_t stream) {
+  DN_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, DN_ERR_BAD_ARG,
+             "dn_bn_finalize: bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, as_stream(stream), partial, rows, C, (double)count, conv_bias, gamma,
+                     beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  return check_launch("bn_finalize_kernel");
+}
+
+int dn_bn_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                      float* scale, float* shift, dn_stream_t stream) {
+  DN_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, DN_ERR_BAD_ARG, "dn_bn_eval_affine: bad argument");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, gamma, beta, running_mean,
+                     running_var, eps, scale, shift);
+  return check_launch("bn_eval_affine_kernel");
+}
+
+int dn_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, int32_t N, int32_t H, int32_t W, int32_t C, float* pooled,
+                        uint8_t* idx, dn_stream_t stream) {
+  DN_REQUIRE(y && scale && shift && pooled && idx, DN_ERR_BAD_ARG, "dn_bn_relu_pool_fwd: null pointer");
+  DN_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && N > 0, DN_ERR_UNSUPPORTED, "dn_bn_relu_pool_fwd: need C%%4==0 and even H,W");
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, as_stream(stream), y, scale, shift, N, H, W, C,
+                     pooled, idx);
+  return check_launch("bn_relu_pool_fwd_kernel");
+}
+
+int dn_bn_relu_pool_bwd(const float* dpooled, const uint8_t* idx, const float* y, const float* mean, const float* invstd, int32_t N,
+                        int32_t H, int32_t W, int32_t C, float* dz, float* partial, dn_stream_t stream) {
+  DN_REQUIRE(dpooled && idx && y && mean && invstd && dz && partial, DN_ERR_BAD_ARG, "dn_bn_relu_pool_bwd: null pointer");
+  DN_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, DN_ERR_UNSUPPORTED, "dn_bn_relu_pool_bwd: need C%%4==0 and even H,W");
+  PoolBwdOp op{dpooled, idx, y, mean, invstd, dz, H / 2, W / 2, H, W, C};
+  return launch_colreduce(op, (long long)N * (H / 2) * (W / 2), C, partial, as_stream(stream), "bn_relu_pool_bwd");
+}
+
+int dn_bn_relu_bwd_reduce(float* da_dz, const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                          int64_t rows, int32_t C, float* partial, dn_stream_t stream) {
+  DN_REQUIRE(da_dz && y && scale && shift && mean && invstd && partial && rows > 0 && C > 0, DN_ERR_BAD_ARG,
+             "dn_bn_relu_bwd_reduce: bad argument");
+  BnReluBwdOp op{da_dz, y, scale, shift, mean, invstd, C};
+  return launch_colreduce(op, rows, C, partial, as_stream(stream), "bn_relu_bwd_reduce");
+}
+
+int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float* invstd, const float* gamma, const float* partial,
+                    int32_t partial_rows, int64_t rows, int32_t C, float* dgamma, float* dbeta, dn_stream_t stream) {
+  DN_REQUIRE(dz_dy && y && mean && invstd && gamma && partial && dgamma && dbeta && rows > 0, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: bad argument");
+  DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply: need C%%4==0");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, partial_rows, C, 2, 0, dbeta);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, partial_rows, C, 2, 1, dgamma);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, dz_dy, y, mean, invstd, gamma, dgamma, dbeta,
+                     (long long)rows, C, (float)(1.0 / (double)rows));
+  return check_launch("bn_bwd_apply");
+}
+
+int dn_act_bwd_reduce(float* g, const float* y_post, int32_t act, float p0, float p1, int64_t rows, int32_t C, float* partial,
+                      dn_stream_t stream) {
+  DN_REQUIRE(g && partial && rows > 0 && C > 0 && (act == DN_ACT_NONE || y_post), DN_ERR_BAD_ARG, "dn_act_bwd_reduce: bad argument");
+  ActBwdOp op{g, y_post, act, p0, p1, C};
+  return launch_colreduce(op, rows, C, partial, as_stream(stream), "act_bwd_reduce");
+}
+
+int dn_colsum_finalize(const float* partial, int32_t rows, int32_t C, int32_t stride, int32_t offset, float* out, dn_stream_t stream) {
+  DN_REQUIRE(partial && out && rows > 0 && C > 0 && stride > 0 && offset >= 0 && offset < stride, DN_ERR_BAD_ARG, "dn_colsum_finalize: bad argument");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), partial, rows, C, stride, offset, out);
+  return check_launch("colsum_finalize_kernel");
+}
+
+int dn_upsample2x_nearest_bwd(const float* dfull, int32_t N, int32_t h, int32_t w, float* dlow, int32_t accumulate, dn_stream_t stream) {
+  DN_REQUIRE(dfull && dlow && N > 0 && h > 0 && w > 0, DN_ERR_BAD_ARG, "dn_upsample2x_nearest_bwd: bad argument");
+  hipLaunchKernelGGL(upsample2x_nearest_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dfull, N, h, w,
+                     dlow, accumulate);
+  return check_launch("upsample2x_nearest_bwd_kernel");
+}
+
+int dn_upsample2x_bilinear_fwd(const float* low, int32_t N, int32_t h, int32_t w, int32_t OH, int32_t OW, float* out, dn_stream_t stream) {
+  DN_REQUIRE(low && out && N > 0 && OH <= 2 * h && OW <= 2 * w && OH > 0 && OW > 0, DN_ERR_BAD_ARG, "dn_upsample2x_bilinear_fwd: bad argument");
+  hipLaunchKernelGGL(upsample2x_bilinear_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW)), dim3(256), 0, as_stream(stream), low, N, h, w,
+                     OH, OW, out);
+  return check_launch("upsample2x_bilinear_fwd_kernel");
+}
+
+int dn_upsample2x_bilinear_bwd(const float* dout, int32_t N, int32_t h, int32_t w, int32_t OH, int32_t OW, float* dlow, int32_t accumulate,
+                               dn_stream_t stream) {
+  DN_REQUIRE(dout && dlow && N > 0 && OH <= 2 * h && OW <= 2 * w && OH > 0 && OW > 0, DN_ERR_BAD_ARG, "dn_upsample2x_bilinear_bwd: bad argument");
+  hipLaunchKernelGGL(upsample2x_bilinear_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dout, N, h, w,
+                     OH, OW, dlow, accumulate);
+  return check_launch("upsample2x_bilinear_bwd_kernel");
+}
+
+int dn_reciprocal_fwd(const float* x, float* y, int64_t n, dn_stream_t stream) {
+  DN_REQUIRE(x && y && n > 0, DN_ERR_BAD_ARG, "dn_reciprocal_fwd: bad argument");
+  hipLaunchKernelGGL(reciprocal_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x, y, (long long)n);
+  return check_launch("reciprocal_fwd_kernel");
+}
+
+int dn_reciprocal_bwd(const float* dy, const float* y, float* dx, int64_t n, dn_stream_t stream) {
+  DN_REQUIRE(dy && y && dx && n > 0, DN_ERR_BAD_ARG, "dn_reciprocal_bwd: bad argument");
+  hipLaunchKernelGGL(reciprocal_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), dy, y, dx, (long long)n);
+  return check_launch("reciprocal_bwd_kernel");
+}
+
+int dn_fill(float* p, float value, int64_t n, dn_stream_t stream) {
+  DN_REQUIRE(p && n >= 0, DN_ERR_BAD_ARG, "dn_fill: bad argument");
+  if (n == 0) return DN_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), p, value, (long long)n);
+  return check_launch("fill_kernel");
+}
+
+int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 int32_t step, double grad_scale, dn_stream_t stream) {
+  DN_REQUIRE(p && g && m && v && n > 0 && step >= 1, DN_ERR_BAD_ARG, "dn_adam_step: bad argument");
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, as_stream(stream), p, g, m, v, (long long)n, (float)beta1, (float)beta2, (float)eps,
+                     (float)weight_decay, step_size, bc2_sqrt, (float)grad_scale);
+  return check_launch("adam_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+"""Host-side execution engine: NHWC activation records, a define-by-run backward tape at *block* granularity, and the
+launch helpers that drive libdispnet_hip.so through its C ABI.
+
+PyTorch is plumbing here (device memory, the caching allocator, streams, autograd hand-off at the model boundary).
+Every numerically significant operation is a HIP kernel launched through supervised_dispnet_amd._lib.
+
+Design notes
+  * A model's forward is ordinary Python that calls the block helpers below.  Each helper launches its forward kernels
+    and, when recording, appends one closure to the tape; the model's backward runs the tape in reverse.  There is no
+    tracing compiler and no graph rewriting: fusion decisions are explicit in the helpers (BN-apply+ReLU of the producer
+    is applied by the consumer's loader, concat and nearest-upsample are virtual, bias/activation/BN-statistics live in
+    the conv epilogue).
+  * `Act.grad` always holds the gradient w.r.t. the LOGICAL value of the activation (after its pending transform).
+    The first writer overwrites, later writers accumulate (skip connections have two consumers).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID_AFFINE, CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD,
+                   ConvDesc)
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# bumped by optimizers that update parameters behind autograd's back (FusedAdam); part of the packed-weight cache key
+PARAM_EPOCH = 0
+
+
+def bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the MI355X (got a %s tensor); this package is the HIP path only and has no "
+                           "CPU fallback" % (what, t.device))
+
+
+class Act:
+    """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
+    __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
+                 "partial_rows", "needs_grad", "strides")
+
+    def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
+        self.t = t
+        self.N, self.H, self.W, self.C = N, H, W, C
+        self.scale = self.shift = self.mean = self.invstd = None
+        self.grad = None
+        self.grad_is_dz = False
+        self.partial = None
+        self.partial_rows = 0
+        self.needs_grad = needs_grad
+        self.strides = strides or (H * W * C, W * C, C, 1)   # (n, h, w, c) element strides
+
+    @property
+    def rows(self):
+        return self.N * self.H * self.W
+
+    @staticmethod
+    def from_nchw_image(x):
+        """User image [N,C,H,W] (any strides) consumed in place through operand strides -- no transpose pass."""
+        n, c, h, w = x.shape
+        sn, sc, sh, sw = x.stride()
+        return Act(x, n, h, w, c, strides=(sn, sh, sw, sc), needs_grad=False)
+
+    def new_like(self):
+        return torch.empty((self.N, self.H, self.W, self.C), dtype=torch.float32, device=self.t.device)
+
+
+class Tape:
+    def __init__(self, recording):
+        self.recording = recording
+        self.steps = []
+
+    def push(self, fn):
+        if self.recording:
+            self.steps.append(fn)
+
+    def run_backward(self):
+        for fn in reversed(self.steps):
+            fn()
+        self.steps = []
+
+
+class Piece:
+    """One operand of a (virtually concatenated) conv input: an Act, optionally nearest-x2 upsampled on the fly."""
+    __slots__ = ("act", "up")
+
+    def __init__(self, act, up=False):
+        self.act, self.up = act, up
+
+    @property
+    def C(self):
+        return self.act.C
+
+
+def _fill_operand(op, piece):
+    a = piece.act
+    op.data = a.t.data_ptr()
+    op.C = a.C
+    op.up_shift = 1 if piece.up else 0
+    op.stride_n, op.stride_h, op.stride_w, op.stride_c = a.strides
+    op.scale = _ptr(a.scale)
+    op.shift = _ptr(a.shift)
+
+
+def _fill_result(res, tensor, C_, H, W, accumulate, ld=None):
+    ld = ld or C_
+    res.data = tensor.data_ptr()
+    res.C = C_
+    res.accumulate = 1 if accumulate else 0
+    res.stride_w = ld
+    res.stride_h = W * ld
+    res.stride_n = H * W * ld
+
+
+class ConvLayer:
+    """Runtime companion of one nn.Conv2d / nn.ConvTranspose2d: packed-weight caches + descriptor builders."""
+
+    def __init__(self, module, transposed=False, in_channels_split=None):
+        self.m = module
+        self.transposed = transposed
+        self.R, self.S = module.kernel_size
+        self.stride = module.stride[0]
+        self.pad = module.padding[0]
+        self.out_pad = module.output_padding[0] if transposed else 0
+        self.Cin = module.in_channels
+        self.Cout = module.out_channels
+        self._packed = {}
+
+    # -- geometry
+    def out_size(self, H, W):
+        if self.transposed:
+            return ((H - 1) * self.stride - 2 * self.pad + self.R + self.out_pad,
+                    (W - 1) * self.stride - 2 * self.pad + self.S + self.out_pad)
+        return ((H + 2 * self.pad - self.R) // self.stride + 1, (W + 2 * self.pad - self.S) // self.stride + 1)
+
+    def _desc(self, kind, N, IH, IW, OH, OW):
+        d = ConvDesc()
+        d.kind = kind
+        d.N, d.IH, d.IW, d.OH, d.OW = N, IH, IW, OH, OW
+        d.R, d.S, d.stride, d.pad = self.R, self.S, self.stride, self.pad
+        return d
+
+    def packed(self, kind, desc):
+        """Packed weights for `kind`, re-laid only when the parameter changed."""
+        w = self.m.weight
+        key = (w.data_ptr(), w._version, PARAM_EPOCH, tuple(desc.in_[i].C for i in range(desc.n_in)),
+               tuple(desc.out[i].C for i in range(desc.n_out)))
+        hit = self._packed.get(kind)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lib = _lib.load()
+        n = lib.dn_conv_packed_weight_elems(C.byref(desc))
+        if n < 0:
+            raise _lib.DispnetHipError("dn_conv_packed_weight_elems: " + _lib.last_error())
+        buf = torch.empty(max(int(n), 1), dtype=torch.float32, device=w.device)
+        wc = w.detach()
+        if not wc.is_contiguous():
+            wc = wc.contiguous()
+        _lib.call("dn_conv_pack_weights", C.byref(desc), wc.data_ptr(), buf.data_ptr(), _stream())
+        self._packed[kind] = (key, buf)
+        return buf
+
+
+def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None):
+    """Forward of conv / conv-transpose over virtually concatenated `pieces`.  Returns (y tensor NHWC, partial, rows)."""
+    a0 = pieces[0].act
+    N = a0.N
+    IH = a0.H * (2 if pieces[0].up else 1)
+    IW = a0.W * (2 if pieces[0].up else 1)
+    OH, OW = out_hw or layer.out_size(IH, IW)
+    kind = CONVT_FWD if layer.transposed else CONV_FWD
+    d = layer._desc(kind, N, IH, IW, OH, OW)
+    d.n_in = len(pieces)
+    for i, p in enumerate(pieces):
+        _fill_operand(d.in_[i], p)
+    y = torch.empty((N, OH, OW, layer.Cout), dtype=torch.float32, device=a0.t.device)
+    d.n_out = 1
+    _fill_result(d.out[0], y, layer.Cout, OH, OW, False)
+    d.w_packed = layer.packed(kind, d).data_ptr()
+    b = layer.m.bias
+    d.bias = _ptr(b.detach()) if b is not None else None
+    d.act, d.act_p0, d.act_p1 = act, p0, p1
+    partial, rows = None, 0
+    if bn_stats:
+        rows = _lib.load().dn_conv_bn_partial_rows(C.byref(d))
+        partial = torch.empty((rows, layer.Cout, 2), dtype=torch.float32, device=y.device)
+        d.bn_partial = partial.data_ptr()
+    _lib.call("dn_convT2d_fwd" if layer.transposed else "dn_conv2d_fwd", C.byref(d), _stream())
+    return y, partial, rows
+
+
+def conv_wgrad(layer, pieces, dy, out_hw, out=None):
+    """Weight gradient in the framework layout (same shape as module.weight); written into `out` when given."""
+    a0 = pieces[0].act
+    IH = a0.H * (2 if pieces[0].up else 1)
+    IW = a0.W * (2 if pieces[0].up else 1)
+    OH, OW = out_hw
+    kind = CONVT_FWD if layer.transposed else CONV_FWD
+    d = layer._desc(kind, a0.N, IH, IW, OH, OW)
+    d.n_in = len(pieces)
+    for i, p in enumerate(pieces):
+        _fill_operand(d.in_[i], p)
+    d.n_out = 1
+    d.out[0].C = layer.Cout
+    lib = _lib.load()
+    nbytes = lib.dn_conv_wgrad_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise _lib.DispnetHipError("dn_conv_wgrad_workspace_bytes: " + _lib.last_error())
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+    dw = out if out is not None else torch.empty_like(layer.m.weight, memory_format=torch.contiguous_format)
+    _lib.call("dn_conv2d_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return dw
+
+
+def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
+    """Input gradient of conv / conv-transpose, routed into each piece's Act.grad (write first, accumulate after)."""
+    targets = [p for p in pieces]
+    if not any(p.act.needs_grad for p in targets):
+        return
+    IH, IW = in_hw                      # logical spatial size of the forward input
+    kind = CONVT_DGRAD if layer.transposed else CONV_DGRAD
+    # the dgrad kernel reads dy (spatial OH x OW) and writes the forward-input-shaped gradient (IH x IW)
+    d = layer._desc(kind, N, OH, OW, IH, IW)
+    d.n_in = 1
+    op = d.in_[0]
+    op.data = dy.data_ptr()
+    op.C = layer.Cout
+    op.up_shift = 0
+    op.stride_c, op.stride_w, op.stride_h, op.stride_n = 1, layer.Cout, OW * layer.Cout, OH * OW * layer.Cout
+    d.n_out = len(targets)
+    post = []
+    for i, p in enumerate(targets):
+        a = p.act
+        if p.up:
+            # gradient w.r.t. the upsampled view: full-resolution scratch, folded 2x2 afterwards
+            tmp = torch.empty((N, IH, IW, a.C), dtype=torch.float32, device=dy.device)
+            _fill_result(d.out[i], tmp, a.C, IH, IW, False)
+            post.append((a, tmp))
+        elif not a.needs_grad:
+            # still needs a destination: scratch (rare: only the image, which is never concatenated)
+            tmp = torch.empty((N, IH, IW, a.C), dtype=torch.float32, device=dy.device)
+            _fill_result(d.out[i], tmp, a.C, IH, IW, False)
+        else:
+            first = a.grad is None
+            if first:
+                a.grad = a.new_like()
+            _fill_result(d.out[i], a.grad, a.C, IH, IW, not first)
+    d.w_packed = layer.packed(kind, d).data_ptr()
+    d.bias = None
+    d.act = ACT_NONE
+    _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
+    for a, tmp in post:
+        if a.C != 1:
+            raise NotImplementedError("upsampled operand with C != 1")
+        first = a.grad is None
+        if first:
+            a.grad = a.new_like()
+        _lib.call("dn_upsample2x_nearest_bwd", tmp.data_ptr(), N, a.H, a.W, a.grad.data_ptr(), 0 if first else 1, _stream())
+
+
+def colsum(partial, rows, Cn, stride=1, offset=0):
+    out = torch.empty(Cn, dtype=torch.float32, device=partial.device)
+    _lib.call("dn_colsum_finalize", partial.data_ptr(), rows, Cn, stride, offset, out.data_ptr(), _stream())
+    return out
+
+
+def act_bwd(g, y_post, act, p0, p1, rows, Cn):
+    """g <- g * act'(y_post) in place; returns the bias gradient (column sums of the result)."""
+    nblk = _lib.load().dn_reduce_blocks(rows, Cn)
+    partial = torch.empty((nblk, Cn), dtype=torch.float32, device=g.device)
+    _lib.call("dn_act_bwd_reduce", g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn, partial.data_ptr(), _stream())
+    return colsum(partial, nblk, Cn)
+
+
+class GradSink:
+    """Where parameter gradients go.  Default: a dict handed back to autograd.  An optimizer arena can register
+    per-parameter destination views to have the engine write gradients in place (no autograd accumulation pass)."""
+
+    def __init__(self):
+        self.grads = {}
+
+    @staticmethod
+    def dest(param):
+        """In-place destination registered by an optimizer arena (contiguous, parameter-shaped), or None."""
+        return getattr(param, "_dn_grad_view", None)
+
+    def put(self, param, g):
+        dst = getattr(param, "_dn_grad_view", None)
+        if dst is not None:
+            if g.data_ptr() != dst.data_ptr():
+                dst.copy_(g.view_as(dst))
+            self.grads[id(param)] = None
+        else:
+            self.grads[id(param)] = g
+
+    def get(self, param):
+        return self.grads.get(id(param))
+
+
+# ------------------------------------------------------------------------------------------------- block helpers
+def block_conv_bn(tape, sink, x_piece, layer, bn, training):
+    """conv3x3 -> BatchNorm (batch statistics when training) -> ReLU, with the BN-apply+ReLU left pending on the result
+    (the consumer's loader applies it).  Reference: torchvision vgg16_bn features triplets used at
+    models/Disp_vgg_BN.py:137-141."""
+    xa = x_piece.act
+    y_t, partial, prow = conv_forward(layer, [x_piece], ACT_NONE, bn_stats=training)
+    OH, OW = y_t.shape[1], y_t.shape[2]
+    Cn = layer.Cout
+    y = Act(y_t, xa.N, OH, OW, Cn)
+    dev = y_t.device
+    y.scale = torch.empty(Cn, dtype=torch.float32, device=dev)
+    y.shift = torch.empty(Cn, dtype=torch.float32, device=dev)
+    if training:
+        y.mean = torch.empty(Cn, dtype=torch.float32, device=dev)
+        y.invstd = torch.empty(Cn, dtype=torch.float32, device=dev)
+        _lib.call("dn_bn_finalize", partial.data_ptr(), prow, Cn, y.rows, _ptr(layer.m.bias.detach()) if layer.m.bias is not None else None,
+                  bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                  bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps, y.mean.data_ptr(), y.invstd.data_ptr(),
+                  y.scale.data_ptr(), y.shift.data_ptr(), _stream())
+        bn.num_batches_tracked += 1
+    else:
+        _lib.call("dn_bn_eval_affine", Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), bn.eps, y.scale.data_ptr(), y.shift.data_ptr(), _stream())
+
+    def backward():
+        if y.grad is None:
+            return
+        g = y.grad
+        if training:
+            if not y.grad_is_dz:
+                nblk = _lib.load().dn_reduce_blocks(y.rows, Cn)
+                y.partial = torch.empty((nblk, Cn, 2), dtype=torch.float32, device=dev)
+                y.partial_rows = nblk
+                _lib.call("dn_bn_relu_bwd_reduce", g.data_ptr(), y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(),
+                          y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn, y.partial.data_ptr(), _stream())
+            dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
+            _lib.call("dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(),
+                      bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.rows, Cn, dgamma.data_ptr(),
+                      dbeta.data_ptr(), _stream())
+            sink.put(bn.weight, dgamma)
+            sink.put(bn.bias, dbeta)
+        else:
+            raise NotImplementedError("backward through eval-mode BatchNorm (frozen statistics) is not implemented")
+        # g is now dL/d(conv output).  The conv bias sits in front of a BatchNorm: its gradient is identically zero in
+        # exact arithmetic (BN removes the mean); the reference's value is rounding noise.  We store exact zeros.
+        if layer.m.bias is not None:
+            sink.put(layer.m.bias, torch.zeros(Cn, dtype=torch.float32, device=dev))
+        sink.put(layer.m.weight, conv_wgrad(layer, [x_piece], g, (OH, OW), out=sink.dest(layer.m.weight)))
+        conv_dgrad(layer, g, xa.N, OH, OW, [x_piece], (xa.H, xa.W))
+        y.grad = None
+
+    tape.push(backward)
+    return y
+
+
+def block_pool(tape, y):
+    """relu(bn(y)) then MaxPool2d(2,2) in one pass; the result is a plain activation (a skip tensor)."""
+    dev = y.t.device
+    p_t = torch.empty((y.N, y.H // 2, y.W // 2, y.C), dtype=torch.float32, device=dev)
+    idx = torch.empty((y.N, y.H // 2, y.W // 2, y.C), dtype=torch.uint8, device=dev)
+    _lib.call("dn_bn_relu_pool_fwd", y.t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.N, y.H, y.W, y.C,
+              p_t.data_ptr(), idx.data_ptr(), _stream())
+    p = Act(p_t, y.N, y.H // 2, y.W // 2, y.C)
+
+    def backward():
+        if p.grad is None:
+            return
+        nblk = _lib.load().dn_reduce_blocks(p.rows, y.C)
+        y.partial = torch.empty((nblk, y.C, 2), dtype=torch.float32, device=dev)
+        y.partial_rows = nblk
+        y.grad = y.new_like()
+        y.grad_is_dz = True
+        _lib.call("dn_bn_relu_pool_bwd", p.grad.data_ptr(), idx.data_ptr(), y.t.data_ptr(), y.mean.data_ptr(),
+                  y.invstd.data_ptr(), y.N, y.H, y.W, y.C, y.grad.data_ptr(), y.partial.data_ptr(), _stream())
+        p.grad = None
+
+    tape.push(backward)
+    return p
+
+
+def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None):
+    """conv / conv-transpose over virtually concatenated pieces + bias + activation in the epilogue.
+    Reference: Conv2dBlock1 / ConvTranspose2dBlock1 / predict_disp (models/Disp_vgg_BN.py:40-70)."""
+    a0 = pieces[0].act
+    in_hw = (a0.H * (2 if pieces[0].up else 1), a0.W * (2 if pieces[0].up else 1))
+    y_t, _, _ = conv_forward(layer, pieces, act, p0, p1, out_hw=out_hw)
+    OH, OW = y_t.shape[1], y_t.shape[2]
+    y = Act(y_t, a0.N, OH, OW, layer.Cout)
+
+    def backward():
+        if y.grad is None:
+            return
+        g = y.grad
+        db = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout)
+        if layer.m.bias is not None:
+            sink.put(layer.m.bias, db)
+        sink.put(layer.m.weight, conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight)))
+        conv_dgrad(layer, g, a0.N, OH, OW, pieces, in_hw)
+        y.grad = None
+
+    tape.push(backward)
+    return y
+
+
+def seed_grad(act, g):
+    """Seed an activation's gradient with one supplied by autograd (owned copy: the tape works in place)."""
+    g = g.reshape(act.N, act.H, act.W, act.C) if act.C == 1 else g.permute(0, 2, 3, 1)
+    if act.grad is None:
+        act.grad = g.clone(memory_format=torch.contiguous_format)
+    else:
+        act.grad.add_(g)
+
+
+def block_bilinear_up2(tape, d, out_hw):
+    """1-channel bilinear x2 (align_corners=False) cropped to out_hw -- models/DispNetS.py:120,126,132 + crop_like."""
+    if d.C != 1:
+        raise NotImplementedError("bilinear upsample is only needed for the 1-channel disparity")
+    OH, OW = out_hw
+    up_t = torch.empty((d.N, OH, OW, 1), dtype=torch.float32, device=d.t.device)
+    _lib.call("dn_upsample2x_bilinear_fwd", d.t.data_ptr(), d.N, d.H, d.W, OH, OW, up_t.data_ptr(), _stream())
+    up = Act(up_t, d.N, OH, OW, 1)
+
+    def backward():
+        if up.grad is None:
+            return
+        first = d.grad is None
+        if first:
+            d.grad = d.new_like()
+        _lib.call("dn_upsample2x_bilinear_bwd", up.grad.data_ptr(), d.N, d.H, d.W, OH, OW, d.grad.data_ptr(),
+                  0 if first else 1, _stream())
+        up.grad = None
+
+    tape.push(backward)
+    return up

@@ -1,0 +1,36 @@
+"""Small differentiable HIP ops used by the callers of the hot path (train.py) -- not part of the reference's module
+namespace, but the reference's call sites have an exact counterpart here."""
+import torch
+
+from . import _lib
+from .engine import _stream, require_cuda
+
+
+class _Reciprocal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x, "disparity")
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        _lib.call("dn_reciprocal_fwd", xc.data_ptr(), y.data_ptr(), xc.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dyc = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.call("dn_reciprocal_bwd", dyc.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), _stream())
+        return dx
+
+
+def reciprocal(disp):
+    """depth = 1/disp  (reference train.py:445, `depth = [1/disp for disp in disparities]`)."""
+    return _Reciprocal.apply(disp)
+
+
+def disp_to_depth_list(disparities):
+    if isinstance(disparities, (tuple, list)):
+        return [reciprocal(d) for d in disparities]
+    return reciprocal(disparities)

@@ -1,0 +1,77 @@
+"""Shared pieces of the drop-in model mirrors: parameter containers with the reference's state_dict layout and the
+autograd bridge that hands a whole-network HIP forward/backward to PyTorch as ONE node."""
+import torch
+import torch.nn as nn
+
+from .. import engine
+
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+VGG_STAGES = ((0, 7), (7, 14), (14, 24), (24, 34), (34, 44))   # features[a:b] slices, models/Disp_vgg_BN.py:137-141
+
+
+class VGG16BNContainer(nn.Module):
+    """Parameter container laid out like torchvision.models.vgg16_bn() (cfg "D" + BatchNorm): `.features` Sequential
+    (indices 0..43), `.avgpool`, `.classifier`.  torchvision only contributes the layout to the reference
+    (models/Disp_vgg_BN.py:84); the modules here are never called -- they hold parameters/buffers under the same
+    state_dict keys.  `with_classifier=False` drops the 123.6 M never-used classifier parameters."""
+
+    def __init__(self, with_classifier=True):
+        super().__init__()
+        layers, c = [], 3
+        for v in VGG16_CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                c = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        if with_classifier:
+            self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(),
+                                            nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 1000))
+
+
+def xavier_init_like_reference(module):
+    """init_weights() of the reference nets: xavier_uniform_ on every Conv2d / ConvTranspose2d / Linear weight, zero
+    bias; the BatchNorm branch is unreachable there (models/Disp_vgg_BN.py:116-120) so BN keeps gamma=1, beta=0."""
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+class HipNetFunction(torch.autograd.Function):
+    """One autograd node for the whole encoder-decoder.  forward: run the net's HIP schedule, recording the engine tape;
+    backward: seed the output gradients, run the tape in reverse, hand parameter gradients back (or nothing for
+    parameters whose gradient the engine wrote in place into an optimizer arena)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        recording = any(ctx.needs_input_grad[2:])
+        tape = engine.Tape(recording)
+        sink = engine.GradSink()
+        outs = net._hip_forward(tape, sink, x)         # list[Act] with C == 1
+        ctx.tape, ctx.sink, ctx.outs, ctx.params = tape, sink, outs, params
+        results = tuple(a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2) for a in outs)
+        return results
+
+    @staticmethod
+    def backward(ctx, *grads):
+        for a, g in zip(ctx.outs, grads):
+            if g is not None:
+                engine.seed_grad(a, g)
+        ctx.tape.run_backward()
+        pg = tuple(ctx.sink.get(p) for p in ctx.params)
+        ctx.tape = ctx.outs = None
+        return (None, None) + pg
+
+
+def run_net(net, x):
+    engine.require_cuda(x, "input image")
+    if x.dtype != torch.float32:
+        raise TypeError("expected a float32 image batch, got %s" % x.dtype)
+    params = [p for p in net._hot_parameters()]
+    for p in params:
+        engine.require_cuda(p, "model parameters")
+    return HipNetFunction.apply(net, x, *params)

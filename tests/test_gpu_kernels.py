@@ -1,0 +1,213 @@
+"""GPU parity of the individual HIP kernel families, called through the C ABI (ctypes) via the engine helpers,
+against plain PyTorch-CPU fp32 references of the same op (F.conv2d & co).  Run on the MI355X box: pytest -m gpu.
+
+Tolerances: the MFMA fp32 path is an exact fp32 FMA chain with a different summation order than ATen's CPU kernels,
+so results agree to fp32 round-off: rtol 2e-4 / atol scaled to the magnitude of the result (stated per check).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+from supervised_dispnet_amd import _lib, engine  # noqa: E402
+from supervised_dispnet_amd._lib import ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID_AFFINE  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def close(name, got, want, rtol=2e-4, atol_rel=2e-5):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(want.shape))
+    scale = float(want.abs().max()) + 1e-30
+    err = (got - want).abs()
+    tol = atol_rel * scale + rtol * want.abs()
+    bad = err > tol
+    if bad.any():
+        idx = np.unravel_index(int(torch.argmax(err - tol)), got.shape)
+        raise AssertionError("%s: %d/%d elements off; worst at %s got %.7g want %.7g (max|want| %.4g, max err %.4g)" % (
+            name, int(bad.sum()), got.numel(), idx, float(got[idx]), float(want[idx]), scale, float(err.max())))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rnd(*shape, lo=-1.0, hi=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def test_library_loads_on_gfx950():
+    lib = _lib.load()
+    assert lib.dn_version() >= 1
+    assert lib.dn_device_arch_ok() == 1, "the HIP kernels are built for gfx950 only"
+
+
+CONV_CASES = [
+    # name,               cins,         ups,               cout, k, s, p, transposed, out_pad, N, H, W, act, affine
+    ("3x3_64_64",         (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 12, 20, ACT_NONE, False),
+    ("3x3_first_nchw",    (3,),         (False,),          64, 3, 1, 1, False, 0, 2, 16, 24, ACT_NONE, False),
+    ("3x3_128_256_bnload", (128,),      (False,),          256, 3, 1, 1, False, 0, 2, 8, 12, ACT_NONE, True),
+    ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
+    ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
+    ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
+    ("7x7_s2",            (3,),         (False,),          32, 7, 2, 3, False, 0, 2, 20, 28, ACT_RELU, False),
+    ("5x5_s2",            (32,),        (False,),          64, 5, 2, 2, False, 0, 2, 18, 22, ACT_RELU, False),
+    ("3x3_s2_odd",        (64,),        (False,),          128, 3, 2, 1, False, 0, 2, 13, 7, ACT_RELU, False),
+    ("1x1",               (64,),        (False,),          160, 1, 1, 0, False, 0, 2, 6, 10, ACT_NONE, False),
+    ("3x3_elu",           (16,),        (False,),          16, 3, 1, 1, False, 0, 1, 8, 8, ACT_ELU, False),
+    ("convT_k4s2p1",      (64,),        (False,),          32, 4, 2, 1, True, 0, 2, 6, 10, ACT_LEAKY, False),
+    ("convT_k4s2p1_big",  (512,),       (False,),          256, 4, 2, 1, True, 0, 2, 4, 13, ACT_LEAKY, False),
+    ("convT_k3s2p1op1",   (32,),        (False,),          16, 3, 2, 1, True, 1, 2, 5, 7, ACT_RELU, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_family_fwd_bwd(case):
+    name, cins, ups, cout, k, s, p, transposed, out_pad, N, H, W, act, affine = case
+    torch.manual_seed(1)
+    mod = (nn.ConvTranspose2d(sum(cins), cout, k, s, p, out_pad) if transposed else nn.Conv2d(sum(cins), cout, k, s, p))
+    with torch.no_grad():
+        mod.bias.uniform_(-0.5, 0.5)
+    # ---- reference (CPU fp32)
+    srcs, ref_in = [], []
+    for i, (c, up) in enumerate(zip(cins, ups)):
+        h, w = (H // 2, W // 2) if up else (H, W)
+        t = rnd(N, c, h, w, seed=i).requires_grad_()
+        srcs.append(t)
+        v = t
+        if affine:
+            sc, sh = rnd(c, lo=0.5, hi=1.5, seed=10 + i), rnd(c, lo=-0.3, hi=0.3, seed=20 + i)
+            v = F.relu(v * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        if up:
+            v = F.interpolate(v, scale_factor=2, mode="nearest")
+        ref_in.append(v)
+    y_ref_pre = mod(torch.cat(ref_in, 1))
+    crop = None
+    if transposed and out_pad:
+        crop = (2 * H - 1, 2 * W)   # exercise crop_like on one axis
+        y_ref_pre = y_ref_pre[:, :, :crop[0], :crop[1]]
+    p0, p1 = (0.1, 0.0) if act == ACT_LEAKY else ((10.0, 0.01) if act == ACT_SIGMOID_AFFINE else (0.0, 0.0))
+    y_ref = {ACT_NONE: lambda v: v, ACT_RELU: F.relu, ACT_LEAKY: lambda v: F.leaky_relu(v, 0.1), ACT_ELU: F.elu,
+             ACT_SIGMOID_AFFINE: lambda v: 10.0 * torch.sigmoid(v) + 0.01}[act](y_ref_pre)
+    g = rnd(*y_ref.shape, seed=99)
+    (y_ref * g).sum().backward()
+    # ---- HIP
+    mod_d = (nn.ConvTranspose2d(sum(cins), cout, k, s, p, out_pad) if transposed else nn.Conv2d(sum(cins), cout, k, s, p)).to(DEV)
+    mod_d.load_state_dict(mod.state_dict())
+    layer = engine.ConvLayer(mod_d[0] if isinstance(mod_d, nn.Sequential) else mod_d, transposed=transposed)
+    pieces = []
+    for i, (t, up) in enumerate(zip(srcs, ups)):
+        n_, c_, h_, w_ = t.shape
+        if name.endswith("nchw"):
+            a = engine.Act.from_nchw_image(t.detach().to(DEV))
+            a.needs_grad = False
+        else:
+            a = engine.Act(nhwc(t.detach()), n_, h_, w_, c_)
+        if affine:
+            a.scale = rnd(c_, lo=0.5, hi=1.5, seed=10 + i).to(DEV)
+            a.shift = rnd(c_, lo=-0.3, hi=0.3, seed=20 + i).to(DEV)
+        pieces.append(engine.Piece(a, up))
+    tape, sink = engine.Tape(True), engine.GradSink()
+    y = engine.block_conv_act(tape, sink, pieces, layer, act, p0, p1, out_hw=crop)
+    torch.cuda.synchronize()
+    close(name + ":y", nchw(y.t), y_ref)
+    y.grad = nhwc(g)
+    tape.run_backward()
+    torch.cuda.synchronize()
+    close(name + ":dw", sink.get(mod_d.weight), mod.weight.grad, rtol=5e-4, atol_rel=5e-5)
+    close(name + ":db", sink.get(mod_d.bias), mod.bias.grad, rtol=5e-4, atol_rel=5e-5)
+    for i, (pc, t) in enumerate(zip(pieces, srcs)):
+        if not pc.act.needs_grad:
+            continue
+        if affine:
+            continue   # gradient w.r.t. the pre-affine tensor goes through the BN path, tested in test_conv_bn_pool_block
+        close(name + ":dx%d" % i, nchw(pc.act.grad), t.grad, rtol=5e-4, atol_rel=5e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 3, 64, 64), (2, 16, 8, 64, 128, 128)], ids=["c3_64_64", "c64_128_128"])
+def test_conv_bn_pool_block(shape):
+    """conv -> BN(train) -> ReLU -> conv -> BN -> ReLU -> MaxPool, forward + full backward vs torch modules (CPU)."""
+    N, H, W, c0, c1, c2 = shape
+    torch.manual_seed(3)
+    ref = nn.Sequential(nn.Conv2d(c0, c1, 3, padding=1), nn.BatchNorm2d(c1), nn.ReLU(), nn.Conv2d(c1, c2, 3, padding=1),
+                        nn.BatchNorm2d(c2), nn.ReLU(), nn.MaxPool2d(2, 2))
+    with torch.no_grad():
+        for m in ref:
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    dev_mods = nn.Sequential(nn.Conv2d(c0, c1, 3, padding=1), nn.BatchNorm2d(c1), nn.ReLU(), nn.Conv2d(c1, c2, 3, padding=1),
+                             nn.BatchNorm2d(c2), nn.ReLU(), nn.MaxPool2d(2, 2)).to(DEV)
+    dev_mods.load_state_dict(ref.state_dict())
+    x = rnd(N, c0, H, W, seed=5).requires_grad_()
+    ref.train()
+    out_ref = ref(x)
+    g = rnd(*out_ref.shape, seed=6)
+    (out_ref * g).sum().backward()
+    tape, sink = engine.Tape(True), engine.GradSink()
+    xa = engine.Act(nhwc(x.detach()), N, H, W, c0)
+    y1 = engine.block_conv_bn(tape, sink, engine.Piece(xa), engine.ConvLayer(dev_mods[0]), dev_mods[1], True)
+    y2 = engine.block_conv_bn(tape, sink, engine.Piece(y1), engine.ConvLayer(dev_mods[3]), dev_mods[4], True)
+    pooled = engine.block_pool(tape, y2)
+    torch.cuda.synchronize()
+    close("pooled", nchw(pooled.t), out_ref)
+    close("running_mean", dev_mods[4].running_mean, ref[4].running_mean, rtol=1e-4)
+    close("running_var", dev_mods[4].running_var, ref[4].running_var, rtol=1e-4)
+    assert int(dev_mods[1].num_batches_tracked) == 1
+    pooled.grad = nhwc(g)
+    tape.run_backward()
+    torch.cuda.synchronize()
+    for i in (0, 3):
+        close("dw%d" % i, sink.get(dev_mods[i].weight), ref[i].weight.grad, rtol=1e-3, atol_rel=1e-4)
+    for i in (1, 4):
+        close("dgamma%d" % i, sink.get(dev_mods[i].weight), ref[i].weight.grad, rtol=1e-3, atol_rel=1e-4)
+        close("dbeta%d" % i, sink.get(dev_mods[i].bias), ref[i].bias.grad, rtol=1e-3, atol_rel=1e-4)
+    close("dx", nchw(xa.grad), x.grad, rtol=1e-3, atol_rel=1e-4)
+    # conv bias in front of BN: exact zeros here, rounding noise in the reference
+    assert float(sink.get(dev_mods[0].bias).abs().max()) == 0.0
+    assert float(ref[0].bias.grad.abs().max()) < 1e-4
+
+
+def test_bilinear_up2_matches_interpolate():
+    x = rnd(2, 1, 5, 7, seed=1).requires_grad_()
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)[:, :, :9, :14]
+    g = rnd(*ref.shape, seed=2)
+    (ref * g).sum().backward()
+    tape = engine.Tape(True)
+    d = engine.Act(nhwc(x.detach()), 2, 5, 7, 1)
+    up = engine.block_bilinear_up2(tape, d, (9, 14))
+    close("bilinear", nchw(up.t), ref, rtol=1e-5, atol_rel=1e-6)
+    up.grad = nhwc(g)
+    tape.run_backward()
+    close("bilinear_bwd", nchw(d.grad), x.grad, rtol=1e-5, atol_rel=1e-6)
+
+
+def test_fused_adam_matches_torch_adam():
+    from supervised_dispnet_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(64, 3, 3, 3), (64,), (17,), (128, 64, 3, 3), (1, 16, 3, 3)]
+    ref_p = [torch.randn(s).requires_grad_() for s in shapes]
+    dev_p = [nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    opt_ref = torch.optim.Adam(ref_p, lr=1e-4, betas=(0.9, 0.999))
+    opt = FusedAdam(dev_p, lr=1e-4, betas=(0.9, 0.999))
+    for it in range(3):
+        for p, q in zip(ref_p, dev_p):
+            gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(it * 100 + p.numel())) * 10 ** (it - 1)
+            p.grad = gr.clone()
+            q._dn_grad_view.copy_(gr.to(DEV))
+        opt_ref.step()
+        opt.step()
+    for p, q in zip(ref_p, dev_p):
+        close("adam", q.detach(), p.detach(), rtol=1e-6, atol_rel=1e-7)

@@ -1,0 +1,190 @@
+"""GPU parity of the drop-in models / losses (HIP path, through the C ABI) against the CPU oracle on identical
+closed-form inputs, and against the committed golden vectors that came from the reference itself.  pytest -m gpu.
+
+Stated fp32 tolerances (north_star: "match the reference PyTorch-CPU forward to a stated fp32 tolerance"):
+  forward disparities         rtol 1e-3, atol 1e-4 * max|ref|   (27 conv layers + 13 training-mode BatchNorms deep)
+  parameter gradients         rtol 5e-3, atol 2e-3 * max|ref|
+  losses / metrics (scalars)  rtol 1e-4
+  integer results             exact
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import supervised_dispnet_amd.loss_functions as LF  # noqa: E402
+import supervised_dispnet_amd.models as models  # noqa: E402
+from oracle import detgen, losses as OL, nets as ON  # noqa: E402  (the checker)
+from supervised_dispnet_amd.functional import reciprocal  # noqa: E402
+from supervised_dispnet_amd.optim import FusedAdam  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def close(name, got, want, rtol, atol_rel):
+    got = got.detach().float().cpu()
+    want = torch.as_tensor(want).detach().float().cpu()
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(want.shape))
+    scale = float(want.abs().max()) + 1e-30
+    err = (got - want).abs()
+    tol = atol_rel * scale + rtol * want.abs()
+    bad = err > tol
+    if bad.any():
+        idx = np.unravel_index(int(torch.argmax(err - tol)), got.shape)
+        raise AssertionError("%s: %d/%d off; worst at %s got %.7g want %.7g (max|want| %.4g, max err %.4g)" % (
+            name, int(bad.sum()), got.numel(), idx, float(got[idx]), float(want[idx]), scale, float(err.max())))
+
+
+def _oracle_params(sd):
+    out = {}
+    for k, v in sd.items():
+        v = v.detach().cpu().clone()
+        if torch.is_floating_point(v) and "running" not in k:
+            v.requires_grad_(True)
+        out[k] = v
+    return out
+
+
+def _is_pre_bn_conv_bias(key):
+    # conv biases directly in front of a BatchNorm: gradient is identically zero (exact) / rounding noise (reference)
+    return key.startswith("features.features.") and key.endswith(".bias") and int(key.split(".")[2]) in (
+        0, 3, 7, 10, 14, 17, 20, 24, 27, 30, 34, 37, 40)
+
+
+@pytest.mark.parametrize("tag,shape,full", [("vggbn_tiny", (2, 64, 96), True), ("vggbn_cfg", (2, 128, 416), False)])
+def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
+    g = golden(tag)
+    b, h, w = shape
+    net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+    detgen.fill_state_dict(net.state_dict(), "vggbn")
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).train()
+    x = detgen.image_batch(b, h, w, tag + ":x")
+    gt = detgen.sparse_depth(b, h, w, tag + ":gt", density=0.3 if full else 0.05)
+    disps = net(x.to(DEV))
+    depth = [reciprocal(d) for d in disps]
+    loss = LF.l1_loss(gt.to(DEV), depth, "kitti") + 0.1 * LF.smooth_loss(depth)
+    loss.backward()
+    torch.cuda.synchronize()
+    # ---- oracle on the same inputs
+    osd = _oracle_params(sd0)
+    odisps = ON.disp_vgg_bn(osd, x, training=True)
+    odepth = [1 / d for d in odisps]
+    oloss = OL.l1_loss(gt, odepth, "kitti") + 0.1 * OL.smooth_loss(odepth)
+    oloss.backward()
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-4)            # the reference's own number
+    for i, (d, od) in enumerate(zip(disps, odisps)):
+        close("disp%d" % i, d, od, rtol=1e-3, atol_rel=1e-4)
+        if full:
+            close("disp%d(golden)" % i, d, g["disp%d" % i], rtol=1e-3, atol_rel=1e-4)
+    for name, p in net.named_parameters():
+        if _is_pre_bn_conv_bias(name):
+            assert float(p.grad.abs().max()) == 0.0
+            continue
+        close("grad:" + name, p.grad, osd[name].grad, rtol=5e-3, atol_rel=2e-3)
+    sd1 = net.state_dict()
+    for key in ("features.features.1.running_mean", "features.features.1.running_var",
+                "features.features.41.running_mean", "features.features.41.running_var"):
+        close(key, sd1[key], g["bn:" + key], rtol=1e-3, atol_rel=1e-4)
+    assert int(sd1["features.features.1.num_batches_tracked"]) == 1
+    if full:
+        net.eval()
+        with torch.no_grad():
+            e = net(x.to(DEV))
+        assert e.shape == (b, 1, h, w)
+        # the golden eval pass ran after ONE training forward, like here (running stats updated once)
+        close("eval_disp0(golden)", e, g["eval_disp0"], rtol=1e-3, atol_rel=1e-4)
+
+
+def test_dispnets_config1(golden):
+    """BASELINE config 1: DispNetS on 2 x (3,128,416)."""
+    g = golden("dispnets_cfg1")
+    net = models.DispNetS(datasets="kitti")
+    detgen.fill_state_dict(net.state_dict(), "dispnets")
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).train()
+    x = detgen.image_batch(2, 128, 416, "dispnets:x")
+    outs = net(x.to(DEV))
+    ws = [detgen.uniform(tuple(o.shape), "dispnets:g%d" % i, -1, 1) for i, o in enumerate(outs)]
+    sum((o * wt.to(DEV)).sum() for o, wt in zip(outs, ws)).backward()
+    osd = _oracle_params(sd0)
+    oouts = ON.dispnets(osd, x, training=True)
+    sum((o * wt).sum() for o, wt in zip(oouts, ws)).backward()
+    for i, (o, oo) in enumerate(zip(outs, oouts)):
+        close("disp%d" % (i + 1), o, oo, rtol=1e-3, atol_rel=1e-4)
+    close("disp4(golden)", outs[3], g["train3_full"], rtol=1e-3, atol_rel=1e-4)
+    for name, p in net.named_parameters():
+        close("grad:" + name, p.grad, osd[name].grad, rtol=5e-3, atol_rel=2e-3)
+    net.eval()
+    with torch.no_grad():
+        e = net(x.to(DEV))
+    s = detgen.summarize(e.cpu())
+    np.testing.assert_allclose(s["samples"], g["eval_samples"], rtol=1e-3, atol=1e-3)
+
+
+def test_losses_match_oracle_and_golden(golden):
+    g = golden("losses")
+    b, h, w = 3, 32, 64
+    gt = detgen.sparse_depth(b, h, w, "loss:gt", density=0.4, lo=0.5, hi=90.0)
+    for ds in ("kitti", "nyu"):
+        for name in ("l1_loss", "l2_loss"):
+            depth = [detgen.uniform((b, 1, h >> i, w >> i), "loss:pred%d" % i, 1e-4, 95.0).to(DEV).requires_grad_() for i in range(4)]
+            v = getattr(LF, name)(gt.to(DEV), depth, ds)
+            v.backward()
+            np.testing.assert_allclose(v.item(), float(g["%s:%s" % (name, ds)]), rtol=1e-5)
+            close("%s:%s:grad" % (name, ds), depth[0].grad, g["%s:%s:grad" % (name, ds)], rtol=1e-4, atol_rel=1e-6)
+    depth = [detgen.uniform((b, 1, h >> i, w >> i), "loss:pred%d" % i, 0.5, 60.0).to(DEV).requires_grad_() for i in range(4)]
+    v = LF.smooth_loss(depth)
+    v.backward()
+    np.testing.assert_allclose(v.item(), float(g["smooth_loss"]), rtol=1e-5)
+    for i in range(4):
+        close("smooth:grad%d" % i, depth[i].grad, g["smooth_loss:grad%d" % i], rtol=1e-4, atol_rel=1e-5)
+    p = detgen.uniform((b, 8, h, w), "loss:ord", 0.0, 1.0).to(DEV).requires_grad_()
+    v = LF.smooth_DORN_loss(p)
+    v.backward()
+    np.testing.assert_allclose(v.item(), float(g["smooth_DORN_loss"]), rtol=1e-5)
+    close("smooth_dorn:grad", p.grad, g["smooth_DORN_loss:grad"], rtol=1e-4, atol_rel=1e-5)
+    gt0 = gt.clone()
+    gt0[1] = 0
+    v = LF.l1_loss(gt0.to(DEV), [detgen.uniform((b, 1, h, w), "loss:pred0", 1e-4, 95.0).to(DEV)], "kitti")
+    assert torch.isnan(v).item()        # empty mask -> NaN, like the reference (mean of empty)
+
+
+def test_compute_errors_golden(golden):
+    g = golden("compute_errors")
+    for ds, (b, h, w), hi in (("kitti", (3, 128, 416), 90.0), ("nyu", (2, 48, 64), 11.0)):
+        gt = detgen.sparse_depth(b, h, w, "err:gt:" + ds, density=0.3, lo=0.5, hi=hi)
+        pred = detgen.uniform((b, h, w), "err:pred:" + ds, 1e-4, hi)
+        got = LF.compute_errors(gt.to(DEV), pred.to(DEV), ds)
+        np.testing.assert_allclose(got, g["errors:%s" % ds], rtol=1e-4)
+
+
+def test_train_step_golden(golden):
+    """train.py:441-522: forward -> 1/disp -> L1 -> zero_grad/backward/Adam step, two iterations, vs the reference."""
+    g = golden("trainstep_vggbn_l1")
+    net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+    detgen.fill_state_dict(net.state_dict(), "vggbn")
+    net.to(DEV).train()
+    opt = FusedAdam(net._hot_parameters(), lr=1e-4, betas=(0.9, 0.999))
+    x = detgen.image_batch(2, 64, 96, "trainstep:x").to(DEV)
+    gt = detgen.sparse_depth(2, 64, 96, "trainstep:gt", density=0.3).to(DEV)
+    ls = []
+    for _ in range(2):
+        depth = [reciprocal(d) for d in net(x)]
+        loss = LF.l1_loss(gt, depth, "kitti")
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ls.append(loss.item())
+    np.testing.assert_allclose(ls, g["losses"], rtol=2e-4)
+    sd = net.state_dict()
+    for key in [k[5:-6] for k in g.files if k.startswith("post:") and k.endswith(":shape")]:
+        if _is_pre_bn_conv_bias(key):
+            continue
+        s = detgen.summarize(sd[key].cpu(), stride=31)
+        np.testing.assert_allclose(s["samples"], g["post:%s:samples" % key], rtol=2e-3, atol=2.5e-4)   # Adam: |update| <= lr per step
