@@ -29,6 +29,35 @@ BN_MOMENTUM = 0.1
 PARAM_EPOCH = 0
 
 
+# Optional per-launch instrumentation (bench.py): a list receiving (kernel_name, algorithmic_flops, start_event, end_event)
+# for every implicit-GEMM launch, bracketed with HIP events on the launch stream.  None = off (zero overhead).
+PROFILE = None
+
+
+def _pick_bn(ntot):
+    return 32 if ntot <= 32 else (64 if ntot <= 64 else 128)
+
+
+class _Timed(object):
+    """Context manager bracketing one C-ABI launch with HIP events when PROFILE is on."""
+
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+        return False
+
+
 def bump_param_epoch():
     global PARAM_EPOCH
     PARAM_EPOCH += 1
@@ -140,6 +169,11 @@ class ConvLayer:
         self.Cout = module.out_channels
         self._packed = {}
 
+    def macs(self, N, IH, IW, OH, OW):
+        """Multiply-accumulates of one forward (== of its dgrad and of its wgrad)."""
+        px = N * IH * IW if self.transposed else N * OH * OW
+        return px * self.Cin * self.Cout * self.R * self.S
+
     # -- geometry
     def out_size(self, H, W):
         if self.transposed:
@@ -199,7 +233,8 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
         rows = _lib.load().dn_conv_bn_partial_rows(C.byref(d))
         partial = torch.empty((rows, layer.Cout, 2), dtype=torch.float32, device=y.device)
         d.bn_partial = partial.data_ptr()
-    _lib.call("dn_convT2d_fwd" if layer.transposed else "dn_conv2d_fwd", C.byref(d), _stream())
+    with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cout), 2 * layer.macs(N, IH, IW, OH, OW)):
+        _lib.call("dn_convT2d_fwd" if layer.transposed else "dn_conv2d_fwd", C.byref(d), _stream())
     return y, partial, rows
 
 
@@ -222,7 +257,9 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None):
         raise _lib.DispnetHipError("dn_conv_wgrad_workspace_bytes: " + _lib.last_error())
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
     dw = out if out is not None else torch.empty_like(layer.m.weight, memory_format=torch.contiguous_format)
-    _lib.call("dn_conv2d_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    with _Timed("igemm_wgrad_kernel<%d>" % _pick_bn(layer.Cin if layer.transposed else layer.Cout),
+                2 * layer.macs(a0.N, IH, IW, OH, OW)):
+        _lib.call("dn_conv2d_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
     return dw
 
 
@@ -262,7 +299,8 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
     d.w_packed = layer.packed(kind, d).data_ptr()
     d.bias = None
     d.act = ACT_NONE
-    _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
+    with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cin), 2 * layer.macs(N, IH, IW, OH, OW)):
+        _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
     for a, tmp in post:
         if a.C != 1:
             raise NotImplementedError("upsampled operand with C != 1")
@@ -290,6 +328,8 @@ class GradSink:
     """Where parameter gradients go.  Default: a dict handed back to autograd.  An optimizer arena can register
     per-parameter destination views to have the engine write gradients in place (no autograd accumulation pass)."""
 
+    reducer = None      # optional distributed.GradReducer notified as arena gradients land (set by the trainer)
+
     def __init__(self):
         self.grads = {}
 
@@ -304,6 +344,8 @@ class GradSink:
             if g.data_ptr() != dst.data_ptr():
                 dst.copy_(g.view_as(dst))
             self.grads[id(param)] = None
+            if GradSink.reducer is not None:
+                GradSink.reducer.grad_ready(param)
         else:
             self.grads[id(param)] = g
 

@@ -71,6 +71,21 @@ class Disp_vgg_BN(nn.Module):
             if ".classifier." not in name:
                 yield p
 
+    def _grad_production_order(self):
+        """Parameters in the order backward writes their gradients (decoder first, encoder stage 5 -> 1): the arena and
+        the all-reduce buckets follow it so each bucket can leave as soon as it is complete."""
+        order = []
+        for name in ("disp0", "iconv0", "upconv0", "disp1", "iconv1", "upconv1", "disp2", "iconv2", "upconv2", "disp3",
+                     "iconv3", "upconv3", "iconv4", "upconv4"):
+            if hasattr(self, name):
+                m = getattr(self, name)[0]
+                order += [m.bias, m.weight]
+        f = self.features.features
+        for i in reversed(range(len(f))):
+            if isinstance(f[i], nn.Conv2d):
+                order += [f[i + 1].weight, f[i + 1].bias, f[i].bias, f[i].weight]
+        return order
+
     def _runtime(self):
         if self._rt is None:
             f = self.features.features

@@ -1,36 +1,33 @@
-"""Fused Adam over a flat parameter arena (reference: torch.optim.Adam at train.py:303-305,520-522).
+"""Flat parameter arena + fused Adam (reference: torch.optim.Adam at train.py:303-305,520-522).
 
-All hot parameters are re-pointed at slices of ONE fp32 buffer; gradients, exp_avg and exp_avg_sq live in three more.
-The engine writes parameter gradients straight into the gradient arena (`param._dn_grad_view`), so a step is a single
-`dn_adam_step` launch over ~20 M elements and the data-parallel all-reduce runs over the same flat buffer in buckets.
-Numerics follow torch.optim.Adam (amsgrad off): lerp/addcmul updates, denom = sqrt(v)/sqrt(1-b2^t) + eps.
+ParamArena (device-agnostic, pure plumbing): re-points every hot parameter at a slice of ONE fp32 buffer and gives each a
+gradient view into a second one (`param._dn_grad_view`), ordered by the order gradients are PRODUCED in backward, so
+the data-parallel reducer can all-reduce contiguous buckets as soon as they are complete.
+FusedAdam (HIP): one `dn_adam_step` launch over the whole arena; numerics follow torch.optim.Adam (amsgrad off):
+lerp / addcmul updates, denom = sqrt(v)/sqrt(1-b2^t) + eps, step_size = lr/(1-b1^t); grad * (1/world) folded in.
 """
 import torch
 
 from . import _lib, engine
 
 
-class FusedAdam(object):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+class ParamArena(object):
+    def __init__(self, params, production_order=None):
         params = [p for p in params if p.requires_grad]
         if not params:
-            raise ValueError("FusedAdam got no trainable parameters")
-        dev = params[0].device
-        engine.require_cuda(params[0], "parameters")
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+            raise ValueError("ParamArena got no trainable parameters")
+        if production_order is not None:
+            rank = {id(p): i for i, p in enumerate(production_order)}
+            params = sorted(params, key=lambda p: rank.get(id(p), len(rank)))
         self.params = params
-        self.step_count = 0
-        n = sum(p.numel() for p in params)
-        # 4-element alignment of every slice keeps float4 loads legal inside the kernels that read parameters directly
+        dev = params[0].device
         offs, total = [], 0
         for p in params:
             offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
+            total += (p.numel() + 3) // 4 * 4        # 16-byte aligned slices
         self.numel, self.offsets = total, offs
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         with torch.no_grad():
             for p, o in zip(params, offs):
                 view = self.flat_p[o:o + p.numel()].view(p.shape)
@@ -38,28 +35,43 @@ class FusedAdam(object):
                 p.data = view
                 p._dn_grad_view = self.flat_g[o:o + p.numel()].view(p.shape)
         engine.bump_param_epoch()
-        self.param_groups = [{"params": params, "lr": self.lr, "betas": self.betas, "eps": self.eps,
-                              "weight_decay": self.weight_decay}]
 
-    def zero_grad(self, set_to_none=True):
-        # gradients are fully overwritten by the engine each backward; only stray autograd .grad tensors need clearing
-        for p in self.params:
-            p.grad = None
-
-    def _gather_stray_grads(self):
-        """Parameters whose gradient arrived through autograd (.grad) instead of the in-place sink."""
+    def gather_stray_grads(self):
+        """Parameters whose gradient arrived through autograd (.grad) instead of the engine's in-place sink."""
         for p in self.params:
             if p.grad is not None:
                 p._dn_grad_view.copy_(p.grad)
                 p.grad = None
 
+
+class FusedAdam(object):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, production_order=None):
+        self.arena = params if isinstance(params, ParamArena) else ParamArena(list(params), production_order)
+        engine.require_cuda(self.arena.flat_p, "parameters")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.step_count = 0
+        self.exp_avg = torch.zeros_like(self.arena.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.arena.flat_p)
+        self.param_groups = [{"params": self.arena.params, "lr": self.lr, "betas": self.betas, "eps": self.eps,
+                              "weight_decay": self.weight_decay}]
+
+    @property
+    def params(self):
+        return self.arena.params
+
+    def zero_grad(self, set_to_none=True):
+        # arena gradients are fully overwritten by the engine every backward; only stray autograd grads need clearing
+        for p in self.arena.params:
+            p.grad = None
+
     @torch.no_grad()
     def step(self, grad_scale=1.0):
-        self._gather_stray_grads()
+        a = self.arena
+        a.gather_stray_grads()
         self.step_count += 1
         g = self.param_groups[0]
-        _lib.call("dn_adam_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                  self.exp_avg_sq.data_ptr(), self.numel, float(g["lr"]), self.betas[0], self.betas[1], self.eps,
+        _lib.call("dn_adam_step", a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                  self.exp_avg_sq.data_ptr(), a.numel, float(g["lr"]), self.betas[0], self.betas[1], self.eps,
                   self.weight_decay, self.step_count, float(grad_scale), engine._stream())
         engine.bump_param_epoch()
 

@@ -3,7 +3,13 @@ closed-form inputs, and against the committed golden vectors that came from the 
 
 Stated fp32 tolerances (north_star: "match the reference PyTorch-CPU forward to a stated fp32 tolerance"):
   forward disparities         rtol 1e-3, atol 1e-4 * max|ref|   (27 conv layers + 13 training-mode BatchNorms deep)
-  parameter gradients         rtol 5e-3, atol 2e-3 * max|ref|
+  parameter gradients         per tensor: relative L2 error <= 2e-2 and at most 0.5 % of the elements outside
+                              (rtol 5e-3, atol 5e-3 * max|ref|); (tiny case) median error against an fp64 run of the oracle
+                              no worse than 10x PyTorch-CPU fp32's own median error.
+                              Why not element-wise max: a ReLU / max-pool input that lies within fp32 round-off of zero
+                              flips its mask between ANY two fp32 implementations (measured: features.28 channel 92,
+                              |z| = 1.2e-6 * max, tests/gpu_diag_grads.py), which moves the affected channel's gradient
+                              by percents while everything else agrees to ~2x the CPU's own fp32 error.
   losses / metrics (scalars)  rtol 1e-4
   integer results             exact
 """
@@ -37,6 +43,20 @@ def close(name, got, want, rtol, atol_rel):
         idx = np.unravel_index(int(torch.argmax(err - tol)), got.shape)
         raise AssertionError("%s: %d/%d off; worst at %s got %.7g want %.7g (max|want| %.4g, max err %.4g)" % (
             name, int(bad.sum()), got.numel(), idx, float(got[idx]), float(want[idx]), scale, float(err.max())))
+
+
+def grad_close(name, got, want, rtol=5e-3, atol_rel=5e-3, max_bad_frac=5e-3, max_rel_l2=2e-2):
+    """Flip-robust gradient comparison (see the module docstring)."""
+    got = got.detach().double().cpu()
+    want = torch.as_tensor(want).detach().double().cpu()
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(want.shape))
+    assert torch.isfinite(got).all(), "%s: non-finite gradient" % name
+    scale = float(want.abs().max()) + 1e-30
+    err = (got - want).abs()
+    bad = float((err > atol_rel * scale + rtol * want.abs()).double().mean())
+    rel_l2 = float(err.norm() / (want.norm() + 1e-30))
+    assert bad <= max_bad_frac and rel_l2 <= max_rel_l2, "%s: %.3g%% elements off, relative L2 error %.3g (max err %.3g of max|ref| %.3g)" % (
+        name, 100 * bad, rel_l2, float(err.max()), scale)
 
 
 def _oracle_params(sd):
@@ -86,7 +106,27 @@ def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
         if _is_pre_bn_conv_bias(name):
             assert float(p.grad.abs().max()) == 0.0
             continue
-        close("grad:" + name, p.grad, osd[name].grad, rtol=5e-3, atol_rel=2e-3)
+        grad_close("grad:" + name, p.grad, osd[name].grad)
+    if full:
+        # fp64 yardstick: the HIP fp32 path must be about as accurate as PyTorch-CPU fp32 is
+        o64 = {k: (v.double() if torch.is_floating_point(v) else v.clone()) for k, v in sd0.items()}
+        for v in o64.values():
+            if torch.is_floating_point(v):
+                v.requires_grad_(True)
+        d64 = ON.disp_vgg_bn(o64, x.double(), training=True)
+        dep64 = [1 / d for d in d64]
+        (OL.l1_loss(gt.double(), dep64, "kitti") + 0.1 * OL.smooth_loss(dep64)).backward()
+        worst = 0.0
+        for name, p in net.named_parameters():
+            if _is_pre_bn_conv_bias(name):
+                continue
+            g64 = o64[name].grad
+            scale = float(g64.abs().max()) + 1e-30
+            e_hip = float((p.grad.cpu().double() - g64).abs().median()) / scale
+            e_cpu = float((osd[name].grad.double() - g64).abs().median()) / scale
+            worst = max(worst, e_hip / max(e_cpu, 1e-9))
+            assert e_hip <= 10 * e_cpu + 1e-6, "%s: median HIP err %.3g vs CPU-fp32 err %.3g (relative to max|grad|)" % (name, e_hip, e_cpu)
+        print("worst HIP/CPU-fp32 median gradient error ratio vs fp64: %.2f" % worst)
     sd1 = net.state_dict()
     for key in ("features.features.1.running_mean", "features.features.1.running_var",
                 "features.features.41.running_mean", "features.features.41.running_var"):
@@ -119,7 +159,7 @@ def test_dispnets_config1(golden):
         close("disp%d" % (i + 1), o, oo, rtol=1e-3, atol_rel=1e-4)
     close("disp4(golden)", outs[3], g["train3_full"], rtol=1e-3, atol_rel=1e-4)
     for name, p in net.named_parameters():
-        close("grad:" + name, p.grad, osd[name].grad, rtol=5e-3, atol_rel=2e-3)
+        grad_close("grad:" + name, p.grad, osd[name].grad)
     net.eval()
     with torch.no_grad():
         e = net(x.to(DEV))
