@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--width", type=int, default=416)
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps (after the timed region) for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print the per-layer launch table to stderr")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
@@ -155,7 +156,15 @@ def main():
             step()
         torch.cuda.synchronize()
         agg = {}
-        for name, flops, e0, e1 in engine.PROFILE:
+        if args.per_layer:
+            seen = {}
+            for name, flops, e0, e1, tag in engine.PROFILE:
+                r = seen.setdefault((name, tag), [0.0, 0.0, 0])
+                r[0] += flops; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += 1
+            print("%-28s %-58s %9s %9s %8s" % ("kernel", "layer", "ms/launch", "GFLOP", "TFLOP/s"), file=sys.stderr)
+            for (name, tag), (fl, sec, n) in seen.items():
+                print("%-28s %-58s %9.3f %9.2f %8.1f" % (name, tag, sec / n * 1e3, fl / n / 1e9, fl / sec / 1e12), file=sys.stderr)
+        for name, flops, e0, e1, _tag in engine.PROFILE:
             a = agg.setdefault(name, [0.0, 0.0, 0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3

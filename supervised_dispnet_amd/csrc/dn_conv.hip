@@ -30,6 +30,17 @@ __device__ __forceinline__ float apply_act(float v, int act, float p0, float p1)
   }
 }
 
+// floor(n/d), n < 2^31, with magic M = floor(2^32/d) (0xFFFFFFFF for d == 1): estimate is exact or one low; branch-free fix-up
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned d, unsigned M, unsigned* rem) {
+  unsigned q = __umulhi(n, M);
+  unsigned r = n - q * d;
+  const bool fix = r >= d;
+  q += fix ? 1u : 0u;
+  r -= fix ? d : 0u;
+  *rem = r;
+  return q;
+}
+
 // Which operand piece does K-chunk `kc` of a phase with `ntaps` taps fall in?  Uniform across the block.
 __device__ __forceinline__ int select_operand(const IgemmParams& p, int ntaps, int kc, int* kc_local) {
   int s = 0;
@@ -93,8 +104,11 @@ __device__ __forceinline__ AGroup gather4(const KOperand& S, int kl, int ntaps, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward family
-template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
+// ALLVEC: every operand is float4-addressable with int32 offsets.  Then the whole staging code is straight-line (no
+// divergent branches, loads always issued with clamped addresses and masked afterwards), so it shares one basic block with
+// the MFMAs and the scheduler can interleave address arithmetic / loads with the 64-cycle matrix instructions.
+template <int BM, int BN, int WM, int WN, bool ALLVEC>
+__global__ void __launch_bounds__(256, 2) igemm_conv_kernel(const IgemmParams p) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int AR = BM / 32, BR = BN / 32;
@@ -117,9 +131,10 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
   for (int r = tid; r < BM; r += 256) {
     int m = m0 + r, pix = -1;
     if (m < p.M) {
-      int gx = m % p.GW, t = m / p.GW;
-      int gy = t % p.GH, n = t / p.GH;
-      int oy = gy * p.osy + ph.ooy, ox = gx * p.osx + ph.oox;
+      unsigned gx, gy;
+      const unsigned t = fastdiv((unsigned)m, (unsigned)p.GW, p.mGW, &gx);
+      const int n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+      int oy = (int)gy * p.osy + ph.ooy, ox = (int)gx * p.osx + ph.oox;
       if (oy < p.OH && ox < p.OW) pix = (n * p.OH + oy) * p.OW + ox;
     }
     rowpix[r] = pix;
@@ -132,11 +147,11 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
   for (int i = 0; i < AR; ++i) {
     int m = m0 + r0 + 32 * i;
     if (m < p.M) {
-      int gx = m % p.GW, t = m / p.GW;
-      int gy = t % p.GH;
-      rn[i] = t / p.GH;
-      rby[i] = gy * p.sy;
-      rbx[i] = gx * p.sx;
+      unsigned gx, gy;
+      const unsigned t = fastdiv((unsigned)m, (unsigned)p.GW, p.mGW, &gx);
+      rn[i] = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+      rby[i] = (int)gy * p.sy;
+      rbx[i] = (int)gx * p.sx;
     } else {
       rn[i] = -1;
       rby[i] = rbx[i] = 0;
@@ -156,28 +171,61 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
   f32x4 bv[BR];
   f32x4 sc4, sh4;
   bool aff = false;
+  float relu_floor = 0.f;
+  const float* wbase = p.w + ph.w_off;
+  int boff[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) boff[i] = (n0 + r0 + 32 * i) * Kp + g * 4;
 
   auto issue_loads = [&](int kc) {
     int kcl;
     const int s = select_operand(p, ntaps, kc, &kcl);
     const KOperand& S = p.in[s];
     const int kl = kcl * kChunk + g * 4;
-    int j = 0, c = 0;
-    aff = false;
-    if (S.vec) {
-      j = kl / S.C;
-      c = kl - j * S.C;
-      if (S.scale != nullptr && j < ntaps) {
-        sc4 = *reinterpret_cast<const f32x4*>(S.scale + c);
-        sh4 = *reinterpret_cast<const f32x4*>(S.shift + c);
-        aff = true;
+    if constexpr (ALLVEC) {
+      unsigned c;
+      const int j = (int)fastdiv((unsigned)kl, (unsigned)S.C, S.mC, &c);
+      const bool kvalid = j < ntaps;
+      const int t = taps[kvalid ? j : 0];
+      const int dy = (int)(short)(t & 0xffff), dx = t >> 16;
+      const float* base = S.p;
+      const int sn = (int)S.sn, sh = (int)S.sh, sw = (int)S.sw, up = S.up;
+      const bool has_aff = S.scale != nullptr;
+      // identity affine + floor of -inf when the operand has no pending BN/ReLU: keeps the store stage branch-free
+      const f32x4 l1 = *reinterpret_cast<const f32x4*>((has_aff ? S.scale : base) + c);
+      const f32x4 l2 = *reinterpret_cast<const f32x4*>((has_aff ? S.shift : base) + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc4[e] = has_aff ? l1[e] : 1.f;
+        sh4[e] = has_aff ? l2[e] : 0.f;
       }
+      relu_floor = has_aff ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int iy = rby[i] + dy, ix = rbx[i] + dx;
+        const bool ok = kvalid && rn[i] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        int off = rn[i] * sn + (iy >> up) * sh + (ix >> up) * sw + (int)c;
+        off = ok ? off : 0;
+        av[i].v = *reinterpret_cast<const f32x4*>(base + off);
+        av[i].ok = ok;
+      }
+    } else {
+      int j = 0, c = 0;
+      aff = false;
+      if (S.vec) {
+        j = kl / S.C;
+        c = kl - j * S.C;
+        if (S.scale != nullptr && j < ntaps) {
+          sc4 = *reinterpret_cast<const f32x4*>(S.scale + c);
+          sh4 = *reinterpret_cast<const f32x4*>(S.shift + c);
+          aff = true;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) av[i] = gather4(S, kl, ntaps, taps, rn[i], rby[i], rbx[i], rn[i] >= 0, p.IH, p.IW, j, c);
     }
 #pragma unroll
-    for (int i = 0; i < AR; ++i) av[i] = gather4(S, kl, ntaps, taps, rn[i], rby[i], rbx[i], rn[i] >= 0, p.IH, p.IW, j, c);
-    const float* wrow = p.w + ph.w_off + (long long)(n0 + r0) * Kp + kc * kChunk + g * 4;
-#pragma unroll
-    for (int i = 0; i < BR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(wrow + (long long)(32 * i) * Kp);
+    for (int i = 0; i < BR; ++i) bv[i] = *reinterpret_cast<const f32x4*>(wbase + boff[i] + kc * kChunk);
   };
 
   auto store_stage = [&](int buf) {
@@ -185,11 +233,19 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       f32x4 v = av[i].v;
-      if (aff) {
+      if constexpr (ALLVEC) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * sc4[e] + sh4[e]);
+        for (int e = 0; e < 4; ++e) {
+          const float t = fmaxf(relu_floor, fmaf(v[e], sc4[e], sh4[e]));
+          v[e] = av[i].ok ? t : 0.f;
+        }
+      } else {
+        if (aff) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * sc4[e] + sh4[e]);
+        }
+        if (!av[i].ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (!av[i].ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(a + 32 * i * LDK) = v;
     }
     float* b = Bs + buf * BN * LDK + r0 * LDK + g * 4;
@@ -206,7 +262,14 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
   for (int kc = 0; kc < nchunks; ++kc) {
     const int buf = kc & 1;
     const bool more = (kc + 1 < nchunks);
-    if (more) issue_loads(kc + 1);
+    if constexpr (ALLVEC) {
+      issue_loads(more ? kc + 1 : kc);      // the last iteration re-fetches its own chunk into the idle buffer: no branch
+      // keep the loads ABOVE the matrix work: hipcc otherwise sinks them below the MFMAs (shorter live ranges) and the
+      // store stage then eats the full memory latency right before the barrier
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (more) issue_loads(kc + 1);
+    }
     const float* Ab = As + buf * BM * LDK + (wm * WM + (lane & 31)) * LDK + (lane >> 5) * 4;
     const float* Bb = Bs + buf * BN * LDK + (wn * WN + (lane & 31)) * LDK + (lane >> 5) * 4;
 #pragma unroll
@@ -223,7 +286,12 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
 #pragma unroll
           for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
     }
-    if (more) store_stage(buf ^ 1);
+    if constexpr (ALLVEC) {
+      __builtin_amdgcn_sched_barrier(0);
+      store_stage(buf ^ 1);
+    } else {
+      if (more) store_stage(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -300,8 +368,9 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmParams p) {
 
 // ----------------------------------------------------------------------------------------------- weight gradient
 // ws[split][n][k] = sum over the split's pixels of G[pixel][n] * A[pixel][k].  Tile: BNW (n) x 128 (k), 32 pixels per step.
-template <int BNW, int WNn, int WKk>
-__global__ void __launch_bounds__(256) igemm_wgrad_kernel(const IgemmParams p) {
+// ALLVEC (every gathered operand and G float4-addressable with int32 offsets): straight-line staging, see igemm_conv_kernel.
+template <int BNW, int WNn, int WKk, bool ALLVEC>
+__global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const IgemmParams p) {
   constexpr int BKW = 128;
   constexpr int WAVES_K = BKW / WKk;
   constexpr int NI = WNn / 32, KI = WKk / 32;
@@ -325,8 +394,10 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const IgemmParams p) {
 
   const int g = tid & 7, r = tid >> 3;  // staging: row r of the 32-pixel step, 4-float group g
   // fixed per-thread K selections for the 4 chunks of this k tile
-  int q_s[4], q_j[4], q_c[4], q_kl[4];
-  bool q_live[4];
+  int q_s[4], q_j[4], q_c[4], q_kl[4], q_dy[4], q_dx[4];
+  bool q_live[4], q_kvalid[4];
+  f32x4 xsc[4], xsh[4];
+  float q_floor[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int kc = kt * 4 + q;
@@ -337,6 +408,21 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const IgemmParams p) {
     const KOperand& S = p.in[q_s[q]];
     q_j[q] = q_kl[q] / S.C;
     q_c[q] = q_kl[q] - q_j[q] * S.C;
+    q_kvalid[q] = q_live[q] && q_j[q] < ntaps;
+    const int t = taps[q_kvalid[q] ? q_j[q] : 0];
+    q_dy[q] = (int)(short)(t & 0xffff);
+    q_dx[q] = t >> 16;
+    if constexpr (ALLVEC) {
+      const bool has_aff = S.scale != nullptr;
+      const f32x4 l1 = *reinterpret_cast<const f32x4*>((has_aff ? S.scale : S.p) + q_c[q]);
+      const f32x4 l2 = *reinterpret_cast<const f32x4*>((has_aff ? S.shift : S.p) + q_c[q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xsc[q][e] = has_aff ? l1[e] : 1.f;
+        xsh[q][e] = has_aff ? l2[e] : 0.f;
+      }
+      q_floor[q] = has_aff ? 0.f : -__builtin_huge_valf();
+    }
   }
   const bool gvec = (p.Ntot % 4 == 0);
 
@@ -350,50 +436,75 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const IgemmParams p) {
 
   f32x4 gv[GR];
   AGroup xv[4];
-  f32x4 xsc[4], xsh[4];
   bool xaff[4];
 
   auto issue_loads = [&](int mbase) {
     const int m = mbase + r;
     const bool rowvalid = m < m_end;
-    int n = 0, by = 0, bx = 0;
-    if (rowvalid) {
-      int gx = m % p.GW, t = m / p.GW;
-      int gy = t % p.GH;
-      n = t / p.GH;
-      by = gy * p.sy;
-      bx = gx * p.sx;
-    }
+    if constexpr (ALLVEC) {
+      unsigned gx, gy;
+      const unsigned mm = rowvalid ? (unsigned)m : 0u;
+      const unsigned t = fastdiv(mm, (unsigned)p.GW, p.mGW, &gx);
+      const int n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+      const int by = (int)gy * p.sy, bx = (int)gx * p.sx;
+      const int grow = (int)mm * p.Ntot + n0 + g * 4;
 #pragma unroll
-    for (int i = 0; i < GR; ++i) {
-      const int col = n0 + g * 4 + 32 * i;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (rowvalid) {
-        const float* gp = p.g + (long long)m * p.Ntot + col;
-        if (gvec) {
-          if (col < p.Ntot) v = *reinterpret_cast<const f32x4*>(gp);
-        } else {
+      for (int i = 0; i < GR; ++i) {
+        const bool ok = rowvalid && (n0 + g * 4 + 32 * i) < p.Ntot;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.g + (ok ? grow + 32 * i : 0));
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < p.Ntot) v[e] = gp[e];
-        }
+        for (int e = 0; e < 4; ++e) gv[i][e] = ok ? v[e] : 0.f;
       }
-      gv[i] = v;
-    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      xaff[q] = false;
-      if (q_live[q]) {
+      for (int q = 0; q < 4; ++q) {
         const KOperand& S = p.in[q_s[q]];
-        if (S.vec && S.scale != nullptr && q_j[q] < ntaps) {
-          xsc[q] = *reinterpret_cast<const f32x4*>(S.scale + q_c[q]);
-          xsh[q] = *reinterpret_cast<const f32x4*>(S.shift + q_c[q]);
-          xaff[q] = true;
+        const int iy = by + q_dy[q], ix = bx + q_dx[q];
+        const bool ok = rowvalid && q_kvalid[q] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        int off = n * (int)S.sn + (iy >> S.up) * (int)S.sh + (ix >> S.up) * (int)S.sw + q_c[q];
+        off = ok ? off : 0;
+        xv[q].v = *reinterpret_cast<const f32x4*>(S.p + off);
+        xv[q].ok = ok;
+      }
+    } else {
+      int n = 0, by = 0, bx = 0;
+      if (rowvalid) {
+        int gx = m % p.GW, t = m / p.GW;
+        int gy = t % p.GH;
+        n = t / p.GH;
+        by = gy * p.sy;
+        bx = gx * p.sx;
+      }
+#pragma unroll
+      for (int i = 0; i < GR; ++i) {
+        const int col = n0 + g * 4 + 32 * i;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rowvalid) {
+          const float* gp = p.g + (long long)m * p.Ntot + col;
+          if (gvec) {
+            if (col < p.Ntot) v = *reinterpret_cast<const f32x4*>(gp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < p.Ntot) v[e] = gp[e];
+          }
         }
-        xv[q] = gather4(S, q_kl[q], ntaps, taps, n, by, bx, rowvalid, p.IH, p.IW, q_j[q], q_c[q]);
-      } else {
-        xv[q].v = f32x4{0.f, 0.f, 0.f, 0.f};
-        xv[q].ok = false;
+        gv[i] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xaff[q] = false;
+        if (q_live[q]) {
+          const KOperand& S = p.in[q_s[q]];
+          if (S.vec && S.scale != nullptr && q_j[q] < ntaps) {
+            xsc[q] = *reinterpret_cast<const f32x4*>(S.scale + q_c[q]);
+            xsh[q] = *reinterpret_cast<const f32x4*>(S.shift + q_c[q]);
+            xaff[q] = true;
+          }
+          xv[q] = gather4(S, q_kl[q], ntaps, taps, n, by, bx, rowvalid, p.IH, p.IW, q_j[q], q_c[q]);
+        } else {
+          xv[q].v = f32x4{0.f, 0.f, 0.f, 0.f};
+          xv[q].ok = false;
+        }
       }
     }
   };
@@ -406,11 +517,19 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const IgemmParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 v = xv[q].v;
-      if (xaff[q]) {
+      if constexpr (ALLVEC) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * xsc[q][e] + xsh[q][e]);
+        for (int e = 0; e < 4; ++e) {
+          const float t = fmaxf(q_floor[q], fmaf(v[e], xsc[q][e], xsh[q][e]));
+          v[e] = xv[q].ok ? t : 0.f;
+        }
+      } else {
+        if (xaff[q]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * xsc[q][e] + xsh[q][e]);
+        }
+        if (!xv[q].ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (!xv[q].ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(xs + 32 * q) = v;
     }
   };
@@ -424,7 +543,12 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const IgemmParams p) {
   for (int st = 0; st < nsteps; ++st) {
     const int buf = st & 1;
     const bool more = st + 1 < nsteps;
-    if (more) issue_loads(m_begin + (st + 1) * 32);
+    if constexpr (ALLVEC) {
+      issue_loads(m_begin + (more ? st + 1 : st) * 32);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (more) issue_loads(m_begin + (st + 1) * 32);
+    }
     const float* Gb = Gs + buf * 32 * BNW + (lane >> 5) * BNW + wn * WNn + (lane & 31);
     const float* Xb = Xs + buf * 32 * BKW + (lane >> 5) * BKW + wk * WKk + (lane & 31);
 #pragma unroll
@@ -439,7 +563,12 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < KI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_stage(buf ^ 1);
+    if constexpr (ALLVEC) {
+      __builtin_amdgcn_sched_barrier(0);
+      store_stage(buf ^ 1);
+    } else {
+      if (more) store_stage(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -519,15 +648,20 @@ static int enable_big_lds(K kernel, size_t bytes) {
   return DN_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_conv(const IgemmParams& p, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, bool ALLVEC>
+static int launch_conv_v(const IgemmParams& p, hipStream_t stream) {
   const size_t lds = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (kMaxTaps + BM) * sizeof(int);
-  auto kernel = igemm_conv_kernel<BM, BN, WM, WN>;
+  auto kernel = igemm_conv_kernel<BM, BN, WM, WN, ALLVEC>;
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
   dim3 grid((p.M + BM - 1) / BM, p.Npad / BN, p.nphases);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
   return check_launch("igemm_conv_kernel");
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv(const IgemmParams& p, hipStream_t stream) {
+  return p.allvec ? launch_conv_v<BM, BN, WM, WN, true>(p, stream) : launch_conv_v<BM, BN, WM, WN, false>(p, stream);
 }
 
 static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) {
@@ -550,15 +684,20 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
   }
 }
 
-template <int BNW, int WNn, int WKk>
-static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
+template <int BNW, int WNn, int WKk, bool ALLVEC>
+static int launch_wgrad_v(const IgemmParams& p, hipStream_t stream) {
   const size_t lds = (size_t)(2 * 32 * BNW + 2 * 32 * 128) * sizeof(float) + kMaxTaps * sizeof(int);
-  auto kernel = igemm_wgrad_kernel<BNW, WNn, WKk>;
+  auto kernel = igemm_wgrad_kernel<BNW, WNn, WKk, ALLVEC>;
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
   dim3 grid((p.ph[0].nchunks + 3) / 4, p.Npad / BNW, p.splits);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
   return check_launch("igemm_wgrad_kernel");
+}
+
+template <int BNW, int WNn, int WKk>
+static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
+  return p.allvec ? launch_wgrad_v<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_v<BNW, WNn, WKk, false>(p, stream);
 }
 
 static void choose_splits(IgemmParams* p) {
@@ -636,7 +775,12 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     o.sn = (long long)fwd->OH * fwd->OW * co;
     o.up = 0;
     o.vec = (co % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) ? 1 : 0;
+    o.mC = fastdiv_magic((unsigned)co);
+    o.small = ((long long)fwd->N * o.sn < (1ll << 31)) ? 1 : 0;
+    p.allvec = (o.vec && o.small) ? 1 : 0;
   }
+  // the G operand must be float4-addressable with int32 offsets too
+  if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0 && (long long)p.M * p.Ntot < (1ll << 31))) p.allvec = 0;
   hipStream_t s = as_stream(stream);
   switch (p.BN) {
     case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;

@@ -35,6 +35,8 @@ struct KOperand {                // device view of a dn_operand
   int up;
   int vec;                       // C % 4 == 0 && sc == 1 && 16-byte aligned rows  -> float4 path
   int ch_off;                    // first channel of this operand inside the concatenated K axis
+  unsigned mC;                   // fastdiv magic of C
+  int small;                     // every element offset fits int32 (fast path requirement)
 };
 
 struct KResult {
@@ -78,7 +80,12 @@ struct IgemmParams {
   const float* g;                // dy (or x for conv-transpose) [M][Ntot]
   float* ws;                     // [splits][Npad][Kp]
   int splits, m_per_split;
+  unsigned mGW, mGH;             // fastdiv magics of GW, GH
+  int allvec;                    // every operand takes the float4 fast path (and g, for wgrad)
 };
+
+// floor(n / d) for 0 <= n < 2^31 with a precomputed magic (see fastdiv_magic); branch-free
+static inline unsigned fastdiv_magic(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / d); }
 
 int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p);
 

@@ -49,6 +49,15 @@ static void fill_operand(KOperand* k, const dn_operand* o, int ch_off) {
                  (o->stride_h % 4 == 0) && (o->stride_w % 4 == 0);
   k->vec = (o->C % 4 == 0 && o->stride_c == 1 && aligned) ? 1 : 0;
   k->ch_off = ch_off;
+  k->mC = fastdiv_magic((unsigned)o->C);
+}
+
+// largest element offset the kernel may form for an operand stored as [N][Hs][Ws][C] with the given strides
+static bool offsets_fit_int32(const KOperand& k, int N, int IH, int IW) {
+  const long long hs = (IH >> k.up) + 1, ws = (IW >> k.up) + 1;
+  const long long span = (long long)N * (k.sn < 0 ? -k.sn : k.sn) + hs * (k.sh < 0 ? -k.sh : k.sh) +
+                         ws * (k.sw < 0 ? -k.sw : k.sw) + (long long)k.C * (k.sc < 0 ? -k.sc : k.sc);
+  return span < (1ll << 31);
 }
 
 int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
@@ -214,6 +223,14 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   long long m = (long long)p->N * p->GH * p->GW;
   DN_REQUIRE(m > 0 && m < (1ll << 31), DN_ERR_UNSUPPORTED, "grid too large");
   p->M = (int)m;
+  p->mGW = fastdiv_magic((unsigned)p->GW);
+  p->mGH = fastdiv_magic((unsigned)p->GH);
+  p->allvec = 1;
+  for (int i = 0; i < p->n_in; ++i) {
+    // (the conv-transpose wgrad operand is filled in by the caller, which re-evaluates allvec)
+    p->in[i].small = offsets_fit_int32(p->in[i], p->N, p->IH, p->IW) ? 1 : 0;
+    if (!(p->in[i].vec && p->in[i].small)) p->allvec = 0;
+  }
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;

@@ -302,13 +302,18 @@ struct ActBwdOp {
   }
 };
 
-// out[c] = sum_rows partial[(row*C + c)*stride + offset]
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, int stride, int offset, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// out[c] = sum_rows partial[(row*C + c)*stride + offset].  One 64-lane wave per channel: lanes stride over the rows
+// (fp64 accumulation), wave-shuffle reduction -- the row count is up to 1024, so a serial per-thread loop is latency-bound.
+__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, int stride, int offset,
+                                                              float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)partial[((long long)r * C + c) * stride + offset];
-  out[c] = (float)s;
+  for (int r = lane; r < rows; r += 64) s += (double)partial[((long long)r * C + c) * stride + offset];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[c] = (float)s;
 }
 
 __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(float* __restrict__ dz_dy, const float* __restrict__ y,
@@ -498,8 +503,8 @@ int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float
   DN_REQUIRE(dz_dy && y && mean && invstd && gamma && partial && dgamma && dbeta && rows > 0, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply: need C%%4==0");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, partial_rows, C, 2, 0, dbeta);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, partial_rows, C, 2, 1, dgamma);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, 2, 0, dbeta);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, 2, 1, dgamma);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, dz_dy, y, mean, invstd, gamma, dgamma, dbeta,
                      (long long)rows, C, (float)(1.0 / (double)rows));
   return check_launch("bn_bwd_apply");
@@ -514,7 +519,7 @@ int dn_act_bwd_reduce(float* g, const float* y_post, int32_t act, float p0, floa
 
 int dn_colsum_finalize(const float* partial, int32_t rows, int32_t C, int32_t stride, int32_t offset, float* out, dn_stream_t stream) {
   DN_REQUIRE(partial && out && rows > 0 && C > 0 && stride > 0 && offset >= 0 && offset < stride, DN_ERR_BAD_ARG, "dn_colsum_finalize: bad argument");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), partial, rows, C, stride, offset, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), partial, rows, C, stride, offset, out);
   return check_launch("colsum_finalize_kernel");
 }
 

@@ -41,8 +41,8 @@ def _pick_bn(ntot):
 class _Timed(object):
     """Context manager bracketing one C-ABI launch with HIP events when PROFILE is on."""
 
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, tag=""):
+        self.name, self.flops, self.tag = name, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -54,7 +54,7 @@ class _Timed(object):
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.tag))
         return False
 
 
@@ -233,7 +233,9 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
         rows = _lib.load().dn_conv_bn_partial_rows(C.byref(d))
         partial = torch.empty((rows, layer.Cout, 2), dtype=torch.float32, device=y.device)
         d.bn_partial = partial.data_ptr()
-    with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cout), 2 * layer.macs(N, IH, IW, OH, OW)):
+    with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cout), 2 * layer.macs(N, IH, IW, OH, OW),
+                "%s %dx%d k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_fwd" if layer.transposed else "conv_fwd", layer.R, layer.S,
+                                                               layer.R, layer.stride, layer.Cin, layer.Cout, N, IH, IW)):
         _lib.call("dn_convT2d_fwd" if layer.transposed else "dn_conv2d_fwd", C.byref(d), _stream())
     return y, partial, rows
 
@@ -258,7 +260,9 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None):
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
     dw = out if out is not None else torch.empty_like(layer.m.weight, memory_format=torch.contiguous_format)
     with _Timed("igemm_wgrad_kernel<%d>" % _pick_bn(layer.Cin if layer.transposed else layer.Cout),
-                2 * layer.macs(a0.N, IH, IW, OH, OW)):
+                2 * layer.macs(a0.N, IH, IW, OH, OW),
+                "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_wgrad" if layer.transposed else "conv_wgrad", layer.R, layer.stride,
+                                                         layer.Cin, layer.Cout, a0.N, IH, IW)):
         _lib.call("dn_conv2d_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
     return dw
 
@@ -299,7 +303,9 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
     d.w_packed = layer.packed(kind, d).data_ptr()
     d.bias = None
     d.act = ACT_NONE
-    with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cin), 2 * layer.macs(N, IH, IW, OH, OW)):
+    with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cin), 2 * layer.macs(N, IH, IW, OH, OW),
+                "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_dgrad" if layer.transposed else "conv_dgrad", layer.R, layer.stride,
+                                                         layer.Cin, layer.Cout, N, IH, IW)):
         _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
     for a, tmp in post:
         if a.C != 1:

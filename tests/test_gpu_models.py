@@ -4,8 +4,8 @@ closed-form inputs, and against the committed golden vectors that came from the 
 Stated fp32 tolerances (north_star: "match the reference PyTorch-CPU forward to a stated fp32 tolerance"):
   forward disparities         rtol 1e-3, atol 1e-4 * max|ref|   (27 conv layers + 13 training-mode BatchNorms deep)
   parameter gradients         per tensor: relative L2 error <= 2e-2 and at most 0.5 % of the elements outside
-                              (rtol 5e-3, atol 5e-3 * max|ref|); (tiny case) median error against an fp64 run of the oracle
-                              no worse than 10x PyTorch-CPU fp32's own median error.
+                              (rtol 5e-3, atol 5e-3 * max|ref|); (tiny case, decoder/head parameters) median error against
+                              an fp64 run of the oracle no worse than 10x PyTorch-CPU fp32's own median error.
                               Why not element-wise max: a ReLU / max-pool input that lies within fp32 round-off of zero
                               flips its mask between ANY two fp32 implementations (measured: features.28 channel 92,
                               |z| = 1.2e-6 * max, tests/gpu_diag_grads.py), which moves the affected channel's gradient
@@ -110,8 +110,8 @@ def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
     if full:
         # fp64 yardstick: the HIP fp32 path must be about as accurate as PyTorch-CPU fp32 is
         o64 = {k: (v.double() if torch.is_floating_point(v) else v.clone()) for k, v in sd0.items()}
-        for v in o64.values():
-            if torch.is_floating_point(v):
+        for k, v in o64.items():
+            if torch.is_floating_point(v) and "running" not in k:
                 v.requires_grad_(True)
         d64 = ON.disp_vgg_bn(o64, x.double(), training=True)
         dep64 = [1 / d for d in d64]
@@ -125,7 +125,11 @@ def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
             e_hip = float((p.grad.cpu().double() - g64).abs().median()) / scale
             e_cpu = float((osd[name].grad.double() - g64).abs().median()) / scale
             worst = max(worst, e_hip / max(e_cpu, 1e-9))
-            assert e_hip <= 10 * e_cpu + 1e-6, "%s: median HIP err %.3g vs CPU-fp32 err %.3g (relative to max|grad|)" % (name, e_hip, e_cpu)
+            # decoder / head parameters sit downstream of every BatchNorm+ReLU: no mask flip can reach them, so there the
+            # HIP path must be as accurate as PyTorch-CPU fp32 itself.  (Encoder layers upstream of a flipped mask move as
+            # a whole, see the module docstring; they are covered by grad_close above.)
+            if not name.startswith("features."):
+                assert e_hip <= 10 * e_cpu + 1e-6, "%s: median HIP err %.3g vs CPU-fp32 err %.3g (relative to max|grad|)" % (name, e_hip, e_cpu)
         print("worst HIP/CPU-fp32 median gradient error ratio vs fp64: %.2f" % worst)
     sd1 = net.state_dict()
     for key in ("features.features.1.running_mean", "features.features.1.running_var",
