@@ -10,6 +10,7 @@
 // group of 8 is permuted between the two half-waves (lanes<32 take k=0..3, lanes>=32 take k=4..7) so one b128 read feeds
 // four MFMAs.  Accumulation is an exact fp32 FMA chain (no reduced precision anywhere).
 #include <atomic>
+#include <stdlib.h>
 
 #include "dn_internal.h"
 
@@ -18,6 +19,9 @@ namespace dn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DN_STAGGER
+#define DN_STAGGER 0
+#endif
 constexpr int LDK = 36;  // padded LDS row (floats) of a [rows][32] K-chunk tile
 
 __device__ __forceinline__ float apply_act(float v, int act, float p0, float p1) {
@@ -39,6 +43,22 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned d, unsigned M, 
   r -= fix ? d : 0u;
   *rem = r;
   return q;
+}
+
+// Two blocks share a CU, i.e. two waves share each SIMD's matrix pipe.  Launched together they run IN PHASE (both in their MFMA
+// phase, then both staging: pipe idle ~25 % -- measured SQ_VALU_MFMA_BUSY 66 %).  A static priority asymmetry between the
+// two wave slots of a SIMD breaks the symmetry: the favoured wave keeps the pipe whenever it wants it, the other fills the
+// gaps while the first one stages.  HW_REG_HW_ID (id 4) bits [3:0] = wave slot within the SIMD.
+__device__ __forceinline__ void stagger_priority() {
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned slot = (lin >> 8) & 1u;
+#if DN_STAGGER == 2
+  if (slot & 1u) {
+    __builtin_amdgcn_s_sleep(64);   // ~4k cycles: start the odd slot half a chunk late
+  }
+#else
+  if (slot & 1u) __builtin_amdgcn_s_setprio(2);
+#endif
 }
 
 // Which operand piece does K-chunk `kc` of a phase with `ntaps` taps fall in?  Uniform across the block.
@@ -119,6 +139,7 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_kernel(const IgemmParams p)
   int* taps = reinterpret_cast<int*>(Bs + 2 * BN * LDK);   // [kMaxTaps]  (dy | dx<<16)
   int* rowpix = taps + kMaxTaps;                           // [BM] output pixel index or -1
 
+  if (DN_STAGGER) stagger_priority();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -381,6 +402,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const IgemmParams p
   float* Xs = smem + 2 * 32 * BNW;                         // [2][32][BKW]
   int* taps = reinterpret_cast<int*>(Xs + 2 * 32 * BKW);   // [kMaxTaps]
 
+  if (DN_STAGGER) stagger_priority();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WAVES_K, wk = wave % WAVES_K;
   const int kt = blockIdx.x, n0 = blockIdx.y * BNW;
@@ -650,7 +672,8 @@ static int enable_big_lds(K kernel, size_t bytes) {
 
 template <int BM, int BN, int WM, int WN, bool ALLVEC>
 static int launch_conv_v(const IgemmParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (kMaxTaps + BM) * sizeof(int);
+  size_t lds = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (kMaxTaps + BM) * sizeof(int);
+  if (const char* e = getenv("DN_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(e);   // tuning aid: lowers blocks per CU
   auto kernel = igemm_conv_kernel<BM, BN, WM, WN, ALLVEC>;
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;

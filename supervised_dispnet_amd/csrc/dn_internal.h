@@ -82,6 +82,9 @@ struct IgemmParams {
   int splits, m_per_split;
   unsigned mGW, mGH;             // fastdiv magics of GW, GH
   int allvec;                    // every operand takes the float4 fast path (and g, for wgrad)
+  int uni32;                     // additionally: every operand has C % 32 == 0, no upsample, < 2 GiB span, <= 32 taps
+                                 //   -> block-uniform tap/channel per K chunk, buffer loads with hardware range check
+  int any_affine;                // some operand carries a pending BN-apply + ReLU
 };
 
 // floor(n / d) for 0 <= n < 2^31 with a precomputed magic (see fastdiv_magic); branch-free
