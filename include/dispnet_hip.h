@@ -182,15 +182,33 @@ int dn_reciprocal_bwd(const float* dy, const float* y, float* dx, int64_t n, dn_
 /* ------------------------------------------------------------------------------------------------------------
  * Losses and metrics (loss_functions.py)
  * ------------------------------------------------------------------------------------------------------------ */
-enum dn_masked_loss_kind { DN_LOSS_L1 = 0, DN_LOSS_L2 = 1 };
-/* l1_loss / l2_loss (loss_functions.py:77-129): per sample mean over valid = 0<gt<max_depth of
- * f(gt - clamp(pred,1e-3,max_depth)), then mean over the batch.  sample_stats: [B][2] (sum, count) scratch.
- * loss: 1 float.  Empty mask -> NaN like the reference. */
-int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t B, int64_t pixels, float max_depth, int32_t kind,
-                       float* sample_stats, float* loss, dn_stream_t stream);
-/* dpred = dloss * f'(.) / (count_b * B) inside the clamp range, 0 elsewhere.  dloss: device scalar. */
-int dn_masked_loss_bwd(const float* gt, const float* pred, const float* sample_stats, const float* dloss, int32_t B,
-                       int64_t pixels, float max_depth, int32_t kind, float* dpred, dn_stream_t stream);
+enum dn_masked_loss_kind { DN_LOSS_L1 = 0, DN_LOSS_L2 = 1, DN_LOSS_BERHU = 2, DN_LOSS_SCALE_INV = 3 };
+#define DN_LOSS_STATS 8   /* floats of per-group statistics kept between forward and backward */
+/* The masked depth-loss family: l1_loss / l2_loss / berhu_loss / Scale_invariant_loss (loss_functions.py:77-189, one
+ * group per SAMPLE: G = B, pixels = H*W) and Multiscale_{L1,FULL_L1,L2,berhu,scale_inv}_loss (:217-315, one group per
+ * SCALE over the whole batch: G = 1, pixels = B*h*w, weight = 1/2^i, accumulate = (i > 0)).
+ * Per group: mean over valid = 0 < gt < max_depth of f(gt, clamp(pred, 1e-3, max_depth)); then
+ *   loss[0] = (accumulate ? loss[0] : 0) + weight * (1/G) * sum_g L_g.   Empty mask -> NaN like the reference.
+ * stats: [G][DN_LOSS_STATS] (kept for the backward); workspace: dn_masked_loss_workspace_bytes(). */
+size_t dn_masked_loss_workspace_bytes(int32_t G, int64_t pixels);
+int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, float weight,
+                       int32_t accumulate, float* stats, void* workspace, size_t workspace_bytes, float* loss, dn_stream_t stream);
+/* dpred = dloss * weight/G * dL_g/dpred  (0 outside the mask / clamp range).  berHu includes the gradient through its
+ * max-residual threshold, like torch autograd.  dloss: device scalar. */
+int dn_masked_loss_bwd(const float* gt, const float* pred, const float* stats, const float* dloss, int32_t G, int64_t pixels,
+                       float max_depth, int32_t kind, float weight, float* dpred, dn_stream_t stream);
+/* One level of generate_{max,avg,bilinear}_pyramid (loss_functions.py:191-215): [N][H][W] -> [N][H/2][W/2];
+ * mode 0 max_pool2d(2,2), 1 avg_pool2d(2,2), 2 F.interpolate(scale_factor=0.5, bilinear, align_corners=False). */
+int dn_pyramid_down2(const float* in, int32_t N, int32_t H, int32_t W, int32_t mode, float* out, dn_stream_t stream);
+/* F.upsample(x, scale_factor=s, mode) of a 1-channel map (Multiscale_FULL_L1_loss, loss_functions.py:243):
+ * mode 0 nearest, 1 bilinear (align_corners=False).  [N][h][w] -> [N][h*s][w*s]. */
+int dn_upsample_int_fwd(const float* low, int32_t N, int32_t h, int32_t w, int32_t scale, int32_t mode, float* out, dn_stream_t stream);
+int dn_upsample_int_bwd(const float* dout, int32_t N, int32_t h, int32_t w, int32_t scale, int32_t mode, float* dlow, dn_stream_t stream);
+/* explainability_loss (loss_functions.py:357-364) for one mask tensor of n elements: binary_cross_entropy(mask, 1).
+ * partial: [dn_reduce1d_blocks(n)] scratch. */
+int32_t dn_reduce1d_blocks(int64_t n);
+int dn_explainability_fwd(const float* mask, int64_t n, float weight, int32_t accumulate, float* partial, float* loss, dn_stream_t stream);
+int dn_explainability_bwd(const float* mask, const float* dloss, int64_t n, float* dmask, dn_stream_t stream);
 /* smooth_loss for ONE map [B][H][W] (loss_functions.py:367-386): sum of the 4 second-difference |.|.mean() terms,
  * scaled by `weight`, accumulated into loss[0] (caller zeroes it).  partial: scratch [dn_smooth_blocks][4]. */
 int32_t dn_smooth_blocks(int32_t B, int32_t H, int32_t W);
@@ -199,9 +217,81 @@ int dn_smooth2_fwd(const float* map, int32_t B, int32_t H, int32_t W, float weig
 int dn_smooth2_bwd(const float* map, const float* dloss, int32_t B, int32_t H, int32_t W, float weight, float* dmap,
                    dn_stream_t stream);
 /* compute_errors (loss_functions.py:401-448): out[8] = abs_diff, abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3.
- * crop rows [y1,y2) cols [x1,x2) (pass 0,H,0,W for none).  scratch: [B][9] floats. */
+ * crop rows [y1,y2) cols [x1,x2) (pass 0,H,0,W for none).  median_scaling != 0: valid_pred *= median(gt)/median(pred)
+ * per sample (:432-433, torch.median = lower middle; exact radix select).  scratch: [B][11] floats. */
 int dn_compute_errors(const float* gt, const float* pred, int32_t B, int32_t H, int32_t W, float max_depth, int32_t y1,
-                      int32_t y2, int32_t x1, int32_t x2, float* scratch, float* out8, dn_stream_t stream);
+                      int32_t y2, int32_t x1, int32_t x2, int32_t median_scaling, float* scratch, float* out8,
+                      dn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Geometry / photometric family (inverse_warp.py, loss_functions.py:317-354, layers.py:199-245)
+ * Images are planar [B][3][h][w]; depth [B][h][w]; rotation_mode 0 euler / 1 quat; padding_mode 0 zeros / 1 border;
+ * align_corners is F.grid_sample's flag (the reference passes none: False on torch >= 1.3, True on its pinned 1.0.1).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* pose_vec2mat + `intrinsics @ pose_mat` (inverse_warp.py:141-157,185-188) with the per-scale intrinsics rescaling of
+ * loss_functions.py:328-329 folded in (downscale = 1 for plain inverse_warp):
+ *   proj[b] (3x4) = K_s @ [R(pose)|t],  kinv_scaled[b] (3x3) = Kinv with columns 0,1 * downscale.
+ * pose element (b, j) at pose[b*pose_stride_b + j], j = tx,ty,tz,rx,ry,rz. */
+int dn_pose_proj_fwd(const float* pose, int64_t pose_stride_b, const float* K, const float* Kinv, int32_t B, int32_t rotation_mode,
+                     float downscale, float* proj, float* kinv_scaled, dn_stream_t stream);
+/* dpose from the per-block partial sums of dproj ([B][nblk][12], nblk = dn_warp_blocks(h,w)) written by the *_bwd below. */
+int32_t dn_warp_blocks(int32_t h, int32_t w);
+int dn_pose_proj_bwd(const float* pose, int64_t pose_stride_b, const float* K, int32_t B, int32_t rotation_mode, float downscale,
+                     const float* dproj_partial, int32_t nblk, float* dpose, int64_t dpose_stride_b, int32_t accumulate,
+                     dn_stream_t stream);
+/* inverse_warp (inverse_warp.py:160-193): pixel2cam, projection, cam2pixel (zeros padding: out-of-range coordinates := 2,
+ * no gradient), bilinear grid_sample.  warped: [B][3][h][w]. */
+int dn_inverse_warp_fwd(const float* img, const float* depth, const float* proj, const float* kinv, int32_t B, int32_t h, int32_t w,
+                        int32_t padding_mode, int32_t align_corners, float* warped, dn_stream_t stream);
+/* gradients w.r.t. depth ([B][h][w], overwrite / accumulate) and the projection (partials, see dn_pose_proj_bwd). */
+int dn_inverse_warp_bwd(const float* img, const float* depth, const float* proj, const float* kinv, int32_t B, int32_t h, int32_t w,
+                        int32_t padding_mode, int32_t align_corners, const float* dwarped, float* ddepth, int32_t accumulate_depth,
+                        float* dproj_partial, dn_stream_t stream);
+/* One (scale, reference image) term of photometric_reconstruction_loss (loss_functions.py:331-342), fused: warp `ref`,
+ * out-of-bound mask = 1 - prod_c(warped_c == 0), diff = (tgt - warped) * oob [* mask], loss (+)= weight * mean|diff|.
+ * mask: explainability mask element (b,y,x) at mask[b*mask_stride_b + y*w + x], or NULL.
+ * partial: [B * dn_warp_blocks(h,w)] scratch. */
+int dn_photometric_fwd(const float* tgt, const float* ref, const float* depth, const float* proj, const float* kinv, const float* mask,
+                       int64_t mask_stride_b, int32_t B, int32_t h, int32_t w, int32_t padding_mode, int32_t align_corners, float weight,
+                       int32_t accumulate, float* partial, float* loss, dn_stream_t stream);
+int dn_photometric_bwd(const float* tgt, const float* ref, const float* depth, const float* proj, const float* kinv, const float* mask,
+                       int64_t mask_stride_b, int32_t B, int32_t h, int32_t w, int32_t padding_mode, int32_t align_corners, float weight,
+                       const float* dloss, float* ddepth, int32_t accumulate_depth, float* dproj_partial, float* dmask,
+                       int64_t dmask_stride_b, dn_stream_t stream);
+/* F.interpolate(x, (H/f, W/f), mode='area') for an exact integer factor (loss_functions.py:326-327): f x f mean. */
+int dn_area_down(const float* in, int64_t planes, int32_t H, int32_t W, int32_t factor, float* out, dn_stream_t stream);
+/* layers.SSIM.forward (layers.py:215-245) on [planes][H][W]; backward workspace: 5*planes*H*W floats; dx / dy nullable. */
+int dn_ssim_fwd(const float* x, const float* y, int64_t planes, int32_t H, int32_t W, float* out, dn_stream_t stream);
+int dn_ssim_bwd(const float* x, const float* y, const float* dout, int64_t planes, int32_t H, int32_t W, float* workspace, float* dx,
+                float* dy, dn_stream_t stream);
+/* layers.get_smooth_loss (layers.py:199-212): disp [B][1][H][W], img [B][C][H][W]; partial: [dn_edge_smooth_blocks][2]. */
+int32_t dn_edge_smooth_blocks(int32_t B, int32_t H, int32_t W);
+int dn_edge_smooth_fwd(const float* disp, const float* img, int32_t B, int32_t C, int32_t H, int32_t W, float* partial, float* loss,
+                       dn_stream_t stream);
+int dn_edge_smooth_bwd(const float* disp, const float* img, const float* dloss, int32_t B, int32_t C, int32_t H, int32_t W, float* ddisp,
+                       dn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DORN ordinal head and loss (models/Disp_vgg_BN_DORN.py:196-227, loss_functions.py:16-74, utils.py:106-175)
+ * ------------------------------------------------------------------------------------------------------------ */
+/* OrdinalRegressionLayer: pre = logits, element (n, pixel, channel) at pre[n*stride_n + pixel*stride_pix + channel*stride_c]
+ * (NHWC: 2K*HW, 2K, 1; NCHW: 2K*HW, 1, HW), channel pairs (A,B) = (2k, 2k+1); ord = planar [N][K][HW] =
+ * softmax(clamp(A), clamp(B))[1]; decode = [N][HW] int64 count of ord > 0.5.  dpre has the layout of pre. */
+int dn_ordinal_fwd(const float* pre, int64_t stride_n, int64_t stride_pix, int64_t stride_c, int32_t N, int64_t HW, int32_t K, float* ord,
+                   int64_t* decode, dn_stream_t stream);
+int dn_ordinal_bwd(const float* pre, int64_t stride_n, int64_t stride_pix, int64_t stride_c, const float* ord, const float* dord, int32_t N,
+                   int64_t HW, int32_t K, float* dpre, dn_stream_t stream);
+/* DORN_loss: target = SID labels int32 [N][HW]; stats[2] = (sum, num_valid) kept for the backward. */
+int32_t dn_ordinal_loss_blocks(int32_t N, int64_t HW);
+int dn_ordinal_loss_fwd(const float* ord, const float* gt, const int32_t* target, int32_t N, int64_t HW, int32_t K, float max_depth,
+                        float* partial, float* stats, float* loss, dn_stream_t stream);
+int dn_ordinal_loss_bwd(const float* ord, const float* gt, const int32_t* target, const float* stats, const float* dloss, int32_t N,
+                        int64_t HW, int32_t K, float max_depth, float* dord, dn_stream_t stream);
+/* get_labels_sid / get_depth_sid (beta = 80.999 kitti, 10.999 nyu). */
+int dn_sid_labels(const float* depth, int64_t n, float ordinal_c, float beta, int32_t* labels, dn_stream_t stream);
+int dn_sid_depth(const int64_t* labels, int64_t n, float ordinal_c, float beta, float* depth, dn_stream_t stream);
+/* Dropout2d apply (and its backward): out[n][p][c] = x[n][p][c] * mask[n][c], NHWC. */
+int dn_channel_scale(const float* x, const float* mask, int32_t N, int64_t HW, int32_t C, float* out, dn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer (train.py:303-305,520-522: torch.optim.Adam, wd = 0) over a flat parameter arena.

@@ -13,7 +13,8 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
-LOSS_L1, LOSS_L2 = 0, 1
+LOSS_L1, LOSS_L2, LOSS_BERHU, LOSS_SCALE_INV = 0, 1, 2, 3
+LOSS_STATS = 8
 
 _f32p = C.c_void_p  # device pointers travel as integers
 
@@ -69,12 +70,41 @@ SIGNATURES = {
     "dn_upsample2x_bilinear_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "dn_reciprocal_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "dn_reciprocal_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
-    "dn_masked_loss_fwd": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _vp, _vp, _vp]),
-    "dn_masked_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _f, _i32, _vp, _vp]),
+    "dn_masked_loss_workspace_bytes": (_sz, [_i32, _i64]),
+    "dn_masked_loss_fwd": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _f, _i32, _vp, _vp, _sz, _vp, _vp]),
+    "dn_masked_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _f, _i32, _f, _vp, _vp]),
+    "dn_pyramid_down2": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_upsample_int_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_upsample_int_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_reduce1d_blocks": (_i32, [_i64]),
+    "dn_explainability_fwd": (C.c_int, [_vp, _i64, _f, _i32, _vp, _vp, _vp]),
+    "dn_explainability_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "dn_smooth_blocks": (_i32, [_i32, _i32, _i32]),
     "dn_smooth2_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _f, _vp, _vp, _vp]),
     "dn_smooth2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
-    "dn_compute_errors": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_compute_errors": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_pose_proj_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp]),
+    "dn_warp_blocks": (_i32, [_i32, _i32]),
+    "dn_pose_proj_bwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _f, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "dn_inverse_warp_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_inverse_warp_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "dn_photometric_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f, _i32, _vp, _vp, _vp]),
+    "dn_photometric_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f, _vp, _vp, _i32, _vp, _vp,
+                                     _i64, _vp]),
+    "dn_area_down": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "dn_ssim_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "dn_ssim_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "dn_edge_smooth_blocks": (_i32, [_i32, _i32, _i32]),
+    "dn_edge_smooth_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_edge_smooth_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_ordinal_fwd": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "dn_ordinal_bwd": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "dn_ordinal_loss_blocks": (_i32, [_i32, _i64]),
+    "dn_ordinal_loss_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp]),
+    "dn_ordinal_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _vp, _vp]),
+    "dn_sid_labels": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
+    "dn_sid_depth": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
+    "dn_channel_scale": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i32, _d, _vp]),
     "dn_fill": (C.c_int, [_vp, _f, _i64, _vp]),
     # diagnostic hook (host only)

@@ -34,54 +34,269 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* lds /* [NV * 16
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-// ------------------------------------------------------------------------------------------- masked L1 / L2
-// one block per sample: (sum f(gt - clamp(pred)), count) over valid = 0 < gt < max_depth
-__global__ void __launch_bounds__(kLossThreads) masked_loss_stats_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
-                                                                         long long pixels, float max_depth, int kind,
-                                                                         float* __restrict__ stats) {
-  const int b = blockIdx.x;
-  const float* g = gt + (long long)b * pixels;
-  const float* p = pred + (long long)b * pixels;
-  float acc[2] = {0.f, 0.f};
-  for (long long i = threadIdx.x; i < pixels; i += kLossThreads) {
-    const float gv = g[i];
+// ------------------------------------------------------------------------------------- masked depth losses
+// A "group" is a run of `pixels` consecutive elements that shares one mask mean: one sample for l1/l2/berhu/scale-inv
+// (loss_functions.py:77-189), the whole batch for the Multiscale_* family (:217-315).  valid = 0 < gt < max_depth,
+// p = clamp(pred, 1e-3, max_depth), d = gt - p, r = |d|.
+//   L1   : mean r                 L2 : mean d^2
+//   berHu: c = 0.2 max r;  mean( r > c ? (r^2 + c^2)/(2c) : r )      (the max is differentiable, like torch's)
+//   SI   : mean (|gt|-|p|)^2 - 0.5 (sum d)^2 / n^2
+// stats[g][8]: 0 sum f | 1 n | 2 sum d (SI) or sum_{r>c} (0.5 - r^2/(2c^2)) (berHu) | 3 max r | 4 #(r == max) | 5 group loss
+constexpr int kStat = 8;
+constexpr int kSplitMax = 64;
+
+static inline int loss_splits(long long pixels) {
+  long long s = (pixels + 16383) / 16384;
+  return (int)(s < 1 ? 1 : (s > kSplitMax ? kSplitMax : s));
+}
+
+// pass A: per (split, group) partial [4] = (sum f, n, sum d, max r); berHu only needs n and max here
+__global__ void __launch_bounds__(256) masked_stats_kernel(const float* __restrict__ gt, const float* __restrict__ pred, long long pixels,
+                                                           float max_depth, int kind, float* __restrict__ partial) {
+  const int g = blockIdx.y, sp = blockIdx.x, nsp = gridDim.x;
+  const float* G = gt + (long long)g * pixels;
+  const float* P = pred + (long long)g * pixels;
+  float acc[3] = {0.f, 0.f, 0.f};
+  float mx = 0.f;
+  for (long long i = sp * 256ll + threadIdx.x; i < pixels; i += nsp * 256ll) {
+    const float gv = G[i];
     if (gv > 0.f && gv < max_depth) {
-      const float d = gv - clampf(p[i], 1e-3f, max_depth);
-      acc[0] += (kind == DN_LOSS_L1) ? fabsf(d) : d * d;
+      const float p = clampf(P[i], 1e-3f, max_depth);
+      const float d = gv - p;
+      float f;
+      if (kind == DN_LOSS_L1) f = fabsf(d);
+      else if (kind == DN_LOSS_L2) f = d * d;
+      else if (kind == DN_LOSS_SCALE_INV) { const float e = fabsf(gv) - fabsf(p); f = e * e; }
+      else f = 0.f;
+      acc[0] += f;
       acc[1] += 1.f;
+      acc[2] += d;
+      mx = fmaxf(mx, fabsf(d));
     }
   }
-  __shared__ float lds[2 * 16];
-  block_sum<2>(acc, lds);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  __shared__ float lds[3 * 16];
+  __shared__ float lmx[4];
+  if ((threadIdx.x & 63) == 0) lmx[threadIdx.x >> 6] = mx;
+  block_sum<3>(acc, lds);
   if (threadIdx.x == 0) {
-    stats[b * 2 + 0] = acc[0];
-    stats[b * 2 + 1] = acc[1];
+    float* o = partial + ((long long)g * nsp + sp) * 4;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    o[3] = fmaxf(fmaxf(lmx[0], lmx[1]), fmaxf(lmx[2], lmx[3]));
   }
 }
 
-__global__ void masked_loss_finalize_kernel(const float* __restrict__ stats, int B, float* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += stats[b * 2] / stats[b * 2 + 1];   // 0/0 -> NaN like mean of empty
-    loss[0] = s / (float)B;
+// reduces the split partials of every group (one thread per group; G and nsp are small)
+__global__ void masked_reduceA_kernel(const float* __restrict__ partial, int G, int nsp, float* __restrict__ stats) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, mx = 0.f;
+  for (int k = 0; k < nsp; ++k) {
+    const float* p = partial + ((long long)g * nsp + k) * 4;
+    s0 += p[0]; s1 += p[1]; s2 += p[2]; mx = fmaxf(mx, p[3]);
   }
+  float* o = stats + g * kStat;
+  o[0] = s0; o[1] = s1; o[2] = s2; o[3] = mx; o[4] = 0.f;
+}
+
+// berHu pass B: with c = 0.2 max r known: partial [4] = (sum f, sum_{r>c} (0.5 - r^2/(2c^2)), #(r == max), 0)
+__global__ void __launch_bounds__(256) berhu_stats_kernel(const float* __restrict__ gt, const float* __restrict__ pred, long long pixels,
+                                                          float max_depth, const float* __restrict__ stats, float* __restrict__ partial) {
+  const int g = blockIdx.y, sp = blockIdx.x, nsp = gridDim.x;
+  const float* G = gt + (long long)g * pixels;
+  const float* P = pred + (long long)g * pixels;
+  const float mx = stats[g * kStat + 3];
+  const float c = 0.2f * mx;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (long long i = sp * 256ll + threadIdx.x; i < pixels; i += nsp * 256ll) {
+    const float gv = G[i];
+    if (gv > 0.f && gv < max_depth) {
+      const float r = fabsf(gv - clampf(P[i], 1e-3f, max_depth));
+      if (r > c) {
+        acc[0] += (r * r + c * c) / (2.f * c);
+        acc[1] += 0.5f - (r * r) / (2.f * c * c);
+      } else {
+        acc[0] += r;
+      }
+      if (r == mx) acc[2] += 1.f;
+    }
+  }
+  __shared__ float lds[3 * 16];
+  block_sum<3>(acc, lds);
+  if (threadIdx.x == 0) {
+    float* o = partial + ((long long)g * nsp + sp) * 4;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = 0.f;
+  }
+}
+
+__global__ void masked_reduceB_kernel(const float* __restrict__ partial, int G, int nsp, float* __restrict__ stats) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nsp; ++k) {
+    const float* p = partial + ((long long)g * nsp + k) * 4;
+    s0 += p[0]; s1 += p[1]; s2 += p[2];
+  }
+  float* o = stats + g * kStat;
+  o[0] = s0; o[2] = s1; o[4] = s2;
+}
+
+// loss[0] = (accumulate ? loss[0] : 0) + weight * (1/G) sum_g L_g        (0/0 -> NaN like the mean of an empty selection)
+__global__ void masked_loss_finalize_kernel(float* __restrict__ stats, int G, int kind, float weight, int accumulate, float* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) {
+    float* st = stats + g * kStat;
+    const float n = st[1];
+    float L = st[0] / n;
+    if (kind == DN_LOSS_SCALE_INV) L = L - (st[2] * st[2]) * 0.5f / (n * n);
+    st[5] = L;
+    s += L;
+  }
+  const float v = weight * (s / (float)G);
+  loss[0] = accumulate ? loss[0] + v : v;
 }
 
 __global__ void masked_loss_bwd_kernel(const float* __restrict__ gt, const float* __restrict__ pred, const float* __restrict__ stats,
-                                       const float* __restrict__ dloss, int B, long long pixels, float max_depth, int kind,
+                                       const float* __restrict__ dloss, int G, long long pixels, float max_depth, int kind, float weight,
                                        float* __restrict__ dpred) {
-  const long long total = (long long)B * pixels;
-  const float dl = dloss[0];
+  const long long total = (long long)G * pixels;
+  const float up = dloss[0] * weight / (float)G;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / pixels);
+    const int g = (int)(i / pixels);
+    const float* st = stats + g * kStat;
     const float gv = gt[i], pv = pred[i];
     float out = 0.f;
-    if (gv > 0.f && gv < max_depth && pv >= 1e-3f && pv <= max_depth) {
-      const float d = pv - gv;   // d/dpred of f(gt - pred)
-      const float fp = (kind == DN_LOSS_L1) ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
-      out = dl * fp / (stats[b * 2 + 1] * (float)B);
+    if (gv > 0.f && gv < max_depth && pv >= 1e-3f && pv <= max_depth) {   // clamp passes gradient inside [lo, hi]
+      const float n = st[1];
+      const float d = pv - gv;                                             // = -(gt - p)
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);             // d|gt-p|/dp
+      float fp;
+      if (kind == DN_LOSS_L1) fp = sg / n;
+      else if (kind == DN_LOSS_L2) fp = 2.f * d / n;
+      else if (kind == DN_LOSS_SCALE_INV) fp = 2.f * d / n + st[2] / (n * n);   // st[2] = sum (gt - p)
+      else {
+        const float mx = st[3], c = 0.2f * mx, r = fabsf(d);
+        float dr = (r > c) ? r / c : 1.f;
+        if (r == mx) dr += 0.2f * st[2] / st[4];                           // through c = 0.2 max r, ties share evenly
+        fp = sg * dr / n;
+      }
+      out = up * fp;
     }
     dpred[i] = out;
+  }
+}
+
+// ------------------------------------------------------------------- ground-truth pyramids (loss_functions.py:191-215)
+// one level: out[n][y][x] from the 2x2 block of in; mode 0 max_pool2d, 1 avg_pool2d (((a+b)+c)+d)/4, 2 bilinear x0.5
+// align_corners=False = ((0.25a + 0.25b) + 0.25c) + 0.25d  (ATen's operation order, probed)
+__global__ void pyramid_down2_kernel(const float* __restrict__ in, int N, int H, int W, int mode, float* __restrict__ out) {
+  const int oh = H / 2, ow = W / 2;
+  const long long total = (long long)N * oh * ow;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh), n = (int)(i / ((long long)ow * oh));
+    const float* p = in + ((long long)n * H + 2 * y) * W + 2 * x;
+    const float a = p[0], b = p[1], c = p[W], d = p[W + 1];
+    float v;
+    if (mode == 0) v = fmaxf(fmaxf(a, b), fmaxf(c, d));
+    else if (mode == 1) v = (((a + b) + c) + d) / 4.f;
+    else v = ((0.25f * a + 0.25f * b) + 0.25f * c) + 0.25f * d;
+    out[i] = v;
+  }
+}
+
+// -------------------------------------------- integer-factor upsample of a 1-channel map (Multiscale_FULL_L1_loss :243)
+// mode 0 nearest, 1 bilinear align_corners=False.  fwd gathers; bwd gathers too (each low pixel sums its dependants).
+__device__ __forceinline__ void bil_src(int o, int scale, int n_in, int* i0, int* i1, float* l1) {
+  float s = ((float)o + 0.5f) / (float)scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  const int a = (int)s;
+  *i0 = a;
+  *i1 = a + (a < n_in - 1 ? 1 : 0);
+  *l1 = s - (float)a;
+}
+
+__global__ void upsample_int_fwd_kernel(const float* __restrict__ low, int N, int h, int w, int scale, int mode, float* __restrict__ out) {
+  const int OH = h * scale, OW = w * scale;
+  const long long total = (long long)N * OH * OW;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % OW), y = (int)((i / OW) % OH), n = (int)(i / ((long long)OW * OH));
+    const float* L = low + (long long)n * h * w;
+    if (mode == 0) {
+      out[i] = L[(y / scale) * w + x / scale];
+    } else {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      bil_src(y, scale, h, &y0, &y1, &ly);
+      bil_src(x, scale, w, &x0, &x1, &lx);
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      out[i] = hy * (hx * L[y0 * w + x0] + lx * L[y0 * w + x1]) + ly * (hx * L[y1 * w + x0] + lx * L[y1 * w + x1]);
+    }
+  }
+}
+
+__global__ void upsample_int_bwd_kernel(const float* __restrict__ dout, int N, int h, int w, int scale, int mode, float* __restrict__ dlow) {
+  const int OH = h * scale, OW = w * scale;
+  const long long total = (long long)N * h * w;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), n = (int)(i / ((long long)w * h));
+    const float* D = dout + (long long)n * OH * OW;
+    float s = 0.f;
+    if (mode == 0) {
+      for (int dy = 0; dy < scale; ++dy)
+        for (int dx = 0; dx < scale; ++dx) s += D[(y * scale + dy) * OW + x * scale + dx];
+    } else {
+      // output rows that can touch low row y: those whose (y0, y1) contains y  ->  o in [(y-1)*scale - scale, (y+1)*scale + scale)
+      const int oy_lo = max(0, (y - 1) * scale - scale), oy_hi = min(OH, (y + 2) * scale + scale);
+      const int ox_lo = max(0, (x - 1) * scale - scale), ox_hi = min(OW, (x + 2) * scale + scale);
+      for (int oy = oy_lo; oy < oy_hi; ++oy) {
+        int y0, y1;
+        float ly;
+        bil_src(oy, scale, h, &y0, &y1, &ly);
+        float wy = 0.f;
+        if (y0 == y) wy += 1.f - ly;
+        if (y1 == y) wy += ly;
+        if (wy == 0.f) continue;
+        for (int ox = ox_lo; ox < ox_hi; ++ox) {
+          int x0, x1;
+          float lx;
+          bil_src(ox, scale, w, &x0, &x1, &lx);
+          float wx = 0.f;
+          if (x0 == x) wx += 1.f - lx;
+          if (x1 == x) wx += lx;
+          if (wx != 0.f) s += wy * wx * D[oy * OW + ox];
+        }
+      }
+    }
+    dlow[i] = s;
+  }
+}
+
+// ----------------------------------------------------------------- explainability_loss (loss_functions.py:357-364)
+// binary_cross_entropy(mask, 1) = mean(-max(log(m), -100)); accumulated into loss[0] by the finalize
+__global__ void __launch_bounds__(256) neglog_sum_kernel(const float* __restrict__ m, long long n, float* __restrict__ partial) {
+  float acc[1] = {0.f};
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc[0] -= fmaxf(logf(m[i]), -100.f);
+  __shared__ float lds[16];
+  block_sum<1>(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+
+__global__ void mean_finalize_kernel(const float* __restrict__ partial, int blocks, double count, float weight, int accumulate,
+                                     float* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0;
+  for (int b = 0; b < blocks; ++b) s += (double)partial[b];
+  const float v = (float)(s / count) * weight;
+  loss[0] = accumulate ? loss[0] + v : v;
+}
+
+__global__ void neglog_bwd_kernel(const float* __restrict__ m, const float* __restrict__ dloss, long long n, float* __restrict__ dm) {
+  const float up = dloss[0] / (float)n;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float x = m[i];
+    dm[i] = up * (x - 1.f) / fmaxf((1.f - x) * x, 1e-12f);      // ATen's binary_cross_entropy_backward with target = 1
   }
 }
 
@@ -173,7 +388,7 @@ __global__ void __launch_bounds__(256) smooth2_bwd_kernel(const float* __restric
 // one block per sample -> scratch[b][9] = sums of (abs_diff, abs_rel, sq_rel, sq_err, sq_log_err, a1, a2, a3), count
 __global__ void __launch_bounds__(kLossThreads) errors_stats_kernel(const float* __restrict__ gt, const float* __restrict__ pred, int H, int W,
                                                                     float max_depth, int y1, int y2, int x1, int x2,
-                                                                    float* __restrict__ scratch) {
+                                                                    const float* __restrict__ medians, float* __restrict__ scratch) {
   const int b = blockIdx.x;
   const long long pixels = (long long)H * W;
   const float* g = gt + b * pixels;
@@ -186,7 +401,8 @@ __global__ void __launch_bounds__(kLossThreads) errors_stats_kernel(const float*
     const int x = (int)(i % W), y = (int)(i / W);
     const float gv = g[i];
     if (gv > 0.f && gv < max_depth && y >= y1 && y < y2 && x >= x1 && x < x2) {
-      const float pv = clampf(p[i], 1e-3f, max_depth);
+      float pv = clampf(p[i], 1e-3f, max_depth);
+      if (medians != nullptr) pv = pv * medians[b * 2] / medians[b * 2 + 1];   // valid_pred * median(gt) / median(pred), :432-433
       const float d = gv - pv;
       const float thr = fmaxf(gv / pv, pv / gv);
       const float dl = logf(gv) - logf(pv);
@@ -206,6 +422,58 @@ __global__ void __launch_bounds__(kLossThreads) errors_stats_kernel(const float*
   if (threadIdx.x == 0)
 #pragma unroll
     for (int k = 0; k < 9; ++k) scratch[b * 9 + k] = acc[k];
+}
+
+// per-sample medians of the valid gt and of the valid clamped pred (torch.median: the LOWER middle for an even count):
+// exact 4-pass radix select on the float bit patterns (all values are positive, so the bits order like the values).
+// one block per sample; medians[b] = (median gt, median pred)
+__global__ void __launch_bounds__(kLossThreads) median_select_kernel(const float* __restrict__ gt, const float* __restrict__ pred, int H, int W,
+                                                                     float max_depth, int y1, int y2, int x1, int x2,
+                                                                     float* __restrict__ medians) {
+  const int b = blockIdx.x;
+  const long long pixels = (long long)H * W;
+  const float* g = gt + b * pixels;
+  const float* p = pred + b * pixels;
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_rank;
+  for (int which = 0; which < 2; ++which) {
+    unsigned prefix = 0, rank = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      for (int k = threadIdx.x; k < 256; k += kLossThreads) hist[k] = 0;
+      __syncthreads();
+      for (long long i = threadIdx.x; i < pixels; i += kLossThreads) {
+        const int x = (int)(i % W), y = (int)(i / W);
+        const float gv = g[i];
+        if (gv > 0.f && gv < max_depth && y >= y1 && y < y2 && x >= x1 && x < x2) {
+          const float v = which == 0 ? gv : clampf(p[i], 1e-3f, max_depth);
+          const unsigned bits = __float_as_uint(v);
+          if (pass == 0 || (bits >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned r = rank;
+        if (pass == 0) {
+          unsigned n = 0;
+          for (int k = 0; k < 256; ++k) n += hist[k];
+          r = n > 0 ? (n - 1) / 2 : 0;
+        }
+        unsigned k = 0;
+        for (; k < 255; ++k) {
+          if (r < hist[k]) break;
+          r -= hist[k];
+        }
+        s_prefix = prefix | (k << shift);
+        s_rank = r;
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      rank = s_rank;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) medians[b * 2 + which] = __uint_as_float(prefix);
+  }
 }
 
 __global__ void errors_finalize_kernel(const float* __restrict__ scratch, int B, float* __restrict__ out8) {
@@ -234,24 +502,77 @@ using namespace dn;
 
 extern "C" {
 
-int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t B, int64_t pixels, float max_depth, int32_t kind, float* sample_stats,
-                       float* loss, dn_stream_t stream) {
-  DN_REQUIRE(gt && pred && sample_stats && loss && B > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_fwd: bad argument");
-  DN_REQUIRE(kind == DN_LOSS_L1 || kind == DN_LOSS_L2, DN_ERR_BAD_ARG, "dn_masked_loss_fwd: bad kind %d", kind);
+size_t dn_masked_loss_workspace_bytes(int32_t G, int64_t pixels) {
+  if (G <= 0 || pixels <= 0) return 0;
+  return (size_t)G * loss_splits(pixels) * 4 * sizeof(float);
+}
+
+int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, float weight,
+                       int32_t accumulate, float* stats, void* workspace, size_t workspace_bytes, float* loss, dn_stream_t stream) {
+  DN_REQUIRE(gt && pred && stats && loss && workspace && G > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_fwd: bad argument");
+  DN_REQUIRE(kind >= DN_LOSS_L1 && kind <= DN_LOSS_SCALE_INV, DN_ERR_BAD_ARG, "dn_masked_loss_fwd: bad kind %d", kind);
+  DN_REQUIRE(workspace_bytes >= dn_masked_loss_workspace_bytes(G, pixels), DN_ERR_WORKSPACE, "dn_masked_loss_fwd: workspace too small");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(masked_loss_stats_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, (long long)pixels, max_depth, kind, sample_stats);
-  hipLaunchKernelGGL(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, s, sample_stats, B, loss);
+  const int nsp = loss_splits(pixels);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(masked_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, kind, partial);
+  hipLaunchKernelGGL(masked_reduceA_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+  if (kind == DN_LOSS_BERHU) {
+    hipLaunchKernelGGL(berhu_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, stats, partial);
+    hipLaunchKernelGGL(masked_reduceB_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+  }
+  hipLaunchKernelGGL(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, s, stats, G, kind, weight, accumulate, loss);
   return check_launch("masked_loss_fwd");
 }
 
-int dn_masked_loss_bwd(const float* gt, const float* pred, const float* sample_stats, const float* dloss, int32_t B, int64_t pixels,
-                       float max_depth, int32_t kind, float* dpred, dn_stream_t stream) {
-  DN_REQUIRE(gt && pred && sample_stats && dloss && dpred && B > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_bwd: bad argument");
-  long long total = (long long)B * pixels;
+int dn_masked_loss_bwd(const float* gt, const float* pred, const float* stats, const float* dloss, int32_t G, int64_t pixels,
+                       float max_depth, int32_t kind, float weight, float* dpred, dn_stream_t stream) {
+  DN_REQUIRE(gt && pred && stats && dloss && dpred && G > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_bwd: bad argument");
+  long long total = (long long)G * pixels;
   int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(masked_loss_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gt, pred, sample_stats, dloss, B,
-                     (long long)pixels, max_depth, kind, dpred);
+  hipLaunchKernelGGL(masked_loss_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gt, pred, stats, dloss, G,
+                     (long long)pixels, max_depth, kind, weight, dpred);
   return check_launch("masked_loss_bwd_kernel");
+}
+
+static inline int ew_blocks(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+int dn_pyramid_down2(const float* in, int32_t N, int32_t H, int32_t W, int32_t mode, float* out, dn_stream_t stream) {
+  DN_REQUIRE(in && out && N > 0 && H >= 2 && W >= 2 && mode >= 0 && mode <= 2, DN_ERR_BAD_ARG, "dn_pyramid_down2: bad argument");
+  hipLaunchKernelGGL(pyramid_down2_kernel, dim3(ew_blocks((long long)N * (H / 2) * (W / 2))), dim3(256), 0, as_stream(stream), in, N, H, W, mode, out);
+  return check_launch("pyramid_down2_kernel");
+}
+
+int dn_upsample_int_fwd(const float* low, int32_t N, int32_t h, int32_t w, int32_t scale, int32_t mode, float* out, dn_stream_t stream) {
+  DN_REQUIRE(low && out && N > 0 && h > 0 && w > 0 && scale >= 1 && (mode == 0 || mode == 1), DN_ERR_BAD_ARG, "dn_upsample_int_fwd: bad argument");
+  hipLaunchKernelGGL(upsample_int_fwd_kernel, dim3(ew_blocks((long long)N * h * w * scale * scale)), dim3(256), 0, as_stream(stream), low, N, h, w, scale, mode, out);
+  return check_launch("upsample_int_fwd_kernel");
+}
+
+int dn_upsample_int_bwd(const float* dout, int32_t N, int32_t h, int32_t w, int32_t scale, int32_t mode, float* dlow, dn_stream_t stream) {
+  DN_REQUIRE(dout && dlow && N > 0 && h > 0 && w > 0 && scale >= 1 && (mode == 0 || mode == 1), DN_ERR_BAD_ARG, "dn_upsample_int_bwd: bad argument");
+  hipLaunchKernelGGL(upsample_int_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dout, N, h, w, scale, mode, dlow);
+  return check_launch("upsample_int_bwd_kernel");
+}
+
+int32_t dn_reduce1d_blocks(int64_t n) { return ew_blocks(n) > 1024 ? 1024 : ew_blocks(n); }
+
+int dn_explainability_fwd(const float* mask, int64_t n, float weight, int32_t accumulate, float* partial, float* loss, dn_stream_t stream) {
+  DN_REQUIRE(mask && partial && loss && n > 0, DN_ERR_BAD_ARG, "dn_explainability_fwd: bad argument");
+  hipStream_t s = as_stream(stream);
+  const int blocks = dn_reduce1d_blocks(n);
+  hipLaunchKernelGGL(neglog_sum_kernel, dim3(blocks), dim3(256), 0, s, mask, (long long)n, partial);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, (double)n, weight, accumulate, loss);
+  return check_launch("explainability_fwd");
+}
+
+int dn_explainability_bwd(const float* mask, const float* dloss, int64_t n, float* dmask, dn_stream_t stream) {
+  DN_REQUIRE(mask && dloss && dmask && n > 0, DN_ERR_BAD_ARG, "dn_explainability_bwd: bad argument");
+  hipLaunchKernelGGL(neglog_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), mask, dloss, (long long)n, dmask);
+  return check_launch("neglog_bwd_kernel");
 }
 
 int32_t dn_smooth_blocks(int32_t B, int32_t H, int32_t W) { return smooth_blocks(B, H, W); }
@@ -272,10 +593,15 @@ int dn_smooth2_bwd(const float* map, const float* dloss, int32_t B, int32_t H, i
 }
 
 int dn_compute_errors(const float* gt, const float* pred, int32_t B, int32_t H, int32_t W, float max_depth, int32_t y1, int32_t y2,
-                      int32_t x1, int32_t x2, float* scratch, float* out8, dn_stream_t stream) {
+                      int32_t x1, int32_t x2, int32_t median_scaling, float* scratch, float* out8, dn_stream_t stream) {
   DN_REQUIRE(gt && pred && scratch && out8 && B > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_compute_errors: bad argument");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(errors_stats_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, H, W, max_depth, y1, y2, x1, x2, scratch);
+  float* medians = nullptr;
+  if (median_scaling) {
+    medians = scratch + (size_t)B * 9;
+    hipLaunchKernelGGL(median_select_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, H, W, max_depth, y1, y2, x1, x2, medians);
+  }
+  hipLaunchKernelGGL(errors_stats_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, H, W, max_depth, y1, y2, x1, x2, medians, scratch);
   hipLaunchKernelGGL(errors_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, B, out8);
   return check_launch("compute_errors");
 }

@@ -257,7 +257,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 1; }
+int dn_version(void) { return 2; }
 
 const char* dn_last_error(void) { return dn::g_err; }
 

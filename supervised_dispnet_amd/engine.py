@@ -495,3 +495,26 @@ def block_bilinear_up2(tape, d, out_hw):
 
     tape.push(backward)
     return up
+
+
+def block_channel_scale(tape, x, mask):
+    """out[n,h,w,c] = x[n,h,w,c] * mask[n,c]  -- nn.Dropout2d in training mode with a precomputed keep/scale mask
+    (models/Disp_vgg_BN_DORN.py:112,191).  The backward is the same kernel on the gradient."""
+    out_t = x.new_like()
+    _lib.call("dn_channel_scale", x.t.data_ptr(), mask.data_ptr(), x.N, x.H * x.W, x.C, out_t.data_ptr(), _stream())
+    out = Act(out_t, x.N, x.H, x.W, x.C)
+
+    def backward():
+        if out.grad is None:
+            return
+        if x.grad is None:
+            x.grad = x.new_like()
+            _lib.call("dn_channel_scale", out.grad.data_ptr(), mask.data_ptr(), x.N, x.H * x.W, x.C, x.grad.data_ptr(), _stream())
+        else:
+            tmp = x.new_like()
+            _lib.call("dn_channel_scale", out.grad.data_ptr(), mask.data_ptr(), x.N, x.H * x.W, x.C, tmp.data_ptr(), _stream())
+            x.grad.add_(tmp)
+        out.grad = None
+
+    tape.push(backward)
+    return out

@@ -1,8 +1,7 @@
 """Mirror of the reference's loss_functions.py on HIP kernels (same function names, argument order and meaning).
 
-Implemented on the MI355X path: l1_loss, l2_loss (incl. the reference's 'nyu' == L1 quirk), smooth_loss,
-smooth_DORN_loss, compute_errors.  The remaining reference losses raise NotImplementedError until their kernels land
-(no silent PyTorch fallback).
+Every function below launches kernels of libdispnet_hip.so through the C ABI; there is no PyTorch fallback (CPU tensors
+raise).  PyTorch only provides the tensors, the stream and the autograd hand-off.
 """
 import torch
 
@@ -14,39 +13,59 @@ _MAX_DEPTH = {"kitti": 80.0, "nyu": 10.0}
 
 def _max_depth(datasets):
     if datasets not in _MAX_DEPTH:
-        raise ValueError("undefined datasets %r" % (datasets,))
+        raise ValueError("undefined datasets %r" % (datasets,))   # the reference does `raise "undefined datasets"` (a TypeError)
     return _MAX_DEPTH[datasets]
 
 
+def _f32c(t, what):
+    require_cuda(t, what)
+    t = t.detach() if not t.requires_grad else t
+    return t.contiguous().float()
+
+
+# ------------------------------------------------------------------------------------------------ masked depth losses
 class _MaskedLoss(torch.autograd.Function):
-    """loss_functions.py:77-129: per-sample mean over valid pixels of f(gt - clamp(pred, 1e-3, max)), batch mean."""
+    """Sum of terms of the masked-loss family (C entry points dn_masked_loss_fwd/_bwd) as ONE autograd node.
+    Term i: `groups[i]` runs of equal length over (gts[i], preds[i]), each with its own mask mean; contributes
+    weights[i] * mean over its groups.  The kernels accumulate into one device scalar -- no host arithmetic."""
 
     @staticmethod
-    def forward(ctx, gt, pred, max_depth, kind):
-        require_cuda(pred, "predicted depth")
-        require_cuda(gt, "ground-truth depth")
-        B = pred.shape[0]
-        gtc, pc = gt.contiguous().float(), pred.contiguous()
-        pixels = pc.numel() // B
-        if gtc.numel() != pc.numel():
-            raise ValueError("gt %s and prediction %s sizes differ" % (tuple(gt.shape), tuple(pred.shape)))
-        stats = torch.empty((B, 2), dtype=torch.float32, device=pc.device)
-        loss = torch.empty((), dtype=torch.float32, device=pc.device)
-        _lib.call("dn_masked_loss_fwd", gtc.data_ptr(), pc.data_ptr(), B, pixels, max_depth, kind, stats.data_ptr(),
-                  loss.data_ptr(), _stream())
-        ctx.save_for_backward(gtc, pc, stats)
-        ctx.cfg = (B, pixels, max_depth, kind, pred.shape)
+    def forward(ctx, max_depth, kind, groups, weights, gts, *preds):
+        lib = _lib.load()
+        dev = preds[0].device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        saved, cfg = [], []
+        for i, (gt, pred) in enumerate(zip(gts, preds)):
+            require_cuda(pred, "predicted depth")
+            require_cuda(gt, "ground-truth depth")
+            gtc, pc = gt.contiguous().float(), pred.contiguous()
+            if gtc.numel() != pc.numel():
+                raise ValueError("gt %s and prediction %s sizes differ" % (tuple(gt.shape), tuple(pred.shape)))
+            g = groups[i]
+            pixels = pc.numel() // g
+            nbytes = lib.dn_masked_loss_workspace_bytes(g, pixels)
+            ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+            stats = torch.empty((g, _lib.LOSS_STATS), dtype=torch.float32, device=dev)
+            _lib.call("dn_masked_loss_fwd", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, weights[i], 0 if i == 0 else 1,
+                      stats.data_ptr(), ws.data_ptr(), nbytes, loss.data_ptr(), _stream())
+            saved += [gtc, pc, stats]
+            cfg.append((g, pixels, weights[i], pred.shape))
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (max_depth, kind, cfg)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        gtc, pc, stats = ctx.saved_tensors
-        B, pixels, max_depth, kind, shape = ctx.cfg
+        max_depth, kind, cfg = ctx.cfg
         dl = dloss.contiguous().float()
-        dpred = torch.empty(shape, dtype=torch.float32, device=pc.device)
-        _lib.call("dn_masked_loss_bwd", gtc.data_ptr(), pc.data_ptr(), stats.data_ptr(), dl.data_ptr(), B, pixels,
-                  max_depth, kind, dpred.data_ptr(), _stream())
-        return None, dpred, None, None
+        grads = []
+        for i, (g, pixels, weight, shape) in enumerate(cfg):
+            gtc, pc, stats = ctx.saved_tensors[3 * i:3 * i + 3]
+            dpred = torch.empty(shape, dtype=torch.float32, device=pc.device)
+            _lib.call("dn_masked_loss_bwd", gtc.data_ptr(), pc.data_ptr(), stats.data_ptr(), dl.data_ptr(), g, pixels, max_depth, kind,
+                      weight, dpred.data_ptr(), _stream())
+            grads.append(dpred)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def _scale0(depth):
@@ -57,17 +76,275 @@ def _scale0(depth):
     return d0
 
 
+def _per_sample(gt_depth, depth, datasets, kind):
+    d0 = _scale0(depth)
+    return _MaskedLoss.apply(_max_depth(datasets), kind, [d0.shape[0]], [1.0], [gt_depth], d0)
+
+
 def l1_loss(gt_depth, depth, datasets):
     """reference loss_functions.py:104-129 (uses scale 0 only: depth[0][:,0])."""
-    return _MaskedLoss.apply(gt_depth, _scale0(depth), _max_depth(datasets), _lib.LOSS_L1)
+    return _per_sample(gt_depth, depth, datasets, _lib.LOSS_L1)
 
 
 def l2_loss(gt_depth, depth, datasets):
     """reference loss_functions.py:77-102; its 'nyu' branch is an L1 (line 97) and is reproduced as such."""
-    kind = _lib.LOSS_L1 if datasets == "nyu" else _lib.LOSS_L2
-    return _MaskedLoss.apply(gt_depth, _scale0(depth), _max_depth(datasets), kind)
+    _max_depth(datasets)
+    return _per_sample(gt_depth, depth, datasets, _lib.LOSS_L1 if datasets == "nyu" else _lib.LOSS_L2)
 
 
+def berhu_loss(gt_depth, depth, datasets):
+    """reference loss_functions.py:131-161.  The reference's 'nyu' branch lost its for-loop (NameError at :149); here it
+    loops like the 'kitti' branch with max depth 10 (SURVEY.md Appendix C #9)."""
+    return _per_sample(gt_depth, depth, datasets, _lib.LOSS_BERHU)
+
+
+def Scale_invariant_loss(gt_depth, depth, datasets):
+    """reference loss_functions.py:163-189."""
+    return _per_sample(gt_depth, depth, datasets, _lib.LOSS_SCALE_INV)
+
+
+# ---------------------------------------------------------------------------------------------------------- pyramids
+_PYR_MODE = {"max": 0, "avg": 1, "bilinear": 2}
+
+
+@torch.no_grad()
+def _pyramid(image, mode):
+    require_cuda(image, "ground-truth depth")
+    cur = image.contiguous().float()
+    pyr = [cur]
+    for _ in range(3):
+        n, h, w = cur.shape
+        nxt = torch.empty((n, h // 2, w // 2), dtype=torch.float32, device=cur.device)
+        _lib.call("dn_pyramid_down2", cur.data_ptr(), n, h, w, mode, nxt.data_ptr(), _stream())
+        pyr.append(nxt)
+        cur = nxt
+    return pyr
+
+
+def generate_max_pyramid(image):
+    """reference loss_functions.py:191-196"""
+    return _pyramid(image, 0)
+
+
+def generate_avg_pyramid(image):
+    """reference loss_functions.py:198-203"""
+    return _pyramid(image, 1)
+
+
+def generate_bilinear_pyramid(image):
+    """reference loss_functions.py:205-215"""
+    return _pyramid(image, 2)
+
+
+def _multiscale(gt_list, preds, kind):
+    """One mask over the WHOLE batch per scale, weight 1/2^i, max depth hard-coded 80 (reference :229-238)."""
+    n = min(len(gt_list), len(preds))
+    return _MaskedLoss.apply(80.0, kind, [1] * n, [1.0 / (2 ** i) for i in range(n)], list(gt_list[:n]), *preds[:n])
+
+
+def Multiscale_L1_loss(gt_depth, depth, pool_type="bilinear"):
+    """reference loss_functions.py:217-238"""
+    if pool_type not in _PYR_MODE:
+        raise ValueError("undefined pool type")
+    return _multiscale(_pyramid(gt_depth, _PYR_MODE[pool_type]), depth, _lib.LOSS_L1)
+
+
+class _UpsampleInt(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, mode):
+        require_cuda(x, "prediction")
+        xc = x.contiguous()
+        b, c, h, w = xc.shape
+        out = torch.empty((b, c, h * scale, w * scale), dtype=torch.float32, device=xc.device)
+        _lib.call("dn_upsample_int_fwd", xc.data_ptr(), b * c, h, w, scale, mode, out.data_ptr(), _stream())
+        ctx.cfg = (b * c, h, w, scale, mode, xc.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, h, w, scale, mode, shape = ctx.cfg
+        d = dout.contiguous()
+        dx = torch.empty(shape, dtype=torch.float32, device=d.device)
+        _lib.call("dn_upsample_int_bwd", d.data_ptr(), n, h, w, scale, mode, dx.data_ptr(), _stream())
+        return dx, None, None
+
+
+def Multiscale_FULL_L1_loss(gt_depth, depth, pool_type="bilinear"):
+    """reference loss_functions.py:240-257: predictions upsampled to full resolution with F.upsample(mode=pool_type)."""
+    modes = {"nearest": 0, "bilinear": 1}
+    if pool_type not in modes:
+        raise NotImplementedError("F.upsample mode %r" % (pool_type,))
+    ups = [_UpsampleInt.apply(d, 2 ** i, modes[pool_type]) for i, d in enumerate(depth)]
+    return _multiscale([gt_depth] * len(depth), ups, _lib.LOSS_L1)
+
+
+def Multiscale_L2_loss(gt_depth, depth):
+    """reference loss_functions.py:259-273"""
+    return _multiscale(_pyramid(gt_depth, 2), depth, _lib.LOSS_L2)
+
+
+def Multiscale_berhu_loss(gt_depth, depth):
+    """reference loss_functions.py:275-296"""
+    return _multiscale(_pyramid(gt_depth, 2), depth, _lib.LOSS_BERHU)
+
+
+def Multiscale_scale_inv_loss(gt_depth, depth):
+    """reference loss_functions.py:298-315"""
+    return _multiscale(_pyramid(gt_depth, 2), depth, _lib.LOSS_SCALE_INV)
+
+
+# -------------------------------------------------------------------------------------------------------- photometric
+_ROT = {"euler": 0, "quat": 1}
+_PAD = {"zeros": 0, "border": 1}
+
+
+class _Photometric(torch.autograd.Function):
+    """photometric_reconstruction_loss (reference loss_functions.py:317-354) as ONE autograd node over all scales and
+    reference images: per (scale, ref) one fused warp+|diff| launch forward and one fused backward launch."""
+
+    @staticmethod
+    def forward(ctx, tgt_img, intrinsics, intrinsics_inv, pose, rot, pad, align, n_ref, n_scale, has_mask, *rest):
+        refs = rest[:n_ref]
+        depths = rest[n_ref:n_ref + n_scale]
+        masks = rest[n_ref + n_scale:] if has_mask else [None] * n_scale
+        dev = tgt_img.device
+        for t in (tgt_img, intrinsics, intrinsics_inv, pose) + tuple(refs) + tuple(depths):
+            require_cuda(t, "photometric loss input")
+        tgt = tgt_img.contiguous().float()
+        refs = [r.contiguous().float() for r in refs]
+        K, Kinv = intrinsics.contiguous().float(), intrinsics_inv.contiguous().float()
+        posec = pose.contiguous().float()
+        B, _, H, W = tgt.shape
+        if posec.shape[1] != n_ref:
+            raise AssertionError("pose.size(1) != len(ref_imgs)")
+        lib = _lib.load()
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        saved = []
+        first = True
+        for d, m in zip(depths, masks):
+            dc = d.contiguous().float()
+            b, _, h, w = dc.shape
+            if m is not None and tuple(m.shape[2:]) != (h, w):
+                raise AssertionError("explainability mask and depth sizes differ")
+            f = H // h
+            down = float(H) / h
+            if f == 1:
+                tgt_s, refs_s = tgt, refs
+            else:
+                tgt_s = torch.empty((B, 3, h, w), dtype=torch.float32, device=dev)
+                _lib.call("dn_area_down", tgt.data_ptr(), B * 3, H, W, f, tgt_s.data_ptr(), _stream())
+                refs_s = []
+                for r in refs:
+                    rs = torch.empty((B, 3, h, w), dtype=torch.float32, device=dev)
+                    _lib.call("dn_area_down", r.data_ptr(), B * 3, H, W, f, rs.data_ptr(), _stream())
+                    refs_s.append(rs)
+            mc = m.contiguous().float() if m is not None else None
+            nb = lib.dn_warp_blocks(h, w)
+            per_ref = []
+            for i, rs in enumerate(refs_s):
+                proj = torch.empty((B, 12), dtype=torch.float32, device=dev)
+                kinv_s = torch.empty((B, 9), dtype=torch.float32, device=dev)
+                _lib.call("dn_pose_proj_fwd", posec.data_ptr() + 4 * 6 * i, 6 * n_ref, K.data_ptr(), Kinv.data_ptr(), B, rot, down,
+                          proj.data_ptr(), kinv_s.data_ptr(), _stream())
+                partial = torch.empty(B * nb, dtype=torch.float32, device=dev)
+                mptr = (mc.data_ptr() + 4 * i * h * w) if mc is not None else None
+                msb = mc.shape[1] * h * w if mc is not None else 0
+                _lib.call("dn_photometric_fwd", tgt_s.data_ptr(), rs.data_ptr(), dc.data_ptr(), proj.data_ptr(), kinv_s.data_ptr(),
+                          mptr, msb, B, h, w, pad, align, 1.0, 0 if first else 1, partial.data_ptr(), loss.data_ptr(), _stream())
+                first = False
+                per_ref.append((rs, proj, kinv_s))
+            saved.append((dc, mc, tgt_s, per_ref, down, h, w))
+        ctx.saved = saved
+        ctx.cfg = (B, rot, pad, align, n_ref, n_scale, has_mask, K, posec, [d.shape for d in depths],
+                   [m.shape if m is not None else None for m in masks])
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        B, rot, pad, align, n_ref, n_scale, has_mask, K, posec, dshapes, mshapes = ctx.cfg
+        dev = posec.device
+        dl = dloss.contiguous().float()
+        lib = _lib.load()
+        dpose = torch.zeros_like(posec)
+        ddepths, dmasks = [], []
+        first_pose = [True] * n_ref
+        for (dc, mc, tgt_s, per_ref, down, h, w), dshape, mshape in zip(ctx.saved, dshapes, mshapes):
+            nb = lib.dn_warp_blocks(h, w)
+            dd = torch.empty(dshape, dtype=torch.float32, device=dev)
+            dm = torch.zeros(mshape, dtype=torch.float32, device=dev) if mshape is not None else None
+            for i, (rs, proj, kinv_s) in enumerate(per_ref):
+                dpp = torch.empty((B, nb, 12), dtype=torch.float32, device=dev)
+                mptr = (mc.data_ptr() + 4 * i * h * w) if mc is not None else None
+                msb = mc.shape[1] * h * w if mc is not None else 0
+                dmptr = (dm.data_ptr() + 4 * i * h * w) if dm is not None else None
+                _lib.call("dn_photometric_bwd", tgt_s.data_ptr(), rs.data_ptr(), dc.data_ptr(), proj.data_ptr(), kinv_s.data_ptr(),
+                          mptr, msb, B, h, w, pad, align, 1.0, dl.data_ptr(), dd.data_ptr(), 0 if i == 0 else 1, dpp.data_ptr(),
+                          dmptr, msb, _stream())
+                _lib.call("dn_pose_proj_bwd", posec.data_ptr() + 4 * 6 * i, 6 * n_ref, K.data_ptr(), B, rot, down, dpp.data_ptr(), nb,
+                          dpose.data_ptr() + 4 * 6 * i, 6 * n_ref, 0 if first_pose[i] else 1, _stream())
+                first_pose[i] = False
+            ddepths.append(dd)
+            dmasks.append(dm)
+        ctx.saved = None
+        grads = [None, None, None, dpose, None, None, None, None, None, None] + [None] * n_ref + ddepths
+        if has_mask:
+            grads += dmasks
+        return tuple(grads)
+
+
+def photometric_reconstruction_loss(tgt_img, ref_imgs, intrinsics, intrinsics_inv, depth, explainability_mask, pose,
+                                    rotation_mode='euler', padding_mode='zeros', align_corners=False):
+    """reference loss_functions.py:317-354.  `align_corners` is F.grid_sample's flag: the reference passes none, which means
+    False on torch >= 1.3 (what its code yields today) and meant True on its pinned torch 1.0.1 (SURVEY.md 8a-12)."""
+    if type(explainability_mask) not in [tuple, list]:
+        explainability_mask = [explainability_mask]
+    if type(depth) not in [list, tuple]:
+        depth = [depth]
+    n = min(len(depth), len(explainability_mask))          # zip() semantics of the reference
+    depth, masks = list(depth[:n]), list(explainability_mask[:n])
+    has_mask = all(m is not None for m in masks)
+    if not has_mask and any(m is not None for m in masks):
+        raise ValueError("explainability masks must be given for every scale or for none")
+    args = list(ref_imgs) + depth + (masks if has_mask else [])
+    return _Photometric.apply(tgt_img, intrinsics, intrinsics_inv, pose, _ROT[rotation_mode], _PAD[padding_mode],
+                              1 if align_corners else 0, len(ref_imgs), n, has_mask, *args)
+
+
+class _Explainability(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *masks):
+        dev = masks[0].device
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        saved = []
+        lib = _lib.load()
+        for i, m in enumerate(masks):
+            require_cuda(m, "explainability mask")
+            mc = m.contiguous().float()
+            partial = torch.empty(lib.dn_reduce1d_blocks(mc.numel()), dtype=torch.float32, device=dev)
+            _lib.call("dn_explainability_fwd", mc.data_ptr(), mc.numel(), 1.0, 0 if i == 0 else 1, partial.data_ptr(), loss.data_ptr(), _stream())
+            saved.append(mc)
+        ctx.save_for_backward(*saved)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dl = dloss.contiguous().float()
+        out = []
+        for mc in ctx.saved_tensors:
+            g = torch.empty_like(mc)
+            _lib.call("dn_explainability_bwd", mc.data_ptr(), dl.data_ptr(), mc.numel(), g.data_ptr(), _stream())
+            out.append(g)
+        return tuple(out)
+
+
+def explainability_loss(mask):
+    """reference loss_functions.py:357-364: sum over scales of binary_cross_entropy(mask, ones)."""
+    if type(mask) not in [tuple, list]:
+        mask = [mask]
+    return _Explainability.apply(*mask)
+
+
+# --------------------------------------------------------------------------------------------------------- smoothness
 class _Smooth(torch.autograd.Function):
     """loss_functions.py:367-386 for a list of [B,C,H,W] maps (each channel treated as its own map)."""
 
@@ -114,35 +391,63 @@ def smooth_DORN_loss(pred_map):
     return _Smooth.apply(2.3, pred_map)
 
 
+# --------------------------------------------------------------------------------------------------------------- DORN
+class _OrdinalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt_depth, ord_labels, target, max_depth):
+        require_cuda(ord_labels, "ordinal probabilities")
+        require_cuda(gt_depth, "ground-truth depth")
+        require_cuda(target, "SID target labels")
+        oc = ord_labels.contiguous().float()
+        n, k, h, w = oc.shape
+        gtc = gt_depth.contiguous().float()
+        tc = target.contiguous().to(torch.int32)
+        if gtc.numel() != n * h * w or tc.numel() != n * h * w:
+            raise ValueError("gt_depth / target must be [N,H,W] matching ord_labels [N,K,H,W]")
+        dev = oc.device
+        nb = _lib.load().dn_ordinal_loss_blocks(n, h * w)
+        partial = torch.empty((nb, 2), dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.call("dn_ordinal_loss_fwd", oc.data_ptr(), gtc.data_ptr(), tc.data_ptr(), n, h * w, k, max_depth, partial.data_ptr(),
+                  stats.data_ptr(), loss.data_ptr(), _stream())
+        ctx.save_for_backward(oc, gtc, tc, stats)
+        ctx.cfg = (n, k, h, w, max_depth)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        oc, gtc, tc, stats = ctx.saved_tensors
+        n, k, h, w, max_depth = ctx.cfg
+        dl = dloss.contiguous().float()
+        dord = torch.empty_like(oc)
+        _lib.call("dn_ordinal_loss_bwd", oc.data_ptr(), gtc.data_ptr(), tc.data_ptr(), stats.data_ptr(), dl.data_ptr(), n, h * w, k,
+                  max_depth, dord.data_ptr(), _stream())
+        return None, dord, None, None
+
+
+def DORN_loss(gt_depth, ord_labels, target, datasets):
+    """reference loss_functions.py:16-74."""
+    return _OrdinalLoss.apply(gt_depth, ord_labels, target, _max_depth(datasets))
+
+
+# ------------------------------------------------------------------------------------------------------------ metrics
 @torch.no_grad()
 def compute_errors(gt, pred, dataset='kitti', crop=True, unsupervised=False):
     """reference loss_functions.py:401-448 -> [abs_diff, abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3] (python floats)."""
-    if unsupervised:
-        raise NotImplementedError("median-scaled metrics (unsupervised=True) are not on the HIP path yet")
     require_cuda(pred, "predicted depth")
+    require_cuda(gt, "ground-truth depth")
     b, h, w = gt.shape
     if dataset == 'kitti':
+        # (the reference leaves max_depth undefined for crop=False, loss_functions.py:411-417; 80 is what it means)
         mx = 80.0
         y1, y2, x1, x2 = (int(0.40810811 * h), int(0.99189189 * h), int(0.03594771 * w), int(0.96405229 * w)) if crop else (0, h, 0, w)
     else:
         mx = 10.0
         y1, y2, x1, x2 = 0, h, 0, w
     gtc, pc = gt.contiguous().float(), pred.contiguous().float()
-    scratch = torch.empty((b, 9), dtype=torch.float32, device=pc.device)
+    scratch = torch.empty((b, 11), dtype=torch.float32, device=pc.device)
     out = torch.empty(8, dtype=torch.float32, device=pc.device)
-    _lib.call("dn_compute_errors", gtc.data_ptr(), pc.data_ptr(), b, h, w, mx, y1, y2, x1, x2, scratch.data_ptr(),
-              out.data_ptr(), _stream())
+    _lib.call("dn_compute_errors", gtc.data_ptr(), pc.data_ptr(), b, h, w, mx, y1, y2, x1, x2, 1 if unsupervised else 0,
+              scratch.data_ptr(), out.data_ptr(), _stream())
     return out.tolist()
-
-
-def _pending(name):
-    def fn(*a, **k):
-        raise NotImplementedError("loss_functions.%s has no HIP kernel yet in this build (no PyTorch fallback by design)" % name)
-    fn.__name__ = name
-    return fn
-
-
-for _n in ("berhu_loss", "Scale_invariant_loss", "Multiscale_L1_loss", "Multiscale_FULL_L1_loss", "Multiscale_L2_loss",
-           "Multiscale_berhu_loss", "Multiscale_scale_inv_loss", "photometric_reconstruction_loss", "explainability_loss",
-           "DORN_loss"):
-    globals()[_n] = _pending(_n)

@@ -5,6 +5,7 @@ clear error rather than silently running something else.
 """
 from .DispNetS import DispNetS
 from .Disp_vgg_BN import Disp_vgg_BN
+from .Disp_vgg_BN_DORN import Disp_vgg_BN_DORN
 
 
 def _out_of_scope(name):

@@ -232,3 +232,49 @@ def test_train_step_golden(golden):
             continue
         s = detgen.summarize(sd[key].cpu(), stride=31)
         np.testing.assert_allclose(s["samples"], g["post:%s:samples" % key], rtol=2e-3, atol=2.5e-4)   # Adam: |update| <= lr per step
+
+
+def test_disp_vgg_bn_dorn_config5(golden):
+    """BASELINE config 5: Disp_vgg_BN_DORN head + DORN loss; eval forward vs the reference's golden, training step (injected
+    Dropout2d mask -- RNG streams cannot be matched) vs the oracle."""
+    import supervised_dispnet_amd.utils as U
+    from oracle import image_ops as OI
+    g = golden("dorn")
+    net = models.Disp_vgg_BN_DORN(datasets="kitti", ordinal_c=8, with_classifier=False)
+    detgen.fill_state_dict(net.state_dict(), "vggdorn")
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).eval()
+    x = detgen.image_batch(1, 64, 96, "vggdorn:x")
+    with torch.no_grad():
+        dec, ordc = net(x.to(DEV))
+    assert dec.dtype == torch.int64 and tuple(dec.shape) == (1, 1, 64, 96) and tuple(ordc.shape) == (1, 8, 64, 96)
+    close("net:ord(golden)", ordc, g["net:ord"], rtol=1e-3, atol_rel=1e-4)
+    assert (dec.cpu().numpy() != g["net:decode"]).mean() < 2e-3      # only P within rounding of 0.5 may flip
+    # ---- training step with a fixed dropout pattern
+    net.train()
+    b, h, w = 2, 64, 96
+    x = detgen.image_batch(b, h, w, "dorn:x")
+    gt = detgen.sparse_depth(b, h, w, "dorn:gt", density=0.3)
+    mask = (detgen.bernoulli((b, 16), "dorn:drop", 0.5).float() * 2.0)
+    net._dropout_mask = mask.to(DEV)
+    tgt = U.get_labels_sid(gt.to(DEV), ordinal_c=8, dataset="kitti")
+    dec, ordc = net(x.to(DEV))
+    loss = LF.DORN_loss(gt.to(DEV), ordc, tgt, "kitti") + 0.1 * LF.smooth_DORN_loss(ordc)
+    loss.backward()
+    osd = _oracle_params(sd0)
+    odec, oord = ON.disp_vgg_bn_dorn(osd, x, training=True, dropout_mask=mask.view(b, 16, 1, 1))
+    otgt = OI.get_labels_sid(gt, ordinal_c=8, dataset="kitti")
+    np.testing.assert_array_equal(tgt.cpu().numpy(), otgt.numpy())
+    oloss = OL.DORN_loss(gt, oord, otgt, "kitti") + 0.1 * OL.smooth_DORN_loss(oord)
+    oloss.backward()
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=2e-4)
+    close("ord", ordc, oord, rtol=1e-3, atol_rel=1e-4)
+    assert (dec.cpu() != odec).float().mean() < 2e-3
+    for name, p in net.named_parameters():
+        if _is_pre_bn_conv_bias(name):
+            continue
+        og = osd[name].grad
+        if og is None:                      # disp1..3 heads feed the trunk, everything has a gradient; classifier is absent
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        grad_close("grad:" + name, p.grad, og)
