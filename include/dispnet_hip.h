@@ -104,8 +104,11 @@ typedef struct dn_conv_desc {
   const float* bias;               /* optional [sum of out C] */
   int32_t act;                     /* dn_activation applied after bias */
   float act_p0, act_p1;
-  float* bn_partial;               /* optional: [dn_conv_bn_partial_rows()][Cout][2] (sum, sum of squares) of the
-                                      PRE-BIAS result per row tile; requires n_out == 1 */
+  float* bn_partial;               /* optional: [dn_conv_bn_partial_rows()][Cout][2] = (sum, sum of squared deviations from the
+                                      tile mean) of the PRE-BIAS result per 128-row tile; requires n_out == 1 */
+  int32_t pad_mode;                /* 0: zero padding; 1: reflection padding (nn.ReflectionPad2d(pad) in front of the conv,
+                                      layers.py:124-136).  Reflection is honoured by DN_CONV_FWD and by the weight gradient;
+                                      its input gradient = DN_CONV_DGRAD with pad 0 on the padded extent + dn_reflect_fold. */
 } dn_conv_desc;
 
 /* Elements of the packed weight buffer for desc->kind (depends on R,S,stride,pad, operand/result channels). */
@@ -133,7 +136,8 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
  * BatchNorm (training statistics), ReLU, MaxPool 2x2, activations  --  all NHWC, HBM-bound.
  * Reference: torchvision vgg16_bn features used by models/Disp_vgg_BN.py:137-141.
  * ------------------------------------------------------------------------------------------------------------ */
-/* partial (sum,sumsq) [rows][C][2] of the pre-bias conv result -> batch mean / biased var, folded affine
+/* partial (sum, M2 about the tile mean) [rows][C][2] of the pre-bias conv result (128-row tiles, merged with the
+ * parallel-variance update in fp64) -> batch mean / biased var, folded affine
  * (scale = gamma*invstd, shift = beta - mean*scale), running-stat update (momentum, unbiased var), save mean/invstd.
  * count = N*H*W.  training != 0.  */
 int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count, const float* conv_bias,
@@ -154,10 +158,12 @@ int dn_bn_relu_pool_bwd(const float* dpooled, const uint8_t* idx, const float* y
 /* dz = da * (y*scale+shift > 0) in place on `da`, plus the same partial sums. */
 int dn_bn_relu_bwd_reduce(float* da_dz, const float* y, const float* scale, const float* shift, const float* mean,
                           const float* invstd, int64_t rows, int32_t C, float* partial, dn_stream_t stream);
-/* finalize partial sums -> dgamma, dbeta; then dy = gamma*invstd*(dz - dbeta/count - xhat*dgamma/count) in place. */
+/* finalize partial sums -> dgamma, dbeta; then dy = gamma*invstd*(dz - dbeta/count - xhat*dgamma/count) in place.
+ * partial: [partial_rows][C][partial_stride] with (sum dz, sum dz*xhat) at offsets partial_offset, partial_offset+1
+ * (stride 2 / offset 0 for the reduce kernels above; stride 4 / offset 0 or 2 for dn_bn_add_relu_bwd). */
 int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float* invstd, const float* gamma,
-                    const float* partial, int32_t partial_rows, int64_t rows, int32_t C, float* dgamma, float* dbeta,
-                    dn_stream_t stream);
+                    const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset, int64_t rows,
+                    int32_t C, float* dgamma, float* dbeta, dn_stream_t stream);
 int32_t dn_reduce_blocks(int64_t rows, int32_t C);   /* rows of `partial` the reduce kernels above write */
 
 /* g_pre = g * act'(.) in place, using the stored POST-activation tensor y_post; also per-channel partial sums
@@ -170,11 +176,38 @@ int dn_colsum_finalize(const float* partial, int32_t rows, int32_t C, int32_t st
 /* dlow[n,h,w] (+)= sum of the 2x2 block of dfull[n,2h..,2w..]   (backward of nearest x2 upsample, C == 1) */
 int dn_upsample2x_nearest_bwd(const float* dfull, int32_t N, int32_t h, int32_t w, float* dlow, int32_t accumulate,
                               dn_stream_t stream);
+/* the same for an NHWC tensor with C channels (layers.upsample, layers.py:193-196; C % 4 == 0 or C == 1) */
+int dn_upsample2x_nearest_bwd_nhwc(const float* dfull, int32_t N, int32_t h, int32_t w, int32_t C, float* dlow, int32_t accumulate,
+                                   dn_stream_t stream);
+/* backward of ReflectionPad2d(pad): dxp is the gradient on the padded extent [N][H+2p][W+2p][C]; dx[N][H][W][C] (+)= the
+ * sum over the padded positions that mirror onto each pixel. */
+int dn_reflect_fold(const float* dxp, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, float* dx, int32_t accumulate,
+                    dn_stream_t stream);
+/* out = relu( (y*scale + shift) + (r_scale ? r*r_scale + r_shift : r) )  -- the tail of a ResNet bottleneck:
+ * bn3(conv3) + identity / downsample-BN, then ReLU (models/Disp_res_50.py:229-247).  NHWC, C % 4 == 0.
+ * r == NULL: no residual, i.e. a materialised relu(bn(y)) (a BatchNorm+ReLU output that leaves the engine as a tensor). */
+int dn_bn_add_relu_fwd(const float* y, const float* scale, const float* shift, const float* r, const float* r_scale, const float* r_shift,
+                       int64_t rows, int32_t C, float* out, dn_stream_t stream);
+/* m = gout * (out > 0).  dz_y = m; partial [dn_reduce_blocks(rows,C)][C][4] = sums of (m, m*xhat_y, m, m*xhat_r).
+ * Residual branch: with r_mean/r_invstd (a downsample BatchNorm) dr = m (overwrite); without, dr (+)= m (dr may be NULL). */
+int dn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const float* mean, const float* invstd, const float* r,
+                       const float* r_mean, const float* r_invstd, int64_t rows, int32_t C, float* dz_y, float* dr, int32_t dr_accumulate,
+                       float* partial, dn_stream_t stream);
+/* MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (models/Disp_res_50.py:73); idx (uint8 per output element) = window
+ * position 0..8 of the first maximum in row-major order.  Backward gathers (deterministic), dx overwrite / accumulate. */
+int dn_maxpool3s2_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* out, uint8_t* idx, dn_stream_t stream);
+int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, int32_t accumulate,
+                      dn_stream_t stream);
+/* out = (x - sub) / div  element-wise (the input normalisation of networks/vgg_encoder.py:80, resnet_encoder.py:89) */
+int dn_sub_div(const float* x, int64_t n, float sub, float div, float* out, dn_stream_t stream);
 /* bilinear x2, align_corners = False, 1 channel (models/DispNetS.py:120,126,132), cropped to (OH,OW). */
 int dn_upsample2x_bilinear_fwd(const float* low, int32_t N, int32_t h, int32_t w, int32_t OH, int32_t OW, float* out,
                                dn_stream_t stream);
 int dn_upsample2x_bilinear_bwd(const float* dout, int32_t N, int32_t h, int32_t w, int32_t OH, int32_t OW, float* dlow,
                                int32_t accumulate, dn_stream_t stream);
+/* out[n][c] = scale * mean over pixels of x[n][p][c] (NHWC): pose = 0.01 * pose_pred(...).mean(3).mean(2), models/PoseExpNet.py:73-75 */
+int dn_spatial_mean_fwd(const float* x, int32_t N, int64_t HW, int32_t C, float scale, float* out, dn_stream_t stream);
+int dn_spatial_mean_bwd(const float* dout, int32_t N, int64_t HW, int32_t C, float scale, float* dx, dn_stream_t stream);
 /* y = 1/x (train.py:445); dx = -dy * y*y */
 int dn_reciprocal_fwd(const float* x, float* y, int64_t n, dn_stream_t stream);
 int dn_reciprocal_bwd(const float* dy, const float* y, float* dx, int64_t n, dn_stream_t stream);

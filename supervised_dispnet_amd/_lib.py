@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
                 ("n_in", C.c_int32), ("in_", Operand * DN_MAX_OPERANDS),
                 ("n_out", C.c_int32), ("out", Result * DN_MAX_OPERANDS),
                 ("w_packed", _f32p), ("bias", _f32p), ("act", C.c_int32), ("act_p0", C.c_float), ("act_p1", C.c_float),
-                ("bn_partial", _f32p)]
+                ("bn_partial", _f32p), ("pad_mode", C.c_int32)]
 
 
 _P = C.POINTER
@@ -61,11 +61,20 @@ SIGNATURES = {
     "dn_bn_relu_pool_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_bn_relu_pool_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_bn_relu_bwd_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
-    "dn_bn_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "dn_bn_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp]),
     "dn_reduce_blocks": (_i32, [_i64, _i32]),
     "dn_act_bwd_reduce": (C.c_int, [_vp, _vp, _i32, _f, _f, _i64, _i32, _vp, _vp]),
     "dn_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dn_upsample2x_nearest_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_upsample2x_nearest_bwd_nhwc": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_reflect_fold": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_bn_add_relu_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "dn_bn_add_relu_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "dn_maxpool3s2_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_maxpool3s2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_sub_div": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
+    "dn_spatial_mean_fwd": (C.c_int, [_vp, _i32, _i64, _i32, _f, _vp, _vp]),
+    "dn_spatial_mean_bwd": (C.c_int, [_vp, _i32, _i64, _i32, _f, _vp, _vp]),
     "dn_upsample2x_bilinear_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dn_upsample2x_bilinear_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "dn_reciprocal_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -85,6 +85,7 @@ struct IgemmParams {
   int uni32;                     // additionally: every operand has C % 32 == 0, no upsample, < 2 GiB span, <= 32 taps
                                  //   -> block-uniform tap/channel per K chunk, buffer loads with hardware range check
   int any_affine;                // some operand carries a pending BN-apply + ReLU
+  int reflect;                   // gather with ReflectionPad2d index mapping instead of zero fill
 };
 
 // floor(n / d) for 0 <= n < 2^31 with a precomputed magic (see fastdiv_magic); branch-free

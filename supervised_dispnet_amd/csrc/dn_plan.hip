@@ -83,6 +83,13 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   p->w = d->w_packed;
   p->bn_partial = d->bn_partial;
   const int st = d->stride, pad = d->pad;
+  DN_REQUIRE(d->pad_mode == 0 || d->pad_mode == 1, DN_ERR_BAD_ARG, "bad pad_mode %d", d->pad_mode);
+  if (d->pad_mode == 1) {
+    DN_REQUIRE(for_wgrad ? d->kind == DN_CONV_FWD : d->kind == DN_CONV_FWD, DN_ERR_UNSUPPORTED,
+               "reflection padding is supported by the conv forward and its weight gradient only");
+    DN_REQUIRE(pad < d->IH && pad < d->IW, DN_ERR_BAD_ARG, "reflection pad %d needs a larger input than %dx%d", pad, d->IH, d->IW);
+    p->reflect = 1;
+  }
 
   if (for_wgrad) {
     DN_REQUIRE(d->kind == DN_CONV_FWD || d->kind == DN_CONVT_FWD, DN_ERR_BAD_ARG, "wgrad needs a forward descriptor");

@@ -110,32 +110,44 @@ __device__ __forceinline__ void stv(float* p, const Vec<V>& r) {
 }
 
 // -------------------------------------------------------------------------------------------------- BN statistics
-// one block per channel: fp64 accumulation of the per-tile fp32 partial sums
+// one block per channel.  partial[t][c] = (sum, M2 about the tile mean) of row tile t (kBnTileRows rows, the last one ragged);
+// merged in fp64: mean = sum_t s_t / N,  M2 = sum_t [ M2_t + n_t (s_t/n_t - mean)^2 ]   (Chan et al.)
+constexpr int kBnTileRows = 128;   // = BM of every igemm_conv_kernel instantiation
 __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
                                                                const float* __restrict__ conv_bias, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* running_mean, float* running_var,
                                                                float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
                                                                float* shift) {
   const int c = blockIdx.x;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = threadIdx.x; r < rows; r += kThreads) {
-    s1 += (double)partial[((long long)r * C + c) * 2 + 0];
-    s2 += (double)partial[((long long)r * C + c) * 2 + 1];
-  }
-  __shared__ double red[2][kThreads];
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
+  __shared__ double red[kThreads];
+  __shared__ double s_mean;
+  double s1 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += kThreads) s1 += (double)partial[((long long)r * C + c) * 2 + 0];
+  red[threadIdx.x] = s1;
   __syncthreads();
   for (int o = kThreads / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + o];
-      red[1][threadIdx.x] += red[1][threadIdx.x + o];
-    }
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_mean = red[0] / count;
+  __syncthreads();
+  const double macc = s_mean;
+  double m2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += kThreads) {
+    const double left = count - (double)r * kBnTileRows;
+    const double nt = left < (double)kBnTileRows ? left : (double)kBnTileRows;
+    const double d = (double)partial[((long long)r * C + c) * 2 + 0] / nt - macc;
+    m2 += (double)partial[((long long)r * C + c) * 2 + 1] + nt * d * d;
+  }
+  __syncthreads();
+  red[threadIdx.x] = m2;
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double macc = red[0][0] / count;
-    double var = red[1][0] / count - macc * macc;   // biased; bias shift does not change it
+    double var = red[0] / count;   // biased; the conv bias shifts the mean only
     if (var < 0.0) var = 0.0;
     const float mean = (float)(macc + (conv_bias ? (double)conv_bias[c] : 0.0));
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -339,6 +351,234 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------ ResNet bottleneck tail
+__global__ void __launch_bounds__(kThreads) bn_add_relu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ r,
+                                                                   const float* __restrict__ r_scale, const float* __restrict__ r_shift,
+                                                                   long long rows, int C, float* __restrict__ out) {
+  const int G = C / 4;
+  const long long total = rows * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int c = (int)(i % G) * 4;
+    const long long o = i * 4;
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+    const f32x4 rv = r != nullptr ? *reinterpret_cast<const f32x4*>(r + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    f32x4 res;
+    if (r_scale != nullptr) {
+      const f32x4 rs = *reinterpret_cast<const f32x4*>(r_scale + c), rb = *reinterpret_cast<const f32x4*>(r_shift + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) res[e] = fmaxf(0.f, (yv[e] * sc[e] + sh[e]) + (rv[e] * rs[e] + rb[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) res[e] = fmaxf(0.f, (yv[e] * sc[e] + sh[e]) + rv[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + o) = res;
+  }
+}
+
+struct AddReluBwdOp {
+  static constexpr int NACC = 4;
+  const float* gout;
+  const float* out;
+  const float* y;
+  const float* mean;
+  const float* invstd;
+  const float* r;
+  const float* r_mean;     // nullable: plain identity
+  const float* r_invstd;
+  float* dz_y;
+  float* dr;
+  int dr_accumulate;
+  int C;
+  template <int V>
+  __device__ __forceinline__ void apply(long long row, int c0, float (&acc)[V][4]) const {
+    const long long o = row * C + c0;
+    const Vec<V> g = ldv<V>(gout + o), ov = ldv<V>(out + o), yv = ldv<V>(y + o), mu = ldv<V>(mean + c0), is = ldv<V>(invstd + c0);
+    Vec<V> m;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      m.v[e] = ov.v[e] > 0.f ? g.v[e] : 0.f;
+      acc[e][0] += m.v[e];
+      acc[e][1] += m.v[e] * (yv.v[e] - mu.v[e]) * is.v[e];
+    }
+    stv<V>(dz_y + o, m);
+    if (r_mean != nullptr) {
+      const Vec<V> rv = ldv<V>(r + o), rm = ldv<V>(r_mean + c0), ri = ldv<V>(r_invstd + c0);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        acc[e][2] += m.v[e];
+        acc[e][3] += m.v[e] * (rv.v[e] - rm.v[e]) * ri.v[e];
+      }
+      stv<V>(dr + o, m);
+    } else if (dr != nullptr) {
+      if (dr_accumulate) {
+        Vec<V> d = ldv<V>(dr + o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d.v[e] += m.v[e];
+        stv<V>(dr + o, d);
+      } else {
+        stv<V>(dr + o, m);
+      }
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------- MaxPool 3x3 / stride 2 / pad 1
+__global__ void __launch_bounds__(kThreads) maxpool3s2_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                                                  float* __restrict__ out, uint8_t* __restrict__ idx) {
+  const int G = C / 4;
+  const long long total = (long long)N * OH * OW * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int g = (int)(i % G);
+    long long pix = i / G;
+    const int ox = (int)(pix % OW);
+    pix /= OW;
+    const int oy = (int)(pix % OH), n = (int)(pix / OH);
+    f32x4 best = f32x4{-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    int bi[4] = {0, 0, 0, 0};
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int iy = 2 * oy - 1 + q / 3, ix = 2 * ox - 1 + q % 3;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * C + g * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!any || v[e] > best[e]) {
+          best[e] = v[e];
+          bi[e] = q;
+        }
+      any = true;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = best;
+    uchar4 code;
+    code.x = (uint8_t)bi[0]; code.y = (uint8_t)bi[1]; code.z = (uint8_t)bi[2]; code.w = (uint8_t)bi[3];
+    *reinterpret_cast<uchar4*>(idx + i * 4) = code;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) maxpool3s2_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ idx, int N, int H,
+                                                                  int W, int C, int OH, int OW, float* __restrict__ dx, int accumulate) {
+  const int G = C / 4;
+  const long long total = (long long)N * H * W * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int g = (int)(i % G);
+    long long pix = i / G;
+    const int ix = (int)(pix % W);
+    pix /= W;
+    const int iy = (int)(pix % H), n = (int)(pix / H);
+    f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(dx + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // windows (oy, ox) with 2*oy - 1 <= iy <= 2*oy + 1
+    for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy < 0 || oy >= OH) continue;
+      const int qy = iy - (2 * oy - 1);
+      for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= OW) continue;
+        const int q = qy * 3 + (ix - (2 * ox - 1));
+        const long long o = ((((long long)n * OH + oy) * OW + ox) * G + g) * 4;
+        const uchar4 code = *reinterpret_cast<const uchar4*>(idx + o);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dout + o);
+        if (code.x == q) s[0] += gv[0];
+        if (code.y == q) s[1] += gv[1];
+        if (code.z == q) s[2] += gv[2];
+        if (code.w == q) s[3] += gv[3];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = s;
+  }
+}
+
+// backward of nearest x2 upsample for NHWC with C channels
+__global__ void upsample2x_nearest_bwd_nhwc_kernel(const float* __restrict__ dfull, int N, int h, int w, int C, float* __restrict__ dlow,
+                                                   int accumulate) {
+  const long long total = (long long)N * h * w * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int x = (int)(t % w);
+    t /= w;
+    const int yy = (int)(t % h), n = (int)(t / h);
+    const float* b = dfull + ((((long long)n * 2 * h + 2 * yy) * 2 * w + 2 * x) * C + c);
+    const long long rs = (long long)2 * w * C;
+    float s = (b[0] + b[C]) + (b[rs] + b[rs + C]);
+    if (accumulate) s += dlow[i];
+    dlow[i] = s;
+  }
+}
+
+__device__ __forceinline__ int reflect_idx(int v, int n) {
+  const int m = n - 1;
+  int a = v < 0 ? -v : v;
+  a = m - a;
+  a = a < 0 ? -a : a;
+  return m - a;
+}
+
+// dx[n][y][x][c] (+)= sum over padded (py, px) in [-pad, H+pad) x [-pad, W+pad) with reflect(py) == y, reflect(px) == x
+__global__ void reflect_fold_kernel(const float* __restrict__ dxp, int N, int H, int W, int C, int pad, float* __restrict__ dx, int accumulate) {
+  const long long total = (long long)N * H * W * C;
+  const int PH = H + 2 * pad, PW = W + 2 * pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H), n = (int)(t / H);
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y;
+    if (y >= 1 && y <= pad) ys[ny++] = -y;
+    if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = 2 * (H - 1) - y;
+    xs[nx++] = x;
+    if (x >= 1 && x <= pad) xs[nx++] = -x;
+    if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = 2 * (W - 1) - x;
+    float s = accumulate ? dx[i] : 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) s += dxp[(((long long)n * PH + ys[a] + pad) * PW + xs[b] + pad) * C + c];
+    dx[i] = s;
+  }
+}
+
+// out[n][c] = scale * mean over the HW pixels of x[n][p][c]   (pose = 0.01 * pose_pred.mean(3).mean(2), models/PoseExpNet.py:73-75)
+// one block per sample; threads stride over (pixel, channel) so consecutive lanes read consecutive addresses
+__global__ void __launch_bounds__(kThreads) spatial_mean_fwd_kernel(const float* __restrict__ x, long long HW, int C, float scale,
+                                                                    float* __restrict__ out) {
+  const int n = blockIdx.x;
+  const float* X = x + (long long)n * HW * C;
+  __shared__ float red[kThreads];
+  for (int c0 = 0; c0 < C; c0 += kThreads) {
+    // thread t handles channel c0 + (t % cw) for pixels t / cw, t / cw + stride, ...
+    const int cw = (C - c0) < kThreads ? (C - c0) : kThreads;
+    const int lanes_per_c = kThreads / cw;
+    const int c = threadIdx.x % cw, pl = threadIdx.x / cw;
+    float s = 0.f;
+    if (pl < lanes_per_c)
+      for (long long p = pl; p < HW; p += lanes_per_c) s += X[p * C + c0 + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < cw) {
+      float t = 0.f;
+      for (int q = 0; q < lanes_per_c; ++q) t += red[q * cw + threadIdx.x];
+      out[(long long)n * C + c0 + threadIdx.x] = scale * (t / (float)HW);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void spatial_mean_bwd_kernel(const float* __restrict__ dout, int N, long long HW, int C, float scale, float* __restrict__ dx) {
+  const long long total = (long long)N * HW * C;
+  const float k = scale / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long n = i / (HW * C);
+    dx[i] = dout[n * C + c] * k;
+  }
+}
+
+__global__ void sub_div_kernel(const float* __restrict__ x, long long n, float sub, float div, float* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = (x[i] - sub) / div;
+}
+
 // ----------------------------------------------------------------------------------------------- 1-channel helpers
 __global__ void upsample2x_nearest_bwd_kernel(const float* __restrict__ dfull, int N, int h, int w, float* __restrict__ dlow, int accumulate) {
   const long long total = (long long)N * h * w;
@@ -499,12 +739,14 @@ int dn_bn_relu_bwd_reduce(float* da_dz, const float* y, const float* scale, cons
 }
 
 int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float* invstd, const float* gamma, const float* partial,
-                    int32_t partial_rows, int64_t rows, int32_t C, float* dgamma, float* dbeta, dn_stream_t stream) {
+                    int32_t partial_rows, int32_t partial_stride, int32_t partial_offset, int64_t rows, int32_t C, float* dgamma,
+                    float* dbeta, dn_stream_t stream) {
   DN_REQUIRE(dz_dy && y && mean && invstd && gamma && partial && dgamma && dbeta && rows > 0, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply: need C%%4==0");
+  DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: partial layout");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, 2, 0, dbeta);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, 2, 1, dgamma);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset + 1, dgamma);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, dz_dy, y, mean, invstd, gamma, dgamma, dbeta,
                      (long long)rows, C, (float)(1.0 / (double)rows));
   return check_launch("bn_bwd_apply");
@@ -543,6 +785,79 @@ int dn_upsample2x_bilinear_bwd(const float* dout, int32_t N, int32_t h, int32_t 
   hipLaunchKernelGGL(upsample2x_bilinear_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dout, N, h, w,
                      OH, OW, dlow, accumulate);
   return check_launch("upsample2x_bilinear_bwd_kernel");
+}
+
+int dn_bn_add_relu_fwd(const float* y, const float* scale, const float* shift, const float* r, const float* r_scale, const float* r_shift,
+                       int64_t rows, int32_t C, float* out, dn_stream_t stream) {
+  DN_REQUIRE(y && scale && shift && out && rows > 0 && C > 0 && ((r_scale == nullptr) == (r_shift == nullptr)) && (r || !r_scale),
+             DN_ERR_BAD_ARG, "dn_bn_add_relu_fwd: bad argument");
+  DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_add_relu_fwd: need C%%4==0");
+  hipLaunchKernelGGL(bn_add_relu_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, as_stream(stream), y, scale, shift, r, r_scale,
+                     r_shift, (long long)rows, C, out);
+  return check_launch("bn_add_relu_fwd_kernel");
+}
+
+int dn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, const float* mean, const float* invstd, const float* r,
+                       const float* r_mean, const float* r_invstd, int64_t rows, int32_t C, float* dz_y, float* dr, int32_t dr_accumulate,
+                       float* partial, dn_stream_t stream) {
+  DN_REQUIRE(gout && out && y && mean && invstd && dz_y && partial && rows > 0 && C > 0, DN_ERR_BAD_ARG, "dn_bn_add_relu_bwd: bad argument");
+  DN_REQUIRE((r_mean == nullptr) == (r_invstd == nullptr), DN_ERR_BAD_ARG, "dn_bn_add_relu_bwd: r_mean / r_invstd go together");
+  DN_REQUIRE(r_mean == nullptr || (r && dr), DN_ERR_BAD_ARG, "dn_bn_add_relu_bwd: the downsample branch needs r and dr");
+  AddReluBwdOp op{gout, out, y, mean, invstd, r, r_mean, r_invstd, dz_y, dr, dr_accumulate, C};
+  return launch_colreduce(op, rows, C, partial, as_stream(stream), "bn_add_relu_bwd");
+}
+
+int dn_maxpool3s2_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* out, uint8_t* idx, dn_stream_t stream) {
+  DN_REQUIRE(x && out && idx && N > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_maxpool3s2_fwd: bad argument");
+  DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool3s2_fwd: need C%%4==0");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * (C / 4))), dim3(kThreads), 0, as_stream(stream), x, N, H, W,
+                     C, OH, OW, out, idx);
+  return check_launch("maxpool3s2_fwd_kernel");
+}
+
+int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, int32_t accumulate,
+                      dn_stream_t stream) {
+  DN_REQUIRE(dout && idx && dx && N > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_maxpool3s2_bwd: bad argument");
+  DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool3s2_bwd: need C%%4==0");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(kThreads), 0, as_stream(stream), dout, idx, N, H,
+                     W, C, OH, OW, dx, accumulate);
+  return check_launch("maxpool3s2_bwd_kernel");
+}
+
+int dn_upsample2x_nearest_bwd_nhwc(const float* dfull, int32_t N, int32_t h, int32_t w, int32_t C, float* dlow, int32_t accumulate,
+                                   dn_stream_t stream) {
+  DN_REQUIRE(dfull && dlow && N > 0 && h > 0 && w > 0 && C > 0, DN_ERR_BAD_ARG, "dn_upsample2x_nearest_bwd_nhwc: bad argument");
+  hipLaunchKernelGGL(upsample2x_nearest_bwd_nhwc_kernel, dim3(ew_blocks((long long)N * h * w * C)), dim3(256), 0, as_stream(stream), dfull, N, h,
+                     w, C, dlow, accumulate);
+  return check_launch("upsample2x_nearest_bwd_nhwc_kernel");
+}
+
+int dn_reflect_fold(const float* dxp, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, float* dx, int32_t accumulate, dn_stream_t stream) {
+  DN_REQUIRE(dxp && dx && N > 0 && C > 0 && pad >= 1 && H > pad && W > pad, DN_ERR_BAD_ARG, "dn_reflect_fold: bad argument (needs H, W > pad)");
+  hipLaunchKernelGGL(reflect_fold_kernel, dim3(ew_blocks((long long)N * H * W * C)), dim3(256), 0, as_stream(stream), dxp, N, H, W, C, pad, dx,
+                     accumulate);
+  return check_launch("reflect_fold_kernel");
+}
+
+int dn_sub_div(const float* x, int64_t n, float sub, float div, float* out, dn_stream_t stream) {
+  DN_REQUIRE(x && out && n > 0 && div != 0.f, DN_ERR_BAD_ARG, "dn_sub_div: bad argument");
+  hipLaunchKernelGGL(sub_div_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x, (long long)n, sub, div, out);
+  return check_launch("sub_div_kernel");
+}
+
+int dn_spatial_mean_fwd(const float* x, int32_t N, int64_t HW, int32_t C, float scale, float* out, dn_stream_t stream) {
+  DN_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, DN_ERR_BAD_ARG, "dn_spatial_mean_fwd: bad argument");
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(N), dim3(kThreads), 0, as_stream(stream), x, (long long)HW, C, scale, out);
+  return check_launch("spatial_mean_fwd_kernel");
+}
+
+int dn_spatial_mean_bwd(const float* dout, int32_t N, int64_t HW, int32_t C, float scale, float* dx, dn_stream_t stream) {
+  DN_REQUIRE(dout && dx && N > 0 && HW > 0 && C > 0, DN_ERR_BAD_ARG, "dn_spatial_mean_bwd: bad argument");
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(ew_blocks((long long)N * HW * C)), dim3(256), 0, as_stream(stream), dout, N, (long long)HW, C,
+                     scale, dx);
+  return check_launch("spatial_mean_bwd_kernel");
 }
 
 int dn_reciprocal_fwd(const float* x, float* y, int64_t n, dn_stream_t stream) {

@@ -80,7 +80,7 @@ def require_cuda(t, what):
 class Act:
     """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
     __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
-                 "partial_rows", "needs_grad", "strides")
+                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu")
 
     def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
         self.t = t
@@ -90,12 +90,22 @@ class Act:
         self.grad_is_dz = False
         self.partial = None
         self.partial_rows = 0
+        self.partial_stride, self.partial_offset = 2, 0
+        self.no_relu = False            # pending BatchNorm affine WITHOUT ReLU (bottleneck bn3 / downsample BN): only
+                                        # block_bn_add_relu may consume it
         self.needs_grad = needs_grad
         self.strides = strides or (H * W * C, W * C, C, 1)   # (n, h, w, c) element strides
 
     @property
     def rows(self):
         return self.N * self.H * self.W
+
+    @staticmethod
+    def from_nchw(x, needs_grad=False):
+        """Any NCHW-shaped tensor (any strides: contiguous NCHW or channels_last) consumed in place through operand strides."""
+        a = Act.from_nchw_image(x)
+        a.needs_grad = needs_grad
+        return a
 
     @staticmethod
     def from_nchw_image(x):
@@ -137,6 +147,8 @@ class Piece:
 
 def _fill_operand(op, piece):
     a = piece.act
+    if a.no_relu:
+        raise RuntimeError("an activation with a pending ReLU-less BatchNorm can only feed block_bn_add_relu")
     op.data = a.t.data_ptr()
     op.C = a.C
     op.up_shift = 1 if piece.up else 0
@@ -158,12 +170,17 @@ def _fill_result(res, tensor, C_, H, W, accumulate, ld=None):
 class ConvLayer:
     """Runtime companion of one nn.Conv2d / nn.ConvTranspose2d: packed-weight caches + descriptor builders."""
 
-    def __init__(self, module, transposed=False, in_channels_split=None):
+    def __init__(self, module, transposed=False, in_channels_split=None, reflect_pad=0):
         self.m = module
         self.transposed = transposed
         self.R, self.S = module.kernel_size
         self.stride = module.stride[0]
         self.pad = module.padding[0]
+        self.reflect = reflect_pad > 0          # nn.ReflectionPad2d(reflect_pad) in front of a pad-0 conv (layers.py:124-136)
+        if self.reflect:
+            if transposed or self.pad != 0:
+                raise ValueError("reflection padding goes with an un-padded nn.Conv2d")
+            self.pad = reflect_pad
         self.out_pad = module.output_padding[0] if transposed else 0
         self.Cin = module.in_channels
         self.Cout = module.out_channels
@@ -186,6 +203,7 @@ class ConvLayer:
         d.kind = kind
         d.N, d.IH, d.IW, d.OH, d.OW = N, IH, IW, OH, OW
         d.R, d.S, d.stride, d.pad = self.R, self.S, self.stride, self.pad
+        d.pad_mode = 1 if (self.reflect and kind == CONV_FWD) else 0
         return d
 
     def packed(self, kind, desc):
@@ -274,8 +292,12 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
         return
     IH, IW = in_hw                      # logical spatial size of the forward input
     kind = CONVT_DGRAD if layer.transposed else CONV_DGRAD
-    # the dgrad kernel reads dy (spatial OH x OW) and writes the forward-input-shaped gradient (IH x IW)
-    d = layer._desc(kind, N, OH, OW, IH, IW)
+    rp = layer.pad if layer.reflect else 0
+    GH, GW = IH + 2 * rp, IW + 2 * rp   # extent the kernel writes: the reflection-padded input when the conv reflects
+    # the dgrad kernel reads dy (spatial OH x OW) and writes the forward-input-shaped gradient (GH x GW)
+    d = layer._desc(kind, N, OH, OW, GH, GW)
+    if layer.reflect:
+        d.pad = 0                       # conv over the padded extent has no padding of its own
     d.n_in = 1
     op = d.in_[0]
     op.data = dy.data_ptr()
@@ -286,13 +308,14 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
     post = []
     for i, p in enumerate(targets):
         a = p.act
-        if p.up:
-            # gradient w.r.t. the upsampled view: full-resolution scratch, folded 2x2 afterwards
-            tmp = torch.empty((N, IH, IW, a.C), dtype=torch.float32, device=dy.device)
-            _fill_result(d.out[i], tmp, a.C, IH, IW, False)
-            post.append((a, tmp))
+        if p.up or layer.reflect:
+            # gradient w.r.t. the (padded / upsampled) view: scratch, folded afterwards
+            tmp = torch.empty((N, GH, GW, a.C), dtype=torch.float32, device=dy.device)
+            _fill_result(d.out[i], tmp, a.C, GH, GW, False)
+            if a.needs_grad:
+                post.append((p, tmp))
         elif not a.needs_grad:
-            # still needs a destination: scratch (rare: only the image, which is never concatenated)
+            # still needs a destination: scratch (rare: a detached skip inside a concat)
             tmp = torch.empty((N, IH, IW, a.C), dtype=torch.float32, device=dy.device)
             _fill_result(d.out[i], tmp, a.C, IH, IW, False)
         else:
@@ -307,13 +330,26 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
                 "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_dgrad" if layer.transposed else "conv_dgrad", layer.R, layer.stride,
                                                          layer.Cin, layer.Cout, N, IH, IW)):
         _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
-    for a, tmp in post:
-        if a.C != 1:
-            raise NotImplementedError("upsampled operand with C != 1")
+    for p, tmp in post:
+        a = p.act
+        cur = tmp
+        if layer.reflect:
+            if p.up:
+                cur = torch.empty((N, IH, IW, a.C), dtype=torch.float32, device=dy.device)
+                _lib.call("dn_reflect_fold", tmp.data_ptr(), N, IH, IW, a.C, rp, cur.data_ptr(), 0, _stream())
+            else:
+                first = a.grad is None
+                if first:
+                    a.grad = a.new_like()
+                _lib.call("dn_reflect_fold", tmp.data_ptr(), N, IH, IW, a.C, rp, a.grad.data_ptr(), 0 if first else 1, _stream())
+                continue
         first = a.grad is None
         if first:
             a.grad = a.new_like()
-        _lib.call("dn_upsample2x_nearest_bwd", tmp.data_ptr(), N, a.H, a.W, a.grad.data_ptr(), 0 if first else 1, _stream())
+        if a.C == 1:
+            _lib.call("dn_upsample2x_nearest_bwd", cur.data_ptr(), N, a.H, a.W, a.grad.data_ptr(), 0 if first else 1, _stream())
+        else:
+            _lib.call("dn_upsample2x_nearest_bwd_nhwc", cur.data_ptr(), N, a.H, a.W, a.C, a.grad.data_ptr(), 0 if first else 1, _stream())
 
 
 def colsum(partial, rows, Cn, stride=1, offset=0):
@@ -360,7 +396,7 @@ class GradSink:
 
 
 # ------------------------------------------------------------------------------------------------- block helpers
-def block_conv_bn(tape, sink, x_piece, layer, bn, training):
+def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
     """conv3x3 -> BatchNorm (batch statistics when training) -> ReLU, with the BN-apply+ReLU left pending on the result
     (the consumer's loader applies it).  Reference: torchvision vgg16_bn features triplets used at
     models/Disp_vgg_BN.py:137-141."""
@@ -369,6 +405,7 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training):
     OH, OW = y_t.shape[1], y_t.shape[2]
     Cn = layer.Cout
     y = Act(y_t, xa.N, OH, OW, Cn)
+    y.no_relu = not relu
     dev = y_t.device
     y.scale = torch.empty(Cn, dtype=torch.float32, device=dev)
     y.shift = torch.empty(Cn, dtype=torch.float32, device=dev)
@@ -390,6 +427,8 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training):
         g = y.grad
         if training:
             if not y.grad_is_dz:
+                if y.no_relu:
+                    raise RuntimeError("a ReLU-less BatchNorm output must be consumed by block_bn_add_relu")
                 nblk = _lib.load().dn_reduce_blocks(y.rows, Cn)
                 y.partial = torch.empty((nblk, Cn, 2), dtype=torch.float32, device=dev)
                 y.partial_rows = nblk
@@ -398,8 +437,8 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training):
             dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
             dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
             _lib.call("dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(),
-                      bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.rows, Cn, dgamma.data_ptr(),
-                      dbeta.data_ptr(), _stream())
+                      bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn,
+                      dgamma.data_ptr(), dbeta.data_ptr(), _stream())
             sink.put(bn.weight, dgamma)
             sink.put(bn.bias, dbeta)
         else:
@@ -441,14 +480,24 @@ def block_pool(tape, y):
     return p
 
 
-def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None):
+def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, stat_bn=None):
     """conv / conv-transpose over virtually concatenated pieces + bias + activation in the epilogue.
-    Reference: Conv2dBlock1 / ConvTranspose2dBlock1 / predict_disp (models/Disp_vgg_BN.py:40-70)."""
+    Reference: Conv2dBlock1 / ConvTranspose2dBlock1 / predict_disp (models/Disp_vgg_BN.py:40-70).
+    `stat_bn`: a BatchNorm2d whose output the reference computes and DISCARDS (models/Disp_res_50.py:141-145: `bn1 =
+    self.bn1(conv1); relu1 = self.relu(conv1)`): only its running statistics are updated, from the conv epilogue's sums."""
     a0 = pieces[0].act
     in_hw = (a0.H * (2 if pieces[0].up else 1), a0.W * (2 if pieces[0].up else 1))
-    y_t, _, _ = conv_forward(layer, pieces, act, p0, p1, out_hw=out_hw)
+    y_t, partial, prow = conv_forward(layer, pieces, act, p0, p1, out_hw=out_hw, bn_stats=stat_bn is not None)
     OH, OW = y_t.shape[1], y_t.shape[2]
     y = Act(y_t, a0.N, OH, OW, layer.Cout)
+    if stat_bn is not None:
+        Cn, dev = layer.Cout, y_t.device
+        scratch = torch.empty((4, Cn), dtype=torch.float32, device=dev)
+        _lib.call("dn_bn_finalize", partial.data_ptr(), prow, Cn, y.rows, _ptr(layer.m.bias.detach()) if layer.m.bias is not None else None,
+                  stat_bn.weight.data_ptr(), stat_bn.bias.data_ptr(), stat_bn.running_mean.data_ptr(), stat_bn.running_var.data_ptr(),
+                  stat_bn.momentum if stat_bn.momentum is not None else BN_MOMENTUM, stat_bn.eps, scratch[0].data_ptr(),
+                  scratch[1].data_ptr(), scratch[2].data_ptr(), scratch[3].data_ptr(), _stream())
+        stat_bn.num_batches_tracked += 1
 
     def backward():
         if y.grad is None:
@@ -514,6 +563,111 @@ def block_channel_scale(tape, x, mask):
             tmp = x.new_like()
             _lib.call("dn_channel_scale", out.grad.data_ptr(), mask.data_ptr(), x.N, x.H * x.W, x.C, tmp.data_ptr(), _stream())
             x.grad.add_(tmp)
+        out.grad = None
+
+    tape.push(backward)
+    return out
+
+
+def block_bn_add_relu(tape, y, r):
+    """out = relu(bn(y) + identity): the tail of a ResNet bottleneck (models/Disp_res_50.py:229-247).  `y` carries a pending
+    ReLU-less BatchNorm (block_conv_bn(..., relu=False)); `r` is either a plain activation (identity) or another ReLU-less
+    BatchNorm output (the downsample branch).  One HBM pass forward, one backward (which also produces the BatchNorm
+    backward's column sums for both branches)."""
+    if r is not None and not y.no_relu:
+        raise RuntimeError("block_bn_add_relu: y must come from block_conv_bn(relu=False)")
+    ds = r is not None and r.no_relu
+    if r is not None and not ds and r.scale is not None:
+        raise RuntimeError("block_bn_add_relu: the identity branch must be a plain activation")
+    dev = y.t.device
+    out_t = y.new_like()
+    _lib.call("dn_bn_add_relu_fwd", y.t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), r.t.data_ptr() if r is not None else None,
+              r.scale.data_ptr() if ds else None, r.shift.data_ptr() if ds else None, y.rows, y.C, out_t.data_ptr(), _stream())
+    out = Act(out_t, y.N, y.H, y.W, y.C)
+
+    def backward():
+        if out.grad is None:
+            return
+        if y.mean is None:
+            raise NotImplementedError("backward through eval-mode BatchNorm (frozen statistics) is not implemented")
+        nblk = _lib.load().dn_reduce_blocks(y.rows, y.C)
+        partial = torch.empty((nblk, y.C, 4), dtype=torch.float32, device=dev)
+        y.grad = y.new_like()
+        y.grad_is_dz = True
+        y.partial, y.partial_rows, y.partial_stride, y.partial_offset = partial, nblk, 4, 0
+        dr, acc = None, 0
+        if ds:
+            r.grad = r.new_like()
+            r.grad_is_dz = True
+            r.partial, r.partial_rows, r.partial_stride, r.partial_offset = partial, nblk, 4, 2
+            dr = r.grad
+        elif r is not None and r.needs_grad:
+            acc = 0 if r.grad is None else 1
+            if r.grad is None:
+                r.grad = r.new_like()
+            dr = r.grad
+        _lib.call("dn_bn_add_relu_bwd", out.grad.data_ptr(), out_t.data_ptr(), y.t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(),
+                  r.t.data_ptr() if r is not None else None, r.mean.data_ptr() if ds else None, r.invstd.data_ptr() if ds else None, y.rows, y.C, y.grad.data_ptr(),
+                  _ptr(dr), acc, partial.data_ptr(), _stream())
+        out.grad = None
+
+    tape.push(backward)
+    return out
+
+
+def block_bn_relu(tape, y):
+    """Materialise relu(bn(y)) of a block_conv_bn result as a plain activation (needed when it leaves the engine as a tensor or
+    feeds a max-pool other than the fused 2x2 one)."""
+    return block_bn_add_relu(tape, y, None)
+
+
+def block_maxpool3s2(tape, x):
+    """MaxPool2d(kernel_size=3, stride=2, padding=1) of a plain activation (models/Disp_res_50.py:73)."""
+    if x.scale is not None:
+        raise RuntimeError("block_maxpool3s2 expects a plain activation")
+    OH, OW = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+    dev = x.t.device
+    o_t = torch.empty((x.N, OH, OW, x.C), dtype=torch.float32, device=dev)
+    idx = torch.empty((x.N, OH, OW, x.C), dtype=torch.uint8, device=dev)
+    _lib.call("dn_maxpool3s2_fwd", x.t.data_ptr(), x.N, x.H, x.W, x.C, o_t.data_ptr(), idx.data_ptr(), _stream())
+    out = Act(o_t, x.N, OH, OW, x.C)
+
+    def backward():
+        if out.grad is None or not x.needs_grad:
+            return
+        first = x.grad is None
+        if first:
+            x.grad = x.new_like()
+        _lib.call("dn_maxpool3s2_bwd", out.grad.data_ptr(), idx.data_ptr(), x.N, x.H, x.W, x.C, x.grad.data_ptr(), 0 if first else 1, _stream())
+        out.grad = None
+
+    tape.push(backward)
+    return out
+
+
+def normalize_input(x, sub, div):
+    """(x - sub) / div on the user's NCHW image (networks/vgg_encoder.py:80, resnet_encoder.py:89) -> plain NCHW tensor."""
+    xc = x.contiguous()
+    out = torch.empty_like(xc)
+    _lib.call("dn_sub_div", xc.data_ptr(), xc.numel(), sub, div, out.data_ptr(), _stream())
+    return out
+
+
+def block_spatial_mean(tape, x, scale=1.0):
+    """[N,H,W,C] -> [N,1,1,C] = scale * mean over H,W  (models/PoseExpNet.py:73-75)."""
+    if x.scale is not None:
+        raise RuntimeError("block_spatial_mean expects a plain activation")
+    o_t = torch.empty((x.N, 1, 1, x.C), dtype=torch.float32, device=x.t.device)
+    _lib.call("dn_spatial_mean_fwd", x.t.data_ptr(), x.N, x.H * x.W, x.C, scale, o_t.data_ptr(), _stream())
+    out = Act(o_t, x.N, 1, 1, x.C)
+
+    def backward():
+        if out.grad is None:
+            return
+        if x.grad is not None:
+            raise RuntimeError("block_spatial_mean: single-consumer input expected")
+        x.grad = x.new_like()
+        _lib.call("dn_spatial_mean_bwd", out.grad.data_ptr(), x.N, x.H * x.W, x.C, scale, x.grad.data_ptr(), _stream())
         out.grad = None
 
     tape.push(backward)

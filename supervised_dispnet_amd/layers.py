@@ -86,3 +86,28 @@ class _EdgeSmooth(torch.autograd.Function):
 def get_smooth_loss(disp, img):
     """reference layers.py:199-212: edge-aware first-order smoothness (gradient w.r.t. the disparity)."""
     return _EdgeSmooth.apply(disp, img)
+
+
+def upsample(x):
+    """reference layers.py:193-196 (nearest x2).  Inside networks.DepthDecoder the upsample is virtual (the consumer conv's
+    loader reads index >> 1); this standalone form is kept for API completeness and is not on the hot path."""
+    raise NotImplementedError("layers.upsample is fused into the consumer convolution on the HIP path (networks.DepthDecoder)")
+
+
+class Conv3x3(nn.Module):
+    """reference layers.py:124-136: ReflectionPad2d(1) (or ZeroPad2d) + Conv2d(3x3).  Parameter container: executed by
+    networks.DepthDecoder through the engine (reflection is a loader index map, not a padded copy)."""
+
+    def __init__(self, in_channels, out_channels, use_refl=True):
+        super(Conv3x3, self).__init__()
+        self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+
+
+class ConvBlock(nn.Module):
+    """reference layers.py:106-121: Conv3x3 + ELU (parameter container, see Conv3x3)."""
+
+    def __init__(self, in_channels, out_channels):
+        super(ConvBlock, self).__init__()
+        self.conv = Conv3x3(in_channels, out_channels)
+        self.nonlin = nn.ELU(inplace=True)

@@ -98,7 +98,7 @@ class DispNetS(nn.Module):
         a, b = float(self.alpha), float(self.beta)
         relu = lambda name, pieces, out_hw=None: engine.block_conv_act(tape, sink, pieces, rt[name], ACT_RELU, out_hw=out_hw)
         head = lambda name, act: engine.block_conv_act(tape, sink, [P(act)], rt[name], ACT_SIGMOID_AFFINE, a, b)
-        img = engine.Act.from_nchw_image(x)
+        img = x
         enc, cur = [], img
         for i in range(1, 8):
             cur = relu("conv%d.0" % i, [P(cur)])

@@ -103,7 +103,7 @@ class Disp_vgg_BN(nn.Module):
 
     def _encoder(self, tape, sink, x):
         rt = self._runtime()
-        cur = engine.Piece(engine.Act.from_nchw_image(x))
+        cur = engine.Piece(x)
         feats = []
         for stage in rt["enc"]:
             for layer, bn in stage:

@@ -6,6 +6,9 @@ clear error rather than silently running something else.
 from .DispNetS import DispNetS
 from .Disp_vgg_BN import Disp_vgg_BN
 from .Disp_vgg_BN_DORN import Disp_vgg_BN_DORN
+from .Disp_res_50 import Disp_res_50
+from .PoseExpNet import PoseExpNet
+from .monodepth2 import monodepth2
 
 
 def _out_of_scope(name):

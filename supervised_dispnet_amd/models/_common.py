@@ -42,17 +42,20 @@ def xavier_init_like_reference(module):
 
 
 class HipNetFunction(torch.autograd.Function):
-    """One autograd node for the whole encoder-decoder.  forward: run the net's HIP schedule, recording the engine tape;
-    backward: seed the output gradients, run the tape in reverse, hand parameter gradients back (or nothing for
-    parameters whose gradient the engine wrote in place into an optimizer arena)."""
+    """One autograd node for a whole network (or sub-network).  forward: run the net's HIP schedule, recording the engine
+    tape; backward: seed the output gradients, run the tape in reverse, hand parameter gradients back (or nothing for
+    parameters whose gradient the engine wrote in place into an optimizer arena) and the gradients of those inputs that
+    require one (feature maps handed to a decoder)."""
 
     @staticmethod
-    def forward(ctx, net, x, *params):
+    def forward(ctx, net, n_in, *rest):
+        inputs, params = rest[:n_in], rest[n_in:]
         recording = any(ctx.needs_input_grad[2:])
         tape = engine.Tape(recording)
         sink = engine.GradSink()
-        outs = net._hip_forward(tape, sink, x)         # list[Act] with C == 1
-        ctx.tape, ctx.sink, ctx.outs, ctx.params = tape, sink, outs, params
+        in_acts = [engine.Act.from_nchw(x, needs_grad=ctx.needs_input_grad[2 + i]) for i, x in enumerate(inputs)]
+        outs = net._hip_forward(tape, sink, *in_acts)         # list[Act]
+        ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
         results = tuple(a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2) for a in outs)
         return results
 
@@ -62,16 +65,18 @@ class HipNetFunction(torch.autograd.Function):
             if g is not None:
                 engine.seed_grad(a, g)
         ctx.tape.run_backward()
+        ig = tuple((a.grad.permute(0, 3, 1, 2) if (a.needs_grad and a.grad is not None) else None) for a in ctx.in_acts)
         pg = tuple(ctx.sink.get(p) for p in ctx.params)
-        ctx.tape = ctx.outs = None
-        return (None, None) + pg
+        ctx.tape = ctx.outs = ctx.in_acts = None
+        return (None, None) + ig + pg
 
 
-def run_net(net, x):
-    engine.require_cuda(x, "input image")
-    if x.dtype != torch.float32:
-        raise TypeError("expected a float32 image batch, got %s" % x.dtype)
+def run_net(net, *inputs):
+    for x in inputs:
+        engine.require_cuda(x, "input tensor")
+        if x.dtype != torch.float32:
+            raise TypeError("expected float32 input, got %s" % x.dtype)
     params = [p for p in net._hot_parameters()]
     for p in params:
         engine.require_cuda(p, "model parameters")
-    return HipNetFunction.apply(net, x, *params)
+    return HipNetFunction.apply(net, len(inputs), *inputs, *params)

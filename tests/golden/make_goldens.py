@@ -52,6 +52,82 @@ def _install_shims():
                                             nn.ReLU(True), nn.Dropout(), nn.Linear(8, 8))
 
     tvm.vgg16_bn = lambda pretrained=False, **kw: _VGG()
+
+    # ResNet: layout only (torchvision.models.ResNet with BasicBlock / Bottleneck), used by networks/resnet_encoder.py
+    def _c3(i, o, s=1):
+        return nn.Conv2d(i, o, 3, s, 1, bias=False)
+
+    def _c1(i, o, s=1):
+        return nn.Conv2d(i, o, 1, s, bias=False)
+
+    class _Basic(nn.Module):
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None):
+            super().__init__()
+            self.conv1, self.bn1 = _c3(inplanes, planes, stride), nn.BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2, self.bn2 = _c3(planes, planes), nn.BatchNorm2d(planes)
+            self.downsample = downsample
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + idt)
+
+    class _Bottle(nn.Module):
+        expansion = 4
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None):
+            super().__init__()
+            self.conv1, self.bn1 = _c1(inplanes, planes), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = _c3(planes, planes, stride), nn.BatchNorm2d(planes)
+            self.conv3, self.bn3 = _c1(planes, planes * 4), nn.BatchNorm2d(planes * 4)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = downsample
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.relu(self.bn2(self.conv2(out)))
+            out = self.bn3(self.conv3(out))
+            return self.relu(out + idt)
+
+    class _ResNet(nn.Module):
+        def __init__(self, block, layers, num_classes=1000):
+            super().__init__()
+            self.inplanes = 64
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            self.layer1 = self._make_layer(block, 64, layers[0])
+            self.layer2 = self._make_layer(block, 128, layers[1], 2)
+            self.layer3 = self._make_layer(block, 256, layers[2], 2)
+            self.layer4 = self._make_layer(block, 512, layers[3], 2)
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(512 * block.expansion, num_classes)
+
+        def _make_layer(self, block, planes, blocks, stride=1):
+            ds = None
+            if stride != 1 or self.inplanes != planes * block.expansion:
+                ds = nn.Sequential(_c1(self.inplanes, planes * block.expansion, stride), nn.BatchNorm2d(planes * block.expansion))
+            layers = [block(self.inplanes, planes, stride, ds)]
+            self.inplanes = planes * block.expansion
+            layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+            return nn.Sequential(*layers)
+
+    tvr = types.ModuleType("torchvision.models.resnet")
+    tvr.BasicBlock, tvr.Bottleneck, tvr.model_urls = _Basic, _Bottle, {}
+    tvm.resnet = tvr
+    tvm.ResNet = _ResNet
+    tvm.resnet18 = lambda pretrained=False, **kw: _ResNet(_Basic, [2, 2, 2, 2])
+    tvm.resnet34 = lambda pretrained=False, **kw: _ResNet(_Basic, [3, 4, 6, 3])
+    tvm.resnet50 = lambda pretrained=False, **kw: _ResNet(_Bottle, [3, 4, 6, 3])
+    tvm.resnet101 = lambda pretrained=False, **kw: _ResNet(_Bottle, [3, 4, 23, 3])
+    tvm.resnet152 = lambda pretrained=False, **kw: _ResNet(_Bottle, [3, 8, 36, 3])
+    sys.modules["torchvision.models.resnet"] = tvr
     tv.models = tvm
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.models"] = tvm
@@ -380,6 +456,104 @@ def gold_kitti(ref_kitti):
     save("kitti_gt", **arrays)
 
 
+def _grad_summaries(net, arrays, keys, prefix="grad:"):
+    params = dict(net.named_parameters())
+    for key in keys:
+        g = params[key].grad
+        if g is None:
+            arrays[prefix + key + ":none"] = np.int64(1)
+            continue
+        for k, v in detgen.summarize(g, stride=53).items():
+            arrays["%s%s:%s" % (prefix, key, k)] = v
+
+
+def gold_res50(ref_res50, ref_loss):
+    """BASELINE config 4 net: Disp_res_50 forward (4 outputs, full at a small shape), l1+smooth backward, bn1 quirk, eval."""
+    b, h, w = 2, 64, 96
+    net = ref_res50.Disp_res_50(datasets="nyu")
+    detgen.fill_state_dict(net.state_dict(), "res50")
+    x = detgen.image_batch(b, h, w, "res50:x")
+    gt = detgen.sparse_depth(b, h, w, "res50:gt", density=0.6, lo=0.3, hi=11.0)
+    net.train()
+    disps = net(x)
+    depth = [1 / d for d in disps]
+    loss = ref_loss.l1_loss(gt, depth, "nyu") + 0.1 * ref_loss.smooth_loss(depth)
+    loss.backward()
+    arrays = {"loss": np.float64(loss.item())}
+    for i, o in enumerate(disps):
+        arrays["disp%d" % i] = _np(o)
+    _grad_summaries(net, arrays, ["conv1.weight", "bn1.weight", "layer1.0.conv1.weight", "layer1.0.downsample.0.weight",
+                                  "layer2.0.bn3.weight", "layer3.5.conv2.weight", "layer4.2.bn3.bias", "upconv5.0.weight",
+                                  "iconv3.0.weight", "iconv1.0.bias", "predict_disp1.0.weight"])
+    sd = net.state_dict()
+    for key in ("bn1.running_mean", "bn1.running_var", "layer4.2.bn3.running_mean", "layer1.0.downsample.1.running_var"):
+        arrays["bn:" + key] = _np(sd[key])
+    arrays["bn1.num_batches_tracked"] = np.int64(int(sd["bn1.num_batches_tracked"]))
+    net.eval()
+    with torch.no_grad():
+        arrays["eval_disp1"] = _np(net(x))
+    save("res50", **arrays)
+
+
+def gold_mono2(ref_networks, ref_mono2):
+    """monodepth2-style nets: vggEncoder(16)+DepthDecoder and ResnetEncoder(18)+DepthDecoder through models.monodepth2."""
+    b, h, w = 2, 64, 96
+    x = (detgen.image_batch(b, h, w, "mono2:x") + 1) / 2          # monodepth2 consumes [0,1] images (train.py:122-127)
+    arrays = {}
+    for tag, enc in (("vgg", ref_networks.vggEncoder(16, False)), ("res18", ref_networks.ResnetEncoder(18, False))):
+        dec = ref_networks.DepthDecoder(enc.num_ch_enc)
+        net = ref_mono2.monodepth2(enc, dec)
+        detgen.fill_state_dict(net.state_dict(), "mono2:" + tag)
+        net.train()
+        outs = net(x)
+        ws = [detgen.uniform(tuple(o.shape), "mono2:g%d" % i, -1, 1) for i, o in enumerate(outs)]
+        sum((o * wt).sum() for o, wt in zip(outs, ws)).backward()
+        for i, o in enumerate(outs):
+            arrays["%s:disp%d" % (tag, i)] = _np(o)
+        keys = ["decoder.decoder.0.conv.conv.weight", "decoder.decoder.9.conv.conv.weight", "decoder.decoder.10.conv.weight",
+                "decoder.decoder.13.conv.bias"]
+        keys += ["encoder.encoder.features.0.weight", "encoder.encoder.features.41.weight"] if tag == "vgg" else \
+                ["encoder.encoder.conv1.weight", "encoder.encoder.bn1.weight", "encoder.encoder.layer2.0.downsample.0.weight",
+                 "encoder.encoder.layer4.1.bn2.bias"]
+        _grad_summaries(net, arrays, keys, prefix=tag + ":grad:")
+        arrays[tag + ":keys"] = np.array(sorted(net.state_dict().keys()))
+        net.eval()
+        with torch.no_grad():
+            arrays[tag + ":eval_disp0"] = _np(net(x))
+    save("mono2", **arrays)
+
+
+def gold_posenet(ref_pose):
+    """PoseExpNet (config 3's pose / explainability producer): masks + pose, train and eval, with and without the mask decoder."""
+    b, h, w = 2, 128, 416
+    tgt = detgen.image_batch(b, h, w, "pose:tgt")
+    refs = [detgen.image_batch(b, h, w, "pose:ref%d" % i) for i in range(2)]
+    arrays = {}
+    for exp in (False, True):
+        net = ref_pose.PoseExpNet(nb_ref_imgs=2, output_exp=exp)
+        detgen.fill_state_dict(net.state_dict(), "posenet")
+        net.train()
+        masks, pose = net(tgt, refs)
+        tag = "exp%d" % int(exp)
+        arrays[tag + ":pose"] = _np(pose)
+        loss = (pose * detgen.uniform(tuple(pose.shape), "pose:gp", -1, 1)).sum()
+        if exp:
+            for i, m in enumerate(masks):
+                for k, v in detgen.summarize(m).items():
+                    arrays["%s:mask%d:%s" % (tag, i, k)] = v
+                loss = loss + (m * detgen.uniform(tuple(m.shape), "pose:gm%d" % i, -1, 1)).sum()
+        loss.backward()
+        keys = ["conv1.0.weight", "conv7.0.weight", "pose_pred.weight", "pose_pred.bias"] + (["upconv5.0.weight", "predict_mask1.weight"] if exp else [])
+        _grad_summaries(net, arrays, keys, prefix=tag + ":grad:")
+        net.eval()
+        with torch.no_grad():
+            m1, pe = net(tgt, refs)
+        arrays[tag + ":eval_pose"] = _np(pe)
+        if exp:
+            arrays[tag + ":eval_mask1_samples"] = detgen.summarize(m1)["samples"]
+    save("posenet", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -392,6 +566,11 @@ def main():
     ref_layers = _load("ref_layers", "layers.py")
     ref_utils = _load("ref_utils", "utils.py")
     ref_kitti = _load("ref_kitti_eval", "kitti_eval/depth_evaluation_utils.py")
+    ref_res50 = _load("ref_disp_res_50", "models/Disp_res_50.py")
+    ref_pose = _load("ref_poseexpnet", "models/PoseExpNet.py")
+    ref_mono2 = _load("ref_monodepth2", "models/monodepth2.py")
+    sys.modules["layers"] = ref_layers                         # networks/depth_decoder.py does `from layers import *`
+    import networks as ref_networks                            # the reference package (sys.path[0] is the reference root)
     want = set(sys.argv[1:])
     sections = {
         "dispnets": lambda: gold_dispnets(ref_dispnets),
@@ -403,6 +582,9 @@ def main():
         "layers": lambda: gold_layers(ref_layers),
         "dorn": lambda: gold_dorn(ref_dorn, ref_utils, ref_loss),
         "kitti": lambda: gold_kitti(ref_kitti),
+        "res50": lambda: gold_res50(ref_res50, ref_loss),
+        "mono2": lambda: gold_mono2(ref_networks, ref_mono2),
+        "posenet": lambda: gold_posenet(ref_pose),
     }
     for name, fn in sections.items():
         if not want or name in want:

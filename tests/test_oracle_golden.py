@@ -266,3 +266,96 @@ def test_train_step_golden(golden):
     np.testing.assert_allclose(ls, g["losses"], rtol=2e-5)
     for key in [k[5:-6] for k in g.files if k.startswith("post:") and k.endswith(":shape")]:
         _check_summary(sd[key], g, "post:%s:" % key, stride=31, rtol=1e-3, atol=2e-5)
+
+
+# ------------------------------------------------------------------ ResNet / monodepth2-style nets / PoseExpNet (oracle/nets_res.py)
+def _fresh_sd(product_module, prefix):
+    """State dict with the reference's keys (taken from the product's parameter containers, whose layout is checked against the
+    reference's key list below) filled with the closed-form values the goldens were generated with."""
+    sd = {k: v.clone() for k, v in product_module.state_dict().items()}
+    detgen.fill_state_dict(sd, prefix)
+    return sd
+
+
+def _grad_check(sd, g, prefix="grad:", rtol=2e-4):
+    for key in sorted({k[len(prefix):].rsplit(":", 1)[0] for k in g.files if k.startswith(prefix)}):
+        if (prefix + key + ":none") in g.files:
+            assert sd[key].grad is None, key
+            continue
+        s = detgen.summarize(sd[key].grad, stride=53)
+        scale = float(np.abs(g[prefix + key + ":samples"]).max()) + 1e-30
+        np.testing.assert_allclose(s["samples"], g[prefix + key + ":samples"], rtol=rtol, atol=2e-5 * scale, err_msg=key)
+
+
+def test_disp_res_50(golden):
+    import supervised_dispnet_amd.models as models
+    from oracle import nets_res
+    g = golden("res50")
+    b, h, w = 2, 64, 96
+    sd = _params(_fresh_sd(models.Disp_res_50("nyu"), "res50"))
+    x = detgen.image_batch(b, h, w, "res50:x")
+    gt = detgen.sparse_depth(b, h, w, "res50:gt", density=0.6, lo=0.3, hi=11.0)
+    disps = nets_res.disp_res_50(sd, x, training=True, datasets="nyu")
+    depth = [1 / d for d in disps]
+    loss = losses.l1_loss(gt, depth, "nyu") + 0.1 * losses.smooth_loss(depth)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    for i, d in enumerate(disps):
+        _close(d, g["disp%d" % i], rtol=1e-4, atol=1e-5)
+    _grad_check(sd, g)
+    assert sd["bn1.weight"].grad is None                      # bn1's output is discarded by the reference (:141-145)
+    for key in ("bn1.running_mean", "bn1.running_var", "layer4.2.bn3.running_mean", "layer1.0.downsample.1.running_var"):
+        _close(sd[key], g["bn:" + key], rtol=1e-4, atol=1e-6)
+    assert int(sd["bn1.num_batches_tracked"]) == int(g["bn1.num_batches_tracked"]) == 1
+    with torch.no_grad():
+        _close(nets_res.disp_res_50(sd, x, training=False, datasets="nyu"), g["eval_disp1"], rtol=1e-4, atol=1e-5)
+
+
+def test_monodepth2_style_nets(golden):
+    import supervised_dispnet_amd.models as models
+    import supervised_dispnet_amd.networks as networks
+    from oracle import nets_res
+    g = golden("mono2")
+    x = (detgen.image_batch(2, 64, 96, "mono2:x") + 1) / 2
+    for tag, enc, which in (("vgg", networks.vggEncoder(16, False), "vgg"), ("res18", networks.ResnetEncoder(18, False), "18")):
+        net = models.monodepth2(enc, networks.DepthDecoder(enc.num_ch_enc))
+        keys = sorted(k for k in net.state_dict().keys() if ".classifier." not in k)
+        want = sorted(k for k in g[tag + ":keys"].tolist() if ".classifier." not in k)
+        assert keys == want                                    # drop-in checkpoint layout
+        sd = _params(_fresh_sd(net, "mono2:" + tag))
+        outs = nets_res.monodepth2(sd, x, which, training=True)
+        ws = [detgen.uniform(tuple(o.shape), "mono2:g%d" % i, -1, 1) for i, o in enumerate(outs)]
+        sum((o * wt).sum() for o, wt in zip(outs, ws)).backward()
+        for i, o in enumerate(outs):
+            _close(o, g["%s:disp%d" % (tag, i)], rtol=1e-4, atol=1e-5)
+        _grad_check(sd, g, prefix=tag + ":grad:")
+        with torch.no_grad():
+            _close(nets_res.monodepth2(sd, x, which, training=False), g[tag + ":eval_disp0"], rtol=1e-4, atol=1e-5)
+
+
+def test_pose_exp_net(golden):
+    import supervised_dispnet_amd.models as models
+    from oracle import nets_res
+    g = golden("posenet")
+    b, h, w = 2, 128, 416
+    tgt = detgen.image_batch(b, h, w, "pose:tgt")
+    refs = [detgen.image_batch(b, h, w, "pose:ref%d" % i) for i in range(2)]
+    for exp in (False, True):
+        tag = "exp%d" % int(exp)
+        sd = _params(_fresh_sd(models.PoseExpNet(2, exp), "posenet"))
+        masks, pose = nets_res.pose_exp_net(sd, tgt, refs, exp, training=True)
+        _close(pose, g[tag + ":pose"], rtol=1e-4, atol=1e-7)
+        loss = (pose * detgen.uniform(tuple(pose.shape), "pose:gp", -1, 1)).sum()
+        if exp:
+            for i, m in enumerate(masks):
+                _check_summary(m, g, "%s:mask%d:" % (tag, i), rtol=1e-4, atol=1e-6)
+                loss = loss + (m * detgen.uniform(tuple(m.shape), "pose:gm%d" % i, -1, 1)).sum()
+        else:
+            assert masks == [None] * 4
+        loss.backward()
+        _grad_check(sd, g, prefix=tag + ":grad:")
+        with torch.no_grad():
+            m1, pe = nets_res.pose_exp_net(sd, tgt, refs, exp, training=False)
+        _close(pe, g[tag + ":eval_pose"], rtol=1e-4, atol=1e-7)
+        if exp:
+            np.testing.assert_allclose(detgen.summarize(m1)["samples"], g[tag + ":eval_mask1_samples"], rtol=1e-4, atol=1e-6)
