@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU-box helper: per-layer bench + rocprofv3 kernel stats.  usage: bash tools/gpu_round.sh <tag>
+tag=${1:-x}
+R=$(pwd)
+mkdir -p gpurun_out
+python bench.py --steps 10 --warmup 3 --per-layer > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o $tag --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --profile-steps 0 --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1
+cd $R
+ls -R gpurun_out/prof_$tag > gpurun_out/prof_${tag}_summary.txt 2>&1 || true
