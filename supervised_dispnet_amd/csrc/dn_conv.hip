@@ -11,6 +11,7 @@
 // four MFMAs.  Accumulation is an exact fp32 FMA chain (no reduced precision anywhere).
 #include <atomic>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "dn_internal.h"
 
@@ -138,6 +139,98 @@ __device__ __forceinline__ AGroup gather4(const KOperand& S, int kl, int ntaps, 
     r.ok = true;
   }
   return r;
+}
+
+// ---- shared epilogue: bias, activation, channel-split store; optional batch-statistic partials
+// C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const IgemmParams& p, f32x16 (&acc)[WM / 32][WN / 32], const int* rowpix, float* As,
+                                              int m0, int n0) {
+  constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * WN + j * 32 + (lane & 31);
+    const bool nvalid = n < p.Ntot;
+    int seg = 0;
+    if (p.n_out > 1 && n >= p.out[1].n_begin) seg = 1;
+    if (p.n_out > 2 && n >= p.out[2].n_begin) seg = 2;
+    const KResult& R = p.out[seg];
+    float* optr = R.p + (n - R.n_begin);
+    const long long sw = R.sw;
+    const bool accumulate = R.accumulate != 0;
+    const float bias = (p.bias != nullptr && nvalid) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int pix = rowpix[row];
+        if (pix >= 0 && nvalid) {
+          float v = apply_act(acc[i][j][reg] + bias, p.act, p.act_p0, p.act_p1);
+          float* o = optr + (long long)pix * sw;
+          if (accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+  }
+
+  if (p.bn_partial != nullptr) {
+    // Per-tile batch statistics of the PRE-BIAS accumulators, in the numerically stable form (sum, M2 about the TILE mean):
+    // dn_bn_finalize merges the tiles with Chan's parallel-variance update.  E[x^2] - mean^2 on raw sums loses the variance
+    // to cancellation whenever |mean| >> std (measured on ResNet-50's 12-values-per-channel layer4).
+    float* red = As;                   // [WAVES_M][BN]
+    float* tmean = As + (BM / WM) * BN;  // [BN]
+    const int nvalid = min(BM, p.M - m0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) s1 += acc[i][j][reg];     // rows past M hold exact zeros
+      s1 += __shfl_xor(s1, 32);
+      if (lane < 32) red[wm * BN + wn * WN + j * 32 + lane] = s1;
+    }
+    __syncthreads();
+    float tot = 0.f;
+    if (tid < BN) {
+#pragma unroll
+      for (int w = 0; w < BM / WM; ++w) tot += red[w * BN + tid];
+      tmean[tid] = tot / (float)nvalid;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float mu = tmean[wn * WN + j * 32 + (lane & 31)];
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+          const float dv = acc[i][j][reg] - mu;
+          s2 += (row < nvalid) ? dv * dv : 0.f;
+        }
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32) red[wm * BN + wn * WN + j * 32 + lane] = s2;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < BM / WM; ++w) m2 += red[w * BN + tid];
+      const int n = n0 + tid;
+      if (n < p.Ntot) {
+        float* dst = p.bn_partial + ((long long)blockIdx.x * p.Ntot + n) * 2;
+        dst[0] = tot;
+        dst[1] = m2;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward family
@@ -337,90 +430,236 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_kernel(const IgemmParams p)
     __syncthreads();
   }
 
-  // ---- epilogue: bias, activation, channel-split store; optional batch-statistic partials
-  // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wn * WN + j * 32 + (lane & 31);
-    const bool nvalid = n < p.Ntot;
-    int seg = 0;
-    if (p.n_out > 1 && n >= p.out[1].n_begin) seg = 1;
-    if (p.n_out > 2 && n >= p.out[2].n_begin) seg = 2;
-    const KResult& R = p.out[seg];
-    float* optr = R.p + (n - R.n_begin);
-    const long long sw = R.sw;
-    const bool accumulate = R.accumulate != 0;
-    const float bias = (p.bias != nullptr && nvalid) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        const int pix = rowpix[row];
-        if (pix >= 0 && nvalid) {
-          float v = apply_act(acc[i][j][reg] + bias, p.act, p.act_p0, p.act_p1);
-          float* o = optr + (long long)pix * sw;
-          if (accumulate) v += *o;
-          *o = v;
-        }
-      }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------- forward family, uniform fast path
+// uni32 plans (every operand: C % 32 == 0, float4-addressable, no upsample, < 2 GiB; <= 32 taps; zero padding): a K chunk
+// never straddles a tap or an operand, so (operand, tap, channel base) are BLOCK-UNIFORM per chunk and live on the scalar
+// unit.  Per chunk and row the vector side is left with: one add + one select for the address, one bit test of a
+// precomputed per-row tap-validity mask, the load, and the deferred BatchNorm-apply + ReLU of the producer.
+//
+// The main loop is hand-scheduled: the iteration is cut into one "slot" per MFMA (64 cycles of matrix pipe each) and the
+// staging work of the NEXT chunk is dealt into the slots in source order -- global loads + address arithmetic under the
+// first MFMAs, the fragment reads of the next K group two slots before they are needed, the LDS store stage under the last
+// MFMAs -- with a sched_barrier after every slot so hipcc keeps that order (left alone it clusters the MFMAs and runs
+// the staging before/after them, i.e. nothing overlaps within a wave).
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParams p) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                                        // [2][BM][LDK]
+  float* Bs = smem + 2 * BM * LDK;                         // [2][BN][LDK]
+  int* taps = reinterpret_cast<int*>(Bs + 2 * BN * LDK);   // [32]  (dy | dx<<16)
+  int* rowpix = taps + 32;                                 // [BM] output pixel index or -1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const KPhase ph = p.ph[blockIdx.z];
+  const int ntaps = ph.ntaps;
+  const int Kp = ph.nchunks * kChunk;
+
+  if (tid < 32) taps[tid] = tid < ntaps ? (((int)p.tdy[ph.tap0 + tid] & 0xffff) | ((int)p.tdx[ph.tap0 + tid] << 16)) : 0;
+  for (int r = tid; r < BM; r += 256) {
+    int m = m0 + r, pix = -1;
+    if (m < p.M) {
+      unsigned gx, gy;
+      const unsigned t = fastdiv((unsigned)m, (unsigned)p.GW, p.mGW, &gx);
+      const int n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+      int oy = (int)gy * p.osy + ph.ooy, ox = (int)gx * p.osx + ph.oox;
+      if (oy < p.OH && ox < p.OW) pix = (n * p.OH + oy) * p.OW + ox;
     }
+    rowpix[r] = pix;
+  }
+  __syncthreads();
+
+  // per-thread staging assignment: K group g (4 floats) of rows r0 + 32*i; per row a bit mask of the taps that land inside
+  const int g = tid & 7, r0 = tid >> 3;
+  int rn[AR], rby[AR], rbx[AR];
+  unsigned vmask[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    const bool live = m < p.M;
+    unsigned gx, gy;
+    const unsigned t = fastdiv(live ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+    rn[i] = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+    rby[i] = (int)gy * p.sy;
+    rbx[i] = (int)gx * p.sx;
+    vmask[i] = live ? 0xffffffffu : 0u;
+  }
+  {
+    unsigned inside[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) inside[i] = 0u;
+    for (int j = 0; j < ntaps; ++j) {
+      const int tp = taps[j];
+      const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        inside[i] |= ((unsigned)(rby[i] + dy) < (unsigned)p.IH && (unsigned)(rbx[i] + dx) < (unsigned)p.IW) ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) vmask[i] &= inside[i];
   }
 
-  if (p.bn_partial != nullptr) {
-    // Per-tile batch statistics of the PRE-BIAS accumulators, in the numerically stable form (sum, M2 about the TILE mean):
-    // dn_bn_finalize merges the tiles with Chan's parallel-variance update.  E[x^2] - mean^2 on raw sums loses the variance
-    // to cancellation whenever |mean| >> std (measured on ResNet-50's 12-values-per-channel layer4).
-    float* red = As;                   // [WAVES_M][BN]
-    float* tmean = As + (BM / WM) * BN;  // [BN]
-    const int nvalid = min(BM, p.M - m0);
-    __syncthreads();
+  f32x16 acc[MI][NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      float s1 = 0.f;
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) s1 += acc[i][j][reg];     // rows past M hold exact zeros
-      s1 += __shfl_xor(s1, 32);
-      if (lane < 32) red[wm * BN + wn * WN + j * 32 + lane] = s1;
-    }
-    __syncthreads();
-    float tot = 0.f;
-    if (tid < BN) {
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const char* wrow = reinterpret_cast<const char*>(p.w + ph.w_off);   // advanced by one chunk (128 B) per iteration
+  unsigned boffB[BR];
 #pragma unroll
-      for (int w = 0; w < BM / WM; ++w) tot += red[w * BN + tid];
-      tmean[tid] = tot / (float)nvalid;
-    }
-    __syncthreads();
+  for (int i = 0; i < BR; ++i) boffB[i] = (unsigned)(((n0 + r0 + 32 * i) * Kp + g * 4) * 4);
+  const int stA = (r0 * LDK + g * 4) * 4;                                                  // staging store offset (bytes)
+  const int frA = ((wm * WM + (lane & 31)) * LDK + (lane >> 5) * 4) * 4;                    // fragment read offsets (bytes)
+  const int frB = ((wn * WN + (lane & 31)) * LDK + (lane >> 5) * 4) * 4;
+  char* AsB = reinterpret_cast<char*>(As);
+  char* BsB = reinterpret_cast<char*>(Bs);
+  constexpr int ABUF = BM * LDK * 4, BBUF = BN * LDK * 4;
+  constexpr int ROWS32 = 32 * LDK * 4;                       // byte distance of 32 tile rows
+
+  // slot schedule (compile-time)
+  constexpr int NM = 16 * MI * NI;                 // MFMAs per chunk
+  constexpr int PK = NM / 4;                       // MFMAs per K group of 8
+  constexpr int NF = MI + NI;                      // fragment reads per K group
+  constexpr int F0 = (PK - NF - 2) > 0 ? (PK - NF - 2) : 0;   // first slot (within a K group) of the next group's reads
+  constexpr int NS = AR + BR;                      // store-stage items
+  constexpr int SSTEP = (NM >= 4 * NS) ? 2 : 1;    // slots between store-stage items
+  constexpr int S0 = NM - SSTEP * NS;              // slot of the first store-stage item
+
+  int buf = 0;
+  for (int s = 0; s < p.n_in; ++s) {
+    const KOperand& S = p.in[s];
+    auto run_operand = [&](auto aff_tag) {
+      constexpr bool HA = decltype(aff_tag)::value;
+      // ---- operand set-up (block-uniform scalars + per-row base offsets)
+      const char* base = reinterpret_cast<const char*>(S.p);
+      const char* scp = reinterpret_cast<const char*>(S.scale);
+      const char* shp = reinterpret_cast<const char*>(S.shift);
+      const int sh = (int)S.sh, sw = (int)S.sw;
+      const int cpt = S.C >> 5;                       // chunks per tap
+      const int nch = ntaps * cpt;
+      unsigned rowoffB[AR];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const float mu = tmean[wn * WN + j * 32 + (lane & 31)];
-      float s2 = 0.f;
+      for (int i = 0; i < AR; ++i) rowoffB[i] = (unsigned)((rn[i] * (int)S.sn + rby[i] * sh + rbx[i] * sw + g * 4) * 4);
+
+      f32x4 av[AR], bv[BR], sc4, sh4;
+      bool aok[AR];
+      // cursor = the chunk whose loads are issued next: index cn = (tap j, chunk-in-tap cc); its tap word is fetched from LDS
+      // one iteration ahead and kept in a VGPR until decoded, so the scalar unit never waits inside the MFMA stream
+      int cn = 0, j = 0, cc = 0;
+      int tapv = taps[0];
+      unsigned soffB = 0, jbit = 0, coffB = 0;
+      const char* wcur = wrow;
+
+      auto cursor_decode = [&]() {
+        const int tapword = __builtin_amdgcn_readfirstlane(tapv);
+        const int dy = (int)(short)(tapword & 0xffff), dx = tapword >> 16;
+        soffB = (unsigned)((dy * sh + dx * sw + cc * 32) * 4);
+        jbit = 1u << j;
+        coffB = (unsigned)((cc * 32 + g * 4) * 4);
+        wcur = wrow;
+      };
+      auto cursor_advance = [&]() {      // clamps at the last chunk (the final iteration re-fetches it into the idle buffer: no branch)
+        const bool more = cn + 1 < nch;
+        const int cc1 = cc + 1;
+        const bool wrap = cc1 == cpt;
+        cn += more ? 1 : 0;
+        cc = more ? (wrap ? 0 : cc1) : cc;
+        j = (more && wrap) ? j + 1 : j;
+        wrow += more ? kChunk * 4 : 0;
+        tapv = taps[j];
+      };
+      auto load_a = [&](int i) {
+        aok[i] = (vmask[i] & jbit) != 0u;
+        const unsigned off = aok[i] ? rowoffB[i] + soffB : 0u;
+        av[i] = *reinterpret_cast<const f32x4*>(base + off);
+      };
+      auto load_aff = [&]() {
+        sc4 = *reinterpret_cast<const f32x4*>(scp + coffB);
+        sh4 = *reinterpret_cast<const f32x4*>(shp + coffB);
+      };
+      auto load_b = [&](int i) { bv[i] = *reinterpret_cast<const f32x4*>(wcur + boffB[i]); };
+      auto store_a = [&](int b, int i) {
+        f32x4 v = av[i];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-          const float dv = acc[i][j][reg] - mu;
-          s2 += (row < nvalid) ? dv * dv : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          float t = v[e];
+          if constexpr (HA) t = fmaxf(0.f, fmaf(t, sc4[e], sh4[e]));
+          v[e] = aok[i] ? t : 0.f;
         }
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32) red[wm * BN + wn * WN + j * 32 + lane] = s2;
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float m2 = 0.f;
+        *reinterpret_cast<f32x4*>(AsB + b * ABUF + stA + i * ROWS32) = v;
+      };
+      auto store_b = [&](int b, int i) { *reinterpret_cast<f32x4*>(BsB + b * BBUF + stA + i * ROWS32) = bv[i]; };
+
+      // pipeline fill for this operand (one exposed memory latency per operand)
+      cursor_decode();
 #pragma unroll
-      for (int w = 0; w < BM / WM; ++w) m2 += red[w * BN + tid];
-      const int n = n0 + tid;
-      if (n < p.Ntot) {
-        float* dst = p.bn_partial + ((long long)blockIdx.x * p.Ntot + n) * 2;
-        dst[0] = tot;
-        dst[1] = m2;
+      for (int i = 0; i < AR; ++i) load_a(i);
+      if constexpr (HA) load_aff();
+#pragma unroll
+      for (int i = 0; i < BR; ++i) load_b(i);
+#pragma unroll
+      for (int i = 0; i < AR; ++i) store_a(buf, i);
+#pragma unroll
+      for (int i = 0; i < BR; ++i) store_b(buf, i);
+      cursor_advance();
+      __syncthreads();
+
+      for (int c = 0; c < nch; ++c) {
+        cursor_decode();                       // chunk min(c+1, nch-1); uses the tap word fetched during the previous iteration
+
+        const char* Ab = AsB + buf * ABUF + frA;
+        const char* Bb = BsB + buf * BBUF + frB;
+        f32x4 fa[2][MI], fb[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * ROWS32);
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) fb[0][jn] = *reinterpret_cast<const f32x4*>(Bb + jn * ROWS32);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const int kg = m / PK, q = m % PK;
+          const int kk = q / (MI * NI), ij = q % (MI * NI);
+          const int i = ij / NI, jn = ij % NI;
+          const int cur = kg & 1, nxt = cur ^ 1;
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][kk], fb[cur][jn][kk], acc[i][jn], 0, 0, 0);
+          // ---- side work of this slot
+          if (m < AR) load_a(m);
+          if (HA && m == AR) load_aff();
+          if (m >= AR + (HA ? 1 : 0) && m < AR + (HA ? 1 : 0) + BR) load_b(m - AR - (HA ? 1 : 0));
+          if (kg < 3 && q >= F0 && q < F0 + NF) {
+            const int f = q - F0;
+            if (f < MI) fa[nxt][f] = *reinterpret_cast<const f32x4*>(Ab + f * ROWS32 + (kg + 1) * 32);
+            else fb[nxt][f - MI] = *reinterpret_cast<const f32x4*>(Bb + (f - MI) * ROWS32 + (kg + 1) * 32);
+          }
+          if (m == (PK + 1 > AR + 1 + BR ? PK + 1 : AR + 1 + BR)) cursor_advance();   // after this chunk's loads are issued
+          if (m >= S0 && (m - S0) % SSTEP == 0) {
+            const int it = (m - S0) / SSTEP;
+            if (it < AR) store_a(buf ^ 1, it);
+            else if (it < NS) store_b(buf ^ 1, it - AR);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        buf ^= 1;
       }
-    }
+      wrow += kChunk * 4;        // the cursor stopped on this operand's last chunk; the next operand's weights follow it
+    };
+    if (ntaps == 0) continue;       // empty phase of a strided scatter (e.g. 1x1 stride 2): the result is bias/activation only
+    if (S.scale != nullptr) run_operand(std::true_type{});
+    else run_operand(std::false_type{});
   }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
 }
 
 // ----------------------------------------------------------------------------------------------- weight gradient
@@ -723,7 +962,20 @@ static int launch_conv_v(const IgemmParams& p, hipStream_t stream) {
 }
 
 template <int BM, int BN, int WM, int WN>
+static int launch_conv_u32(const IgemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (32 + BM) * sizeof(int);
+  auto kernel = igemm_conv_u32_kernel<BM, BN, WM, WN>;
+  int rc = enable_big_lds(kernel, lds);
+  if (rc != DN_OK) return rc;
+  dim3 grid((p.M + BM - 1) / BM, p.Npad / BN, p.nphases);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  return check_launch("igemm_conv_u32_kernel");
+}
+
+template <int BM, int BN, int WM, int WN>
 static int launch_conv(const IgemmParams& p, hipStream_t stream) {
+  if (p.uni32 && !getenv("DN_NO_U32"))
+    return launch_conv_u32<BM, BN, WM, WN>(p, stream);
   return p.allvec ? launch_conv_v<BM, BN, WM, WN, true>(p, stream) : launch_conv_v<BM, BN, WM, WN, false>(p, stream);
 }
 

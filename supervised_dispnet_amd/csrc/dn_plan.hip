@@ -246,7 +246,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     p->in[i].small = offsets_fit_int32(p->in[i], p->N, p->IH, p->IW) ? 1 : 0;
     if (!(p->in[i].vec && p->in[i].small)) p->allvec = 0;
   }
-  if (!p->allvec) p->uni32 = 0;
+  if (!p->allvec || p->reflect) p->uni32 = 0;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;
