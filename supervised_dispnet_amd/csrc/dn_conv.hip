@@ -888,6 +888,212 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const IgemmParams p
   }
 }
 
+// ------------------------------------------------------------------------------- weight gradient, uniform fast path
+// uni32 plans: each of the 4 K chunks of this block's k tile sits in ONE (operand, tap, channel base) -- block-uniform and
+// loop-invariant (the loop runs over pixels), so it lives in SGPRs.  Hand-scheduled like igemm_conv_u32_kernel: the next
+// 32-pixel step's loads and address arithmetic are dealt under the first MFMAs of the current step, the LDS fragment reads
+// one K pair ahead of their MFMAs, the store stage under the last MFMAs.
+template <int BNW, int WNn, int WKk, bool AFF>
+__global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmParams p) {
+  constexpr int BKW = 128;
+  constexpr int WAVES_K = BKW / WKk;
+  constexpr int NI = WNn / 32, KI = WKk / 32;
+  constexpr int GR = BNW / 32;  // float4 groups per thread for the G tile
+  static_assert((BNW / WNn) * WAVES_K == 4, "4 waves per block");
+  extern __shared__ __align__(16) float smem[];
+  float* Gs = smem;                                        // [2][32][BNW]
+  float* Xs = smem + 2 * 32 * BNW;                         // [2][32][BKW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WAVES_K, wk = wave % WAVES_K;
+  const int kt = blockIdx.x, n0 = blockIdx.y * BNW;
+  const KPhase ph = p.ph[0];
+  const int ntaps = ph.ntaps, nchunks = ph.nchunks, Kp = nchunks * kChunk;
+  const int m_begin = blockIdx.z * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int g = tid & 7, r = tid >> 3;  // staging: row r of the 32-pixel step, 4-float group g
+
+  // block-uniform descriptors of the 4 K chunks
+  const char* qbase[4];
+  int qsn[4], qsh[4], qsw[4], qdy[4], qdx[4], qtapB[4];
+  unsigned qc0B[4];
+  bool qlive[4];
+  f32x4 xsc[4], xsh[4];
+  float qfloor[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int kc = kt * 4 + q;
+    int kcl = 0;
+    const int s = kc < nchunks ? select_operand(p, ntaps, kc, &kcl) : 0;
+    const KOperand& S = p.in[s];
+    unsigned c0;
+    const int j = (int)fastdiv((unsigned)(kcl * kChunk), (unsigned)S.C, S.mC, &c0);
+    qlive[q] = kc < nchunks && j < ntaps;
+    const int jj = qlive[q] ? j : 0;
+    qbase[q] = reinterpret_cast<const char*>(S.p);
+    qsn[q] = __builtin_amdgcn_readfirstlane((int)S.sn);
+    qsh[q] = __builtin_amdgcn_readfirstlane((int)S.sh);
+    qsw[q] = __builtin_amdgcn_readfirstlane((int)S.sw);
+    qdy[q] = __builtin_amdgcn_readfirstlane((int)p.tdy[jj]);
+    qdx[q] = __builtin_amdgcn_readfirstlane((int)p.tdx[jj]);
+    qtapB[q] = (qdy[q] * qsh[q] + qdx[q] * qsw[q] + (int)c0) * 4;       // scalar part of the gather offset (bytes)
+    qc0B[q] = (unsigned)((c0 + g * 4) * 4);
+    if constexpr (AFF) {
+      const bool has_aff = S.scale != nullptr;
+      const f32x4 l1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.scale : S.p) + qc0B[q]);
+      const f32x4 l2 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.shift : S.p) + qc0B[q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xsc[q][e] = has_aff ? l1[e] : 1.f;
+        xsh[q][e] = has_aff ? l2[e] : 0.f;
+      }
+      qfloor[q] = has_aff ? 0.f : -__builtin_huge_valf();
+    }
+  }
+
+  f32x16 acc[NI][KI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < KI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const char* gbase = reinterpret_cast<const char*>(p.g);
+  const bool gcol_ok[1] = {true};
+  (void)gcol_ok;
+  f32x4 gv[GR], xv[4];
+  bool xok[4], rowvalid = false;
+  int pn = 0, pby = 0, pbx = 0;
+  unsigned goffB = 0;
+
+  auto decode_pixel = [&](int mbase) {
+    const int m = mbase + r;
+    rowvalid = m < m_end;
+    const unsigned mm = rowvalid ? (unsigned)m : 0u;
+    unsigned gx, gy;
+    const unsigned t = fastdiv(mm, (unsigned)p.GW, p.mGW, &gx);
+    pn = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+    pby = (int)gy * p.sy;
+    pbx = (int)gx * p.sx;
+    goffB = (mm * (unsigned)p.Ntot + (unsigned)(n0 + g * 4)) * 4u;
+  };
+  auto load_g = [&](int i) {
+    // columns past Ntot only exist in the last n tile of a padded Ntot: clamp the address, zero at the store stage
+    const bool ok = (n0 + g * 4 + 32 * i) < p.Ntot;
+    gv[i] = *reinterpret_cast<const f32x4*>(gbase + (ok ? goffB + 128u * i : 0u));
+  };
+  auto load_x = [&](int q) {
+    const int iy = pby + qdy[q], ix = pbx + qdx[q];
+    xok[q] = (int)rowvalid & (int)qlive[q] & (int)((unsigned)iy < (unsigned)p.IH) & (int)((unsigned)ix < (unsigned)p.IW);
+    unsigned off = (unsigned)((pn * qsn[q] + pby * qsh[q] + pbx * qsw[q] + g * 4) * 4 + qtapB[q]);
+    asm volatile("" : "+v"(off));            // keep the address arithmetic unconditional (no exec-masked region, no branch)
+    off = xok[q] ? off : 0u;
+    xv[q] = *reinterpret_cast<const f32x4*>(qbase[q] + off);
+  };
+  char* GsB = reinterpret_cast<char*>(Gs);
+  char* XsB = reinterpret_cast<char*>(Xs);
+  constexpr int GBUF = 32 * BNW * 4, XBUF = 32 * BKW * 4;
+  const int stG = (r * BNW + g * 4) * 4, stX = (r * BKW + g * 4) * 4;
+  bool rowvalid_st = false;      // validity of the row whose data sits in gv/xv (snapshotted at load time)
+  auto store_g = [&](int b, int i) {
+    f32x4 v = gv[i];
+    const bool ok = (int)rowvalid_st & (int)((n0 + g * 4 + 32 * i) < p.Ntot);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+    *reinterpret_cast<f32x4*>(GsB + b * GBUF + stG + i * 128) = v;
+  };
+  auto store_x = [&](int b, int q) {
+    f32x4 v = xv[q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[e];
+      if constexpr (AFF) t = fmaxf(qfloor[q], fmaf(t, xsc[q][e], xsh[q][e]));
+      v[e] = xok[q] ? t : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(XsB + b * XBUF + stX + q * 128) = v;
+  };
+
+  constexpr int NM = 16 * NI * KI;                 // MFMAs per 32-pixel step
+  constexpr int PS = NI * KI;                      // MFMAs per pixel pair
+  constexpr int NS = GR + 4;                       // store-stage items
+  constexpr int SSTEP = (NM >= 4 * NS) ? 2 : 1;
+  constexpr int S0 = NM - SSTEP * NS;
+
+  const int nsteps = (m_end > m_begin) ? (m_end - m_begin + 31) / 32 : 0;
+  if (nsteps > 0) {
+    decode_pixel(m_begin);
+    rowvalid_st = rowvalid;
+#pragma unroll
+    for (int i = 0; i < GR; ++i) load_g(i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_x(q);
+#pragma unroll
+    for (int i = 0; i < GR; ++i) store_g(0, i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_x(0, q);
+  }
+  __syncthreads();
+  const int frG = ((lane >> 5) * BNW + wn * WNn + (lane & 31)) * 4;
+  const int frX = ((lane >> 5) * BKW + wk * WKk + (lane & 31)) * 4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    const int mnext = m_begin + (st + 1 < nsteps ? st + 1 : st) * 32;   // last step re-fetches itself into the idle buffer
+    const char* Gb = GsB + buf * GBUF + frG;
+    const char* Xb = XsB + buf * XBUF + frX;
+    float fa[2][NI], fb[2][KI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fa[0][i] = *reinterpret_cast<const float*>(Gb + i * 128);
+#pragma unroll
+    for (int j = 0; j < KI; ++j) fb[0][j] = *reinterpret_cast<const float*>(Xb + j * 128);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int s2 = m / PS, ij = m % PS;
+      const int i = ij / KI, j = ij % KI;
+      const int cur = s2 & 1, nxt = cur ^ 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      // ---- side work of this slot
+      if (m == 0) { decode_pixel(mnext); }
+      if (m >= 1 && m < 1 + GR) load_g(m - 1);
+      if (m >= 1 + GR && m < 5 + GR) load_x(m - 1 - GR);
+      if (s2 < 15) {     // fragments of the next pixel pair, spread over this pair's slots
+        if (PS >= NI + KI) {
+          if (ij < NI) fa[nxt][ij] = *reinterpret_cast<const float*>(Gb + (s2 + 1) * 2 * BNW * 4 + ij * 128);
+          else if (ij < NI + KI) fb[nxt][ij - NI] = *reinterpret_cast<const float*>(Xb + (s2 + 1) * 2 * BKW * 4 + (ij - NI) * 128);
+        } else if (ij == 0) {
+#pragma unroll
+          for (int a = 0; a < NI; ++a) fa[nxt][a] = *reinterpret_cast<const float*>(Gb + (s2 + 1) * 2 * BNW * 4 + a * 128);
+#pragma unroll
+          for (int b = 0; b < KI; ++b) fb[nxt][b] = *reinterpret_cast<const float*>(Xb + (s2 + 1) * 2 * BKW * 4 + b * 128);
+        }
+      }
+      if (m >= S0 && (m - S0) % SSTEP == 0) {
+        const int it = (m - S0) / SSTEP;
+        if (it == 0) rowvalid_st = rowvalid;
+        if (it < GR) store_g(buf ^ 1, it);
+        else if (it < NS) store_x(buf ^ 1, it - GR);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  float* ws = p.ws + (long long)blockIdx.z * p.Npad * Kp;
+#pragma unroll
+  for (int j = 0; j < KI; ++j) {
+    const int k = kt * BKW + wk * WKk + j * 32 + (lane & 31);
+    if (k >= Kp) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = n0 + wn * WNn + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        ws[(long long)n * Kp + k] = acc[i][j][reg];
+      }
+  }
+}
+
 // packed (n, k) -> framework weight index, or -1 for a padding slot
 __device__ __forceinline__ long long packed_to_framework(const IgemmParams& p, const KPhase& ph, int n, int k) {
   if (n >= p.Ntot) return -1;
@@ -1010,19 +1216,48 @@ static int launch_wgrad_v(const IgemmParams& p, hipStream_t stream) {
   return check_launch("igemm_wgrad_kernel");
 }
 
+template <int BNW, int WNn, int WKk, bool AFF>
+static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)(2 * 32 * BNW + 2 * 32 * 128) * sizeof(float);
+  auto kernel = igemm_wgrad_u32_kernel<BNW, WNn, WKk, AFF>;
+  int rc = enable_big_lds(kernel, lds);
+  if (rc != DN_OK) return rc;
+  dim3 grid((p.ph[0].nchunks + 3) / 4, p.Npad / BNW, p.splits);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  return check_launch("igemm_wgrad_u32_kernel");
+}
+
 template <int BNW, int WNn, int WKk>
 static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
+  if (p.uni32 && p.allvec && !getenv("DN_NO_U32"))
+    return p.any_affine ? launch_wgrad_u32<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_u32<BNW, WNn, WKk, false>(p, stream);
   return p.allvec ? launch_wgrad_v<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_v<BNW, WNn, WKk, false>(p, stream);
 }
 
+// Pixel splits of the weight gradient.  Every block does the same amount of work and the chip holds `slots` blocks at once
+// (256 CUs x blocks per CU, LDS-limited), so the launch should fill a whole number of rounds from below: tiles * splits just
+// under R * slots (1026 blocks on 1024 slots run as THREE rounds, measured 103 vs 135 TFLOP/s).  Fewest rounds that reach
+// 92 % slot use wins (fewer splits = fewer partial slabs for wgrad_reduce_kernel).
 static void choose_splits(IgemmParams* p) {
   const int tiles = ((p->ph[0].nchunks + 3) / 4) * (p->Npad / p->BN);
-  int want = (1024 + tiles - 1) / tiles;
+  const int per_cu = p->BN >= 128 ? 2 : (p->BN >= 64 ? 3 : 4);
+  const int slots = 256 * per_cu;
   int max_by_work = (p->M + 255) / 256;  // at least 8 steps of 32 pixels per split
-  int splits = want < 1 ? 1 : want;
-  if (splits > max_by_work) splits = max_by_work;
-  if (splits < 1) splits = 1;
-  int per = (p->M + splits - 1) / splits;
+  if (max_by_work < 1) max_by_work = 1;
+  int best = 1;
+  double best_util = 0.0;
+  for (int R = 1; R <= 4; ++R) {
+    int sp = (R * slots) / tiles;
+    if (sp < 1) continue;
+    if (sp > max_by_work) sp = max_by_work;
+    const double util = (double)tiles * sp / ((double)((tiles * sp + slots - 1) / slots) * slots);
+    if (util > best_util + 1e-9) {
+      best_util = util;
+      best = sp;
+    }
+    if (util >= 0.92) break;
+  }
+  int per = (p->M + best - 1) / best;
   per = (per + 31) / 32 * 32;
   p->m_per_split = per;
   p->splits = (p->M + per - 1) / per;
@@ -1093,9 +1328,12 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     o.mC = fastdiv_magic((unsigned)co);
     o.small = ((long long)fwd->N * o.sn < (1ll << 31)) ? 1 : 0;
     p.allvec = (o.vec && o.small) ? 1 : 0;
+    p.any_affine = 0;
+    p.uni32 = (p.allvec && co % 32 == 0 && p.ph[0].ntaps <= 32 && (long long)fwd->N * o.sn * 4 + 64 < (1ll << 31)) ? 1 : 0;
   }
   // the G operand must be float4-addressable with int32 offsets too
   if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0 && (long long)p.M * p.Ntot < (1ll << 31))) p.allvec = 0;
+  if (!p.allvec || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.uni32 = 0;
   hipStream_t s = as_stream(stream);
   switch (p.BN) {
     case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;
