@@ -63,3 +63,22 @@ class GradReducer(object):
             h.wait()
         self.reset()
         return 1.0 / self.world
+
+
+def shard_slice(global_batch, rank, world):
+    """Contiguous per-rank slice of a global batch, in rank order -- the split nn.DataParallel.scatter makes
+    (train.py:316); the global batch must divide evenly so every rank steps the same shapes."""
+    if global_batch % world != 0:
+        raise ValueError("global batch %d does not divide over %d ranks" % (global_batch, world))
+    per = global_batch // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def global_masked_mean(local_sum, local_count, process_group=None):
+    """sum / count over ALL ranks.  The Multiscale_* losses and DORN_loss normalise by the valid-pixel count of the whole
+    batch (loss_functions.py:232-237, 72-73), which the reference's DataParallel sees gathered on GPU0; under one process
+    per GPU the (sum, count) pairs are exchanged (one tiny all-reduce) before the division so the value is identical."""
+    pair = torch.stack([local_sum.reshape(-1), local_count.reshape(-1).to(local_sum.dtype)])
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=process_group)
+    return pair[0] / pair[1]

@@ -1,0 +1,131 @@
+"""World-size-2 data-parallel tests on CPU (gloo): the arena / bucketed gradient exchange that bench.py and train.py run over
+RCCL on the GPUs.  Device-agnostic plumbing only -- no HIP kernel is involved, nothing here touches
+the oracle."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(16, 17, 3, 3), (16,), (1, 16, 3, 3), (1,), (32, 16, 4, 4), (16,), (64, 3, 3, 3), (64,), (64,), (64,), (7,)]
+    return [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+
+
+def _worker_reduce(rank, world, port, bucket_bytes, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from supervised_dispnet_amd.distributed import GradReducer, shard_slice
+        from supervised_dispnet_amd.optim import ParamArena
+        params = _make_params()
+        order = list(reversed(params))                       # gradients are produced last-layer-first
+        arena = ParamArena(params, production_order=order)
+        assert [id(p) for p in arena.params] == [id(p) for p in order]
+        red = GradReducer(arena, bucket_bytes=bucket_bytes)
+        # buckets tile the arena contiguously, in production order
+        assert red.buckets[0]["lo"] == 0 and red.buckets[-1]["hi"] == arena.numel
+        for a, b in zip(red.buckets[:-1], red.buckets[1:]):
+            assert a["hi"] == b["lo"]
+        for step in range(2):                                # two steps: the reducer must re-arm itself
+            for i, p in enumerate(arena.params):
+                p._dn_grad_view.fill_(float((rank + 1) * (i + 1) + step))
+                if i != 3:                                   # one parameter never reports (e.g. no gradient this step)
+                    red.grad_ready(p)
+            scale = red.finish()
+            assert scale == 1.0 / world
+            for i, p in enumerate(arena.params):
+                want = sum((r + 1) * (i + 1) + step for r in range(world))
+                assert torch.all(p._dn_grad_view == want), (step, i)
+            # padding slots between 16-byte aligned slices stay zero
+            used = torch.zeros(arena.numel, dtype=torch.bool)
+            for p, o in zip(arena.params, arena.offsets):
+                used[o:o + p.numel()] = True
+            assert torch.all(arena.flat_g[~used] == 0)
+        # the batch shards exactly like DataParallel.scatter: contiguous slices in rank order
+        sl = shard_slice(32, rank, world)
+        assert (sl.start, sl.stop) == (rank * 16, rank * 16 + 16)
+        out.put((rank, "ok"))
+    except Exception as e:      # surface the failure in the parent
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 10, 1 << 30])
+def test_bucketed_gradient_allreduce_world2(bucket_bytes):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_reduce, args=(r, 2, port, bucket_bytes, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _worker_loss_counts(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from supervised_dispnet_amd.distributed import global_masked_mean
+        # whole-batch masked means (Multiscale_* / DORN normalise by the GLOBAL valid count, loss_functions.py:232-237,72-73):
+        # rank-local (sum, count) pairs are exchanged before the division
+        local_sum = torch.tensor([3.0 if rank == 0 else 10.0])
+        local_cnt = torch.tensor([2.0 if rank == 0 else 6.0])
+        m = global_masked_mean(local_sum, local_cnt)
+        assert torch.allclose(m, torch.tensor([13.0 / 8.0]))
+        out.put((rank, "ok"))
+    except Exception as e:
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_masked_mean_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_loss_counts, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_single_process_reducer_is_a_no_op():
+    from supervised_dispnet_amd.distributed import GradReducer, shard_slice
+    from supervised_dispnet_amd.optim import ParamArena
+    arena = ParamArena(_make_params())
+    red = GradReducer(arena)
+    for p in arena.params:
+        p._dn_grad_view.fill_(2.0)
+        red.grad_ready(p)
+    assert red.finish() == 1.0
+    assert torch.all(arena.params[0]._dn_grad_view == 2.0)
+    assert shard_slice(32, 0, 1) == slice(0, 32)
+    with pytest.raises(ValueError):
+        shard_slice(30, 0, 4)
