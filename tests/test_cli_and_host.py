@@ -1,0 +1,167 @@
+"""Host-side logic of the drop-in command lines (train.py / test_disp.py) and the KITTI ground-truth generation:
+flag surface of the reference (train.py:30-91, test_disp.py:23-49), the product's vectorised
+duplicate-min scatter against the oracle's restatement of the reference loop and against the golden vectors, the
+scene-folder readers.  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TRAIN_DEFAULTS = {
+    "network": "disp_vgg", "dataset": "kitti", "imagenet_normalization": False, "pretrained_encoder": False, "loss": "Multi_L1",
+    "ordinal_c": 80, "diff_lr": False, "sgd": False, "record": False, "unsupervised": False, "data_amount": 1, "monodepth2": False,
+    "dataset_format": "sequential", "sequence_length": 3, "rotation_mode": "euler", "padding_mode": "zeros", "with_gt": False,
+    "workers": 4, "epochs": 200, "epoch_size": 0, "batch_size": 4, "lr": 1e-4, "momentum": 0.9, "beta": 0.999, "weight_decay": 0,
+    "print_freq": 10, "evaluate": False, "pretrained_disp": None, "pretrained_exp_pose": None, "seed": 0,
+    "log_summary": "progress_log_summary.csv", "log_full": "progress_log_full.csv", "photo_loss_weight": 1, "mask_loss_weight": 0,
+    "smooth_loss_weight": 0, "log_output": False, "training_output_freq": 0,
+}
+TEST_DEFAULTS = {
+    "imagenet_normalization": False, "ordinal_c": 80, "unsupervised": False, "monodepth2": False, "pic": False, "error": False,
+    "stereo": False, "mono": False, "pretrained_posenet": None, "img_height": 128, "img_width": 416, "no_resize": False,
+    "dataset_dir": ".", "dataset_list": None, "output_dir": None, "gt_type": "KITTI", "img_exts": ["png", "jpg", "bmp"],
+}
+
+
+def test_train_cli_surface_matches_reference():
+    import train
+    p = train.build_parser()
+    a = p.parse_args(["DATA"])
+    for k, v in TRAIN_DEFAULTS.items():
+        assert getattr(a, k) == v, k
+    a = p.parse_args("DATA -b32 -m0.0 -s0.0 --loss L1 --network disp_vgg_BN --with-gt --wd 1e-5 --learning-rate 3e-4 -e "
+                     "--pretrained-disp X --pretrained-exppose Y -p 2 -f 5 -j 9".split())
+    assert (a.batch_size, a.loss, a.network, a.with_gt, a.weight_decay, a.lr, a.evaluate) == (32, "L1", "disp_vgg_BN", True, 1e-5, 3e-4, True)
+    assert (a.pretrained_disp, a.pretrained_exp_pose, a.photo_loss_weight, a.training_output_freq, a.workers) == ("X", "Y", 2.0, 5, 9)
+    assert set(train.NETWORKS) == {"dispnet", "disp_res", "disp_res_50", "disp_res_18", "disp_vgg", "disp_vgg_BN", "FCRN", "res50_aspp",
+                                   "ASPP", "disp_res_101", "DORN", "disp_vgg_BN_DORN"}
+    assert set(train.LOSSES) == {"Multi_L1", "Multi_full_L1", "Multi_berhu", "Multi_L2", "L1", "berhu", "L2", "scale_inv",
+                                 "Multi_scale_inv", "DORN"}
+    # README recipe -> folder name built from the non-default keys, in the reference's order (utils.py:11-43)
+    name = train.save_path_formatter(a, p)
+    assert name.split(os.sep)[0] == "DATA,b32,lr0.0003,p2.0,networkdisp_vgg_BN,lossL1"
+
+
+def test_train_rejects_unknown_selectors():
+    import train
+    a = train.build_parser().parse_args(["DATA", "--loss", "nope"])
+    with pytest.raises(ValueError):
+        train.supervised_loss(a, None, None, None)
+    a = train.build_parser().parse_args(["DATA", "--network", "nope"])
+    with pytest.raises(ValueError):
+        train.create_disp_net(a, None, None, "cpu")
+
+
+def test_test_disp_cli_surface_matches_reference():
+    import test_disp
+    p = test_disp.build_parser()
+    with pytest.raises(SystemExit):
+        p.parse_args([])                                     # --network and --pretrained-dispnet are required
+    a = p.parse_args(["--network", "disp_vgg_BN", "--pretrained-dispnet", "CKPT"])
+    for k, v in TEST_DEFAULTS.items():
+        assert getattr(a, k) == v, k
+
+
+def test_checkpoint_files_and_keys(tmp_path):
+    import train
+    st = {"epoch": 1, "state_dict": {"w": torch.zeros(1)}, "optimizer": {"step": 1}}
+    train.save_checkpoint(str(tmp_path), st, {"epoch": 1, "state_dict": {}}, is_best=True, epoch=0, record=True)
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["dispnet_checkpoint.pth.tar", "dispnet_model_best.pth.tar", "exp_pose_checkpoint.pth.tar",
+                     "exp_pose_model_best.pth.tar", "weights_0"]
+    assert set(torch.load(tmp_path / "dispnet_model_best.pth.tar").keys()) == {"epoch", "state_dict", "optimizer"}
+
+
+def _cloud(seed, n, h, w):
+    r = np.random.RandomState(seed)
+    # many points per pixel and integer-ish coordinates so duplicates AND (n-1)-linearisation collisions are common
+    pts = np.stack([r.randint(0, w, n).astype(np.float64), r.randint(0, h, n).astype(np.float64), r.uniform(-2, 80, n)], 1)
+    return pts
+
+
+@pytest.mark.parametrize("seed,n,h,w", [(0, 5000, 24, 40), (1, 20000, 37, 124), (2, 50, 8, 9), (3, 0, 5, 7)])
+def test_vectorised_duplicate_min_scatter_is_bit_exact(seed, n, h, w):
+    from oracle import kitti_gt as OK
+    from supervised_dispnet_amd import kitti_eval as KE
+    pts = _cloud(seed, n, h, w)
+    got = KE.scatter_depth_min_duplicates(pts, (h, w))
+    want = OK.scatter_depth_min_duplicates(pts, (h, w))
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+def test_kitti_ground_truth_matches_reference_golden(golden, tmp_path):
+    """The product's file-reading path (calibration text, velodyne .bin) on the synthetic scene whose reference outputs are
+    the committed golden vectors."""
+    import importlib.util
+    import pathlib
+    from supervised_dispnet_amd import kitti_eval as KE
+    g = golden("kitti_gt")
+    spec = importlib.util.spec_from_file_location("mk", pathlib.Path(__file__).parent / "golden" / "make_goldens.py")
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    p_rect, r_rect, r, t, velo = mk.synthetic_kitti_scene()
+    fmt = lambda a: " ".join("%.6e" % v for v in a)
+    (tmp_path / "calib_cam_to_cam.txt").write_text("calib_time: 09-Jan-2012 13:57:47\nR_rect_00: %s\nP_rect_02: %s\n" % (fmt(r_rect), fmt(p_rect)))
+    (tmp_path / "calib_velo_to_cam.txt").write_text("calib_time: 15-Mar-2012 11:37:16\nR: %s\nT: %s\n" % (fmt(r), fmt(t)))
+    velo.astype(np.float32).tofile(tmp_path / "0000000000.bin")
+    for shape in ((375, 1242), (120, 400)):
+        depth = KE.generate_depth_map(str(tmp_path), str(tmp_path / "0000000000.bin"), shape, cam=2)
+        mask = KE.generate_mask(depth, 1e-3, 80)
+        yy, xx = np.nonzero(depth)
+        np.testing.assert_array_equal(np.stack([yy, xx], 1).astype(np.int32), g["depth:%dx%d:yx" % shape])
+        np.testing.assert_array_equal(depth[yy, xx], g["depth:%dx%d:val" % shape])            # bit-exact float64
+        assert int(mask.sum()) == int(g["mask:%dx%d:count" % shape])
+        np.testing.assert_array_equal(mask.sum(1).astype(np.int32), g["mask:%dx%d:rowsum" % shape])
+    assert tuple(KE.garg_crop(375, 1242)) == (153, 371, 44, 1197)
+    assert tuple(KE.garg_crop(128, 416)) == (52, 126, 14, 401)
+
+
+def test_scene_folder_readers_and_rank_sampler(tmp_path):
+    from PIL import Image
+    from supervised_dispnet_amd import data as D
+    root = tmp_path / "kitti"
+    for scene in ("s1", "s2"):
+        d = root / scene
+        d.mkdir(parents=True)
+        np.savetxt(d / "cam.txt", np.array([[100.0, 0, 8], [0, 100.0, 4], [0, 0, 1]]))
+        for i in range(4):
+            Image.fromarray(np.full((8, 16, 3), 10 * i, dtype=np.uint8)).save(d / ("%07d.jpg" % i), quality=100)
+            np.save(d / ("%07d.npy" % i), np.full((8, 16), float(i + 1), dtype=np.float32))
+    (root / "train.txt").write_text("s1\ns2\n")
+    (root / "val.txt").write_text("s2\n")
+    mean, std = D.normalization()
+    ds = D.SequenceFolder(str(root), seed=0, train=True, sequence_length=3, transform=D.Transform(mean, std, flip=True))
+    assert len(ds) == 4                                               # 2 scenes x (4 - 2) centre frames
+    img, gt = ds[0]
+    assert img.shape == (3, 8, 16) and gt.shape == (8, 16) and img.dtype == torch.float32
+    assert float(img.min()) >= -1.0 - 1e-6 and float(img.max()) <= 1.0 + 1e-6
+    five = D.SequenceFolder(str(root), seed=0, train=True, sequence_length=3, transform=D.Transform(mean, std, flip=False), with_refs=True)[0]
+    assert len(five) == 5 and len(five[1]) == 2 and np.allclose(five[2] @ five[3], np.eye(3), atol=1e-5)
+    val = D.ValidationSet(str(root), transform=D.Transform(mean, std, flip=False))
+    assert len(val) == 4 and val[1][1].shape == (8, 16)
+    # global batch 4 over 2 ranks: same global order, contiguous halves
+    a = list(D.RankSampler(8, 4, 0, 2, shuffle=True, seed=3))
+    b = list(D.RankSampler(8, 4, 1, 2, shuffle=True, seed=3))
+    assert len(a) == 2 and sorted(sum(a, []) + sum(b, [])) == list(range(8))
+    whole = list(D.RankSampler(8, 4, 0, 1, shuffle=True, seed=3))
+    assert [x + y for x, y in zip(a, b)] == whole
+    s = D.SyntheticDepthSet(3)
+    assert torch.equal(s[1][0], s[1][0]) and 0.02 < float((s[0][1] > 0).float().mean()) < 0.08
+
+
+def test_imresize_matches_scipy_misc_semantics():
+    from supervised_dispnet_amd import kitti_eval as KE
+    img = np.zeros((4, 4, 3), dtype=np.float32)
+    img[:, 2:] = 255.0
+    out = KE.imresize_bilinear(img, (2, 2))        # PIL's bilinear reduce (support scales with the factor), as scipy.misc used
+    assert out.shape == (2, 2, 3) and out.dtype == np.uint8 and out[0, 0, 0] < 64 and out[0, 1, 0] > 192
+    # float input is byte-scaled by its own min / max first (scipy.misc.toimage): [10, 20] -> [0, 255]
+    ramp = np.repeat(np.linspace(10.0, 20.0, 4, dtype=np.float32)[None, :, None], 3, 2).repeat(4, 0)
+    same = KE.imresize_bilinear(ramp, (4, 4))
+    assert same[0, 0, 0] == 0 and same[0, 3, 0] == 255

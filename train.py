@@ -1,0 +1,464 @@
+#!/usr/bin/env python3
+"""Trainer for the DispNet hot path on MI355X -- the command line of the reference's train.py (flags, defaults and `dest`s of
+train.py:30-91; loss / network selectors of :239-262,449-468; per-iteration sequence of :420-522; checkpoint keys of
+:376-388), driving the HIP engine instead of cuDNN:
+
+    python3 train.py DATA -b32 --network disp_vgg_BN --loss L1 --with-gt
+    python3 -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py DATA -b32 ...   # one rank per GPU
+
+What differs from the reference, on purpose:
+  * one process per GPU over RCCL instead of single-process nn.DataParallel: `-b` stays the GLOBAL batch, every rank takes
+    its contiguous slice, gradients are summed by the bucketed all-reduce (distributed.GradReducer), BatchNorm statistics
+    stay per replica exactly as under DataParallel;
+  * Adam runs as one fused kernel over a flat arena; the 123.6 M unused VGG-classifier parameters are not optimised;
+  * --unsupervised gets the 5-tuple loader the reference's branch needs (C-1); unknown selectors raise ValueError (C-12);
+  * `--synthetic N` (extension) trains on N synthetic samples with the statistics of SURVEY.md section 8d, for boxes
+    without a dataset; tensorboard / progress-bar logging is replaced by plain prints and the two CSV logs.
+"""
+import argparse
+import csv
+import datetime
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+NETWORKS = ("dispnet", "disp_res", "disp_res_50", "disp_res_18", "disp_vgg", "disp_vgg_BN", "FCRN", "res50_aspp", "ASPP",
+            "disp_res_101", "DORN", "disp_vgg_BN_DORN")
+LOSSES = ("Multi_L1", "Multi_full_L1", "Multi_berhu", "Multi_L2", "L1", "berhu", "L2", "scale_inv", "Multi_scale_inv", "DORN")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Structure from Motion Learner training on KITTI and CityScapes Dataset",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--network", default="disp_vgg", type=str, help="network type")
+    p.add_argument("--dataset", default="kitti", type=str, help="dataset name")
+    p.add_argument("--imagenet-normalization", action="store_true", help="use imagenet parameter for normalization.")
+    p.add_argument("--pretrained-encoder", action="store_true", help="use imagenet pretrained parameter.")
+    p.add_argument("--loss", default="Multi_L1", type=str, help="loss type")
+    p.add_argument("--ordinal-c", default=80, type=int, metavar="N", help="DORN loss channel number")
+    p.add_argument("--diff-lr", action="store_true", help="use different learning rate for encoder and decoder")
+    p.add_argument("--sgd", action="store_true", help="use sgd optimizer, if not then adam")
+    p.add_argument("--record", action="store_true", help="save every epoch checkpoints")
+    p.add_argument("--unsupervised", action="store_true", help="to have unsupervised loss")
+    p.add_argument("--data-amount", default=1, type=float, metavar="M", help="percentage of data to be trained")
+    p.add_argument("--monodepth2", action="store_true", help="to finetune over monodepth2 model")
+    p.add_argument("data", metavar="DIR", help="path to dataset")
+    p.add_argument("--dataset-format", default="sequential", metavar="STR", help="dataset format: stacked | sequential")
+    p.add_argument("--sequence-length", type=int, metavar="N", help="sequence length for training", default=3)
+    p.add_argument("--rotation-mode", type=str, choices=["euler", "quat"], default="euler", help="rotation mode for PoseExpnet")
+    p.add_argument("--padding-mode", type=str, choices=["zeros", "border"], default="zeros", help="padding mode for image warping")
+    p.add_argument("--with-gt", action="store_true", help="use ground truth for validation")
+    p.add_argument("-j", "--workers", default=4, type=int, metavar="N", help="number of data loading workers")
+    p.add_argument("--epochs", default=200, type=int, metavar="N", help="number of total epochs to run")
+    p.add_argument("--epoch-size", default=0, type=int, metavar="N", help="manual epoch size (will match dataset size if not set)")
+    p.add_argument("-b", "--batch-size", default=4, type=int, metavar="N", help="mini-batch size (global, over all ranks)")
+    p.add_argument("--lr", "--learning-rate", default=1e-4, type=float, metavar="LR", help="initial learning rate")
+    p.add_argument("--momentum", default=0.9, type=float, metavar="M", help="momentum for sgd, alpha parameter for adam")
+    p.add_argument("--beta", default=0.999, type=float, metavar="M", help="beta parameters for adam")
+    p.add_argument("--weight-decay", "--wd", default=0, type=float, metavar="W", help="weight decay")
+    p.add_argument("--print-freq", default=10, type=int, metavar="N", help="print frequency")
+    p.add_argument("-e", "--evaluate", dest="evaluate", action="store_true", help="evaluate model on validation set")
+    p.add_argument("--pretrained-disp", dest="pretrained_disp", default=None, metavar="PATH", help="path to pre-trained dispnet model")
+    p.add_argument("--pretrained-exppose", dest="pretrained_exp_pose", default=None, metavar="PATH",
+                   help="path to pre-trained Exp Pose net model")
+    p.add_argument("--seed", default=0, type=int, help="seed for random functions, and network initialization")
+    p.add_argument("--log-summary", default="progress_log_summary.csv", metavar="PATH", help="csv of per-epoch train and valid stats")
+    p.add_argument("--log-full", default="progress_log_full.csv", metavar="PATH", help="csv of per-gradient descent train stats")
+    p.add_argument("-p", "--photo-loss-weight", type=float, help="weight for photometric loss", metavar="W", default=1)
+    p.add_argument("-m", "--mask-loss-weight", type=float, help="weight for explainabilty mask loss", metavar="W", default=0)
+    p.add_argument("-s", "--smooth-loss-weight", type=float, help="weight for disparity smoothness loss", metavar="W", default=0)
+    p.add_argument("--log-output", action="store_true", help="will log dispnet outputs and warped imgs at validation step")
+    p.add_argument("-f", "--training-output-freq", type=int, metavar="N", default=0,
+                   help="frequence for outputting dispnet outputs and warped imgs at training")
+    # extensions (not in the reference)
+    p.add_argument("--synthetic", type=int, default=0, metavar="N", help="train on N synthetic samples instead of DIR")
+    p.add_argument("--img-height", type=int, default=128, help="synthetic image height")
+    p.add_argument("--img-width", type=int, default=416, help="synthetic image width")
+    p.add_argument("--train-pose", action="store_true", help="also optimise PoseExpNet (the reference never does, appendix C-3)")
+    p.add_argument("--save-root", default="checkpoints", help="directory under which the run folder is created")
+    return p
+
+
+def save_path_formatter(args, parser):
+    """utils.py:11-43: DIR name, then every non-default key of a fixed list, then a timestamp."""
+    d = vars(args)
+    parts = [os.path.basename(os.path.normpath(d["data"]))]
+    if d["epochs"] != parser.get_default("epochs"):
+        parts.append("{}epochs".format(d["epochs"]))
+    for key, prefix in (("epoch_size", "epoch_size"), ("sequence_length", "seq"), ("rotation_mode", "rot_"), ("padding_mode", "padding_"),
+                        ("batch_size", "b"), ("lr", "lr"), ("photo_loss_weight", "p"), ("mask_loss_weight", "m"),
+                        ("smooth_loss_weight", "s"), ("network", "network"), ("pretrained_encoder", "pretrained_encoder"), ("loss", "loss")):
+        if d[key] != parser.get_default(key):
+            parts.append("{}{}".format(prefix, d[key]))
+    return os.path.join(",".join(parts), datetime.datetime.now().strftime("%m-%d-%H:%M"))
+
+
+def save_checkpoint(save_path, dispnet_state, exp_pose_state, is_best, epoch, filename="checkpoint.pth.tar", record=False):
+    """utils.py:85-99 file names and dict keys."""
+    for prefix, state in (("dispnet", dispnet_state), ("exp_pose", exp_pose_state)):
+        torch.save(state, os.path.join(save_path, "{}_{}".format(prefix, filename)))
+    if record:
+        rec = os.path.join(save_path, "weights_{}".format(epoch))
+        os.makedirs(rec, exist_ok=True)
+        torch.save(dispnet_state, os.path.join(rec, "dispnet_{}".format(filename)))
+    if is_best:
+        for prefix in ("dispnet", "exp_pose"):
+            shutil.copyfile(os.path.join(save_path, "{}_{}".format(prefix, filename)),
+                            os.path.join(save_path, "{}_model_best.pth.tar".format(prefix)))
+
+
+def create_disp_net(args, models, networks, device):
+    if args.monodepth2:
+        if args.network == "disp_vgg_BN":
+            enc = networks.vggEncoder(num_layers=16, pretrained=False).to(device)
+        elif args.network == "disp_res_18":
+            enc = networks.ResnetEncoder(num_layers=18, pretrained=False).to(device)
+        else:
+            raise ValueError("undefined network")
+        dec = networks.DepthDecoder(enc.num_ch_enc).to(device)
+        return models.monodepth2(encoder=enc, decoder=dec)
+    table = {"dispnet": "DispNetS", "disp_res": "Disp_res", "disp_res_50": "Disp_res_50", "disp_res_18": "Disp_res_18",
+             "disp_vgg": "Disp_vgg_feature", "disp_vgg_BN": "Disp_vgg_BN", "FCRN": "FCRN", "res50_aspp": "res50_aspp",
+             "ASPP": "deeplab_depth", "disp_res_101": "Disp_res_101"}
+    if args.network in table:
+        return getattr(models, table[args.network])(datasets=args.dataset).to(device)
+    if args.network == "DORN":
+        return models.DORN(freeze=args.diff_lr, datasets=args.dataset).to(device)
+    if args.network == "disp_vgg_BN_DORN":
+        return models.Disp_vgg_BN_DORN(ordinal_c=args.ordinal_c, datasets=args.dataset).to(device)
+    raise ValueError("undefined network")
+
+
+def supervised_loss(args, LF, gt_depth, depth, pred_ord=None, target_c=None):
+    L = args.loss
+    if L == "Multi_L1":
+        return LF.Multiscale_L1_loss(gt_depth, depth)
+    if L == "Multi_full_L1":
+        return LF.Multiscale_FULL_L1_loss(gt_depth, depth)
+    if L == "Multi_berhu":
+        return LF.Multiscale_berhu_loss(gt_depth, depth)
+    if L == "Multi_L2":
+        return LF.Multiscale_L2_loss(gt_depth, depth)
+    if L == "L1":
+        return LF.l1_loss(gt_depth, depth, args.dataset)
+    if L == "berhu":
+        return LF.berhu_loss(gt_depth, depth, args.dataset)
+    if L == "L2":
+        return LF.l2_loss(gt_depth, depth, args.dataset)
+    if L == "scale_inv":
+        return LF.Scale_invariant_loss(gt_depth, depth, args.dataset)
+    if L == "Multi_scale_inv":
+        return LF.Multiscale_scale_inv_loss(gt_depth, depth)
+    if L == "DORN":
+        return LF.DORN_loss(gt_depth, pred_ord, target_c, args.dataset)
+    raise ValueError("undefined loss")
+
+
+class Meter(object):
+    def __init__(self, n=1):
+        self.sum, self.count, self.val = np.zeros(n), 0, np.zeros(n)
+
+    def update(self, v, k=1):
+        v = np.atleast_1d(np.asarray(v, dtype=np.float64))
+        self.val = v
+        self.sum += v * k
+        self.count += k
+
+    @property
+    def avg(self):
+        return self.sum / max(self.count, 1)
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py drives the MI355X HIP path; no GPU is visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    if args.batch_size % world != 0:
+        raise SystemExit("-b %d must divide over %d ranks" % (args.batch_size, world))
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build(only_library=True)
+    if world > 1:
+        dist.barrier()
+    import supervised_dispnet_amd.loss_functions as LF
+    import supervised_dispnet_amd.models as models
+    import supervised_dispnet_amd.networks as networks
+    import supervised_dispnet_amd.utils as U
+    from supervised_dispnet_amd import data as D, engine
+    from supervised_dispnet_amd.distributed import GradReducer
+    from supervised_dispnet_amd.functional import reciprocal
+    from supervised_dispnet_amd.optim import FusedAdam
+
+    save_path = os.path.join(args.save_root, save_path_formatter(args, parser))
+    if rank == 0:
+        print("=> will save everything to {}".format(save_path))
+        os.makedirs(save_path, exist_ok=True)
+    torch.manual_seed(args.seed)
+    if args.evaluate:
+        args.epochs = 0
+
+    # ---- data
+    with_refs = bool(args.unsupervised)
+    if args.synthetic > 0:
+        maxd = 10.0 if args.dataset == "nyu" else 80.0
+        train_set = D.SyntheticDepthSet(args.synthetic, args.img_height, args.img_width, max_depth=maxd, seed=args.seed,
+                                        sequence_length=args.sequence_length, with_refs=with_refs)
+        val_set = D.SyntheticDepthSet(max(args.batch_size, args.synthetic // 4), args.img_height, args.img_width, max_depth=maxd,
+                                      seed=args.seed + 1, sequence_length=args.sequence_length, with_refs=with_refs and not args.with_gt)
+    elif args.dataset == "kitti":
+        if args.dataset_format != "sequential":
+            raise ValueError("only the sequential folder format is supported on this path")
+        mean, std = D.normalization(args.imagenet_normalization, args.monodepth2)
+        print("=> fetching scenes in '{}'".format(args.data))
+        train_set = D.SequenceFolder(args.data, transform=D.Transform(mean, std, flip=True), seed=args.seed, train=True,
+                                     sequence_length=args.sequence_length, percentage=args.data_amount, with_refs=with_refs)
+        if args.with_gt:
+            val_set = D.ValidationSet(args.data, transform=D.Transform(mean, std, flip=False))
+        else:
+            val_set = D.SequenceFolder(args.data, transform=D.Transform(mean, std, flip=False), seed=args.seed, train=False,
+                                       sequence_length=args.sequence_length, with_refs=True)
+    else:
+        raise ValueError("dataset '{}' needs the reference's NYU h5 loader, which is outside this path; use --synthetic".format(args.dataset))
+    if rank == 0:
+        print("{} samples found in {} train scenes".format(len(train_set), len(train_set.scenes)))
+        print("{} samples found in {} valid scenes".format(len(val_set), len(val_set.scenes)))
+    per_rank = args.batch_size // world
+    train_sampler = D.RankSampler(len(train_set), args.batch_size, rank, world, shuffle=True, seed=args.seed)
+    val_sampler = D.RankSampler(len(val_set), args.batch_size, rank, world, shuffle=False, drop_last=False)
+    workers = min(per_rank, os.cpu_count() or 1)     # the reference uses num_workers = batch_size and ignores -j (train.py:201-206)
+    train_loader = torch.utils.data.DataLoader(train_set, batch_sampler=train_sampler, num_workers=workers, pin_memory=True)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_sampler=val_sampler, num_workers=workers, pin_memory=True)
+    if args.epoch_size == 0:
+        args.epoch_size = len(train_loader)
+
+    # ---- models
+    if rank == 0:
+        print("=> creating model")
+    disp_net = create_disp_net(args, models, networks, device)
+    output_exp = args.mask_loss_weight > 0
+    pose_exp_net = models.PoseExpNet(nb_ref_imgs=args.sequence_length - 1, output_exp=output_exp).to(device)
+    if args.pretrained_exp_pose:
+        pose_exp_net.load_state_dict(torch.load(args.pretrained_exp_pose, map_location=device)["state_dict"], strict=False)
+    else:
+        pose_exp_net.init_weights()
+    weights = None
+    if args.pretrained_disp and not args.monodepth2:
+        weights = torch.load(args.pretrained_disp, map_location=device)
+        disp_net.load_state_dict(weights["state_dict"])
+    elif not args.monodepth2:
+        disp_net.init_weights(use_pretrained_weights=args.pretrained_encoder)
+
+    hot = list(disp_net._hot_parameters()) if hasattr(disp_net, "_hot_parameters") else [p for p in disp_net.parameters() if p.requires_grad]
+    if args.train_pose:
+        hot += [p for p in pose_exp_net.parameters() if p.requires_grad]
+    reducer = None
+    if args.diff_lr:
+        groups = [{"params": disp_net.get_1x_lr_params(), "lr": args.lr}, {"params": disp_net.get_10x_lr_params(), "lr": args.lr * 10}]
+        optimizer = torch.optim.SGD(groups, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    elif args.sgd:
+        optimizer = torch.optim.SGD([{"params": hot, "lr": args.lr}], lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    else:
+        if rank == 0:
+            print("=> setting adam solver")
+        order = disp_net._grad_production_order() if hasattr(disp_net, "_grad_production_order") else None
+        optimizer = FusedAdam(hot, lr=args.lr, betas=(args.momentum, args.beta), weight_decay=args.weight_decay, production_order=order)
+        if world > 1:
+            reducer = GradReducer(optimizer.arena)
+            engine.GradSink.reducer = reducer
+    if weights is not None and "optimizer" in weights and not args.monodepth2:
+        try:
+            optimizer.load_state_dict(weights["optimizer"])
+        except Exception as e:    # a reference checkpoint carries torch.optim.Adam state (incl. the unused classifier slots)
+            print("=> optimizer state not restored ({}); Adam moments start from zero".format(e))
+
+    if rank == 0:
+        with open(os.path.join(save_path, args.log_summary), "w") as f:
+            csv.writer(f, delimiter="\t").writerow(["train_loss", "validation_loss"])
+        with open(os.path.join(save_path, args.log_full), "w") as f:
+            csv.writer(f, delimiter="\t").writerow(["train_loss", "photo_loss", "explainability_loss", "smooth_loss"])
+
+    ctx = dict(args=args, device=device, LF=LF, U=U, reciprocal=reciprocal, rank=rank, world=world, reducer=reducer, save_path=save_path)
+
+    def run_validation(epoch):
+        if args.with_gt:
+            return validate_with_gt(ctx, val_loader, disp_net)
+        return validate_without_gt(ctx, val_loader, disp_net, pose_exp_net)
+
+    if args.pretrained_disp or args.evaluate:
+        errors, names = run_validation(0)
+        if rank == 0:
+            print(" * Avg " + ", ".join("{} : {:.3f}".format(n, e) for n, e in zip(names, errors)))
+
+    best_error, n_iter = -1.0, 0
+    for epoch in range(args.epochs):
+        train_sampler.set_epoch(epoch)
+        train_loss, n_iter = train(ctx, train_loader, disp_net, pose_exp_net, optimizer, args.epoch_size, n_iter)
+        if rank == 0:
+            print(" * Avg Loss : {:.3f}".format(train_loss))
+        errors, names = run_validation(epoch)
+        if rank == 0:
+            print(" * Avg " + ", ".join("{} : {:.3f}".format(n, e) for n, e in zip(names, errors)))
+            decisive = float(errors[1])
+            if best_error < 0:
+                best_error = decisive
+            is_best = decisive < best_error
+            best_error = min(best_error, decisive)
+            save_checkpoint(save_path,
+                            {"epoch": epoch + 1, "state_dict": disp_net.state_dict(), "optimizer": optimizer.state_dict()},
+                            {"epoch": epoch + 1, "state_dict": pose_exp_net.state_dict()}, is_best, epoch, record=args.record)
+            with open(os.path.join(save_path, args.log_summary), "a") as f:
+                csv.writer(f, delimiter="\t").writerow([train_loss, decisive])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _to_device_batch(batch, device, unsupervised):
+    if unsupervised:
+        tgt, refs, intr, intr_inv, gt = batch
+        return (tgt.to(device, non_blocking=True), [r.to(device, non_blocking=True) for r in refs],
+                torch.as_tensor(intr).float().to(device), torch.as_tensor(intr_inv).float().to(device), gt.to(device, non_blocking=True))
+    tgt, gt = batch
+    return tgt.to(device, non_blocking=True), None, None, None, gt.to(device, non_blocking=True)
+
+
+def train(ctx, loader, disp_net, pose_exp_net, optimizer, epoch_size, n_iter):
+    args, device, LF, U, reciprocal = ctx["args"], ctx["device"], ctx["LF"], ctx["U"], ctx["reciprocal"]
+    rank, reducer = ctx["rank"], ctx["reducer"]
+    w1, w2, w3 = args.photo_loss_weight, args.mask_loss_weight, args.smooth_loss_weight
+    disp_net.train()
+    pose_exp_net.train()
+    if args.diff_lr:          # freeze BN (train.py:406-411)
+        for m in disp_net.modules():
+            if m.__class__.__name__.find("BatchNorm") != -1:
+                m.eval()
+    losses, batch_time, data_time = Meter(), Meter(), Meter()
+    end = time.time()
+    for i, batch in enumerate(loader):
+        data_time.update(time.time() - end)
+        tgt_img, ref_imgs, intrinsics, intrinsics_inv, gt_depth = _to_device_batch(batch, device, args.unsupervised)
+        explainability_mask, pose = (None, None)
+        if args.unsupervised:
+            explainability_mask, pose = pose_exp_net(tgt_img, ref_imgs)
+        if args.dataset == "nyu" and gt_depth.dim() == 4:
+            gt_depth = torch.squeeze(gt_depth[:, 0, :, :])
+        pred_ord = target_c = depth = None
+        if args.loss == "DORN":
+            target_c = U.get_labels_sid(gt_depth, ordinal_c=args.ordinal_c, dataset=args.dataset)
+            _pred_d, pred_ord = disp_net(tgt_img)
+        else:
+            disparities = disp_net(tgt_img)
+            if args.monodepth2:
+                depth = [5.4 * reciprocal(d) for d in disparities]       # 5.4 = stereo scale factor (train.py:443)
+            else:
+                depth = [reciprocal(d) for d in disparities]
+        if not args.unsupervised:
+            loss_1 = supervised_loss(args, LF, gt_depth, depth, pred_ord, target_c)
+        else:
+            loss_1 = LF.photometric_reconstruction_loss(tgt_img, ref_imgs, intrinsics, intrinsics_inv, depth, explainability_mask, pose,
+                                                        args.rotation_mode, args.padding_mode)
+        loss_2 = LF.explainability_loss(explainability_mask) if w2 > 0 else 0
+        # the reference evaluates the smoothness term unconditionally and multiplies it by -s (train.py:483-488);
+        # with -s 0 (the README recipe) the product is exactly 0 for the finite values it takes, so it is skipped
+        if w3 != 0:
+            loss_3 = LF.smooth_DORN_loss(pred_ord) if args.loss == "DORN" else LF.smooth_loss(depth)
+        else:
+            loss_3 = 0
+        loss = w1 * loss_1 + w2 * loss_2 + w3 * loss_3
+        optimizer.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            optimizer.step(grad_scale=reducer.finish())
+        else:
+            optimizer.step()
+        lv = float(loss.item())
+        losses.update(lv, args.batch_size)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if rank == 0:
+            with open(os.path.join(ctx["save_path"], args.log_full), "a") as f:
+                csv.writer(f, delimiter="\t").writerow([lv, float(loss_1.item()), float(loss_2.item()) if w2 > 0 else 0,
+                                                         float(loss_3.item()) if w3 != 0 else 0])
+            if i % args.print_freq == 0:
+                print("Train: [{}/{}] Time {:.3f} ({:.3f}) Data {:.3f} Loss {:.4f} ({:.4f})".format(
+                    i, min(len(loader), epoch_size), batch_time.val[0], batch_time.avg[0], data_time.avg[0], lv, losses.avg[0]))
+        if i >= epoch_size - 1:
+            break
+        n_iter += 1
+    return float(losses.avg[0]), n_iter
+
+
+@torch.no_grad()
+def validate_with_gt(ctx, loader, disp_net):
+    args, device, LF, U = ctx["args"], ctx["device"], ctx["LF"], ctx["U"]
+    names = ["abs_diff", "abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"]
+    errors = Meter(len(names))
+    disp_net.eval()
+    for i, (tgt_img, depth) in enumerate(loader):
+        tgt_img, depth = tgt_img.to(device), depth.to(device)
+        if args.dataset == "nyu" and depth.dim() == 4:
+            depth = torch.squeeze(depth[:, 0, :, :])
+        if args.loss == "DORN":
+            pred, _ = disp_net(tgt_img)
+            output_depth = torch.squeeze(U.get_depth_sid(pred, ordinal_c=args.ordinal_c, dataset=args.dataset), 1)
+        else:
+            output_depth = 1 / disp_net(tgt_img)[:, 0]
+            if args.monodepth2:
+                output_depth = output_depth * 5.4
+        if output_depth.shape[-2:] != depth.shape[-2:]:
+            output_depth = torch.nn.functional.interpolate(output_depth.unsqueeze(1), size=depth.shape[-2:], mode="bilinear",
+                                                           align_corners=True).squeeze(1)
+        errors.update(LF.compute_errors(depth, output_depth, dataset=args.dataset, unsupervised=args.unsupervised), tgt_img.size(0))
+    return _all_rank_average(ctx, errors), names
+
+
+@torch.no_grad()
+def validate_without_gt(ctx, loader, disp_net, pose_exp_net):
+    args, device, LF = ctx["args"], ctx["device"], ctx["LF"]
+    w1, w2, w3 = args.photo_loss_weight, args.mask_loss_weight, args.smooth_loss_weight
+    losses = Meter(3)
+    disp_net.eval()
+    pose_exp_net.eval()
+    for i, batch in enumerate(loader):
+        tgt_img, ref_imgs, intrinsics, intrinsics_inv, _gt = _to_device_batch(batch, device, True)
+        disp = disp_net(tgt_img)
+        depth = 1 / disp
+        explainability_mask, pose = pose_exp_net(tgt_img, ref_imgs)
+        l1 = float(LF.photometric_reconstruction_loss(tgt_img, ref_imgs, intrinsics, intrinsics_inv, depth, explainability_mask, pose,
+                                                      args.rotation_mode, args.padding_mode).item())
+        l2 = float(LF.explainability_loss(explainability_mask).item()) if w2 > 0 else 0.0
+        l3 = float(LF.smooth_loss(depth).item())
+        losses.update([w1 * l1 + w2 * l2 + w3 * l3, l1, l2], tgt_img.size(0))
+    return _all_rank_average(ctx, losses), ["Total loss", "Photo loss", "Exp loss"]
+
+
+def _all_rank_average(ctx, meter):
+    if ctx["world"] > 1:
+        import torch.distributed as dist
+        t = torch.tensor(np.r_[meter.sum, meter.count], dtype=torch.float64, device=ctx["device"])
+        dist.all_reduce(t)
+        return (t[:-1] / t[-1].clamp(min=1)).cpu().numpy()
+    return meter.avg
+
+
+if __name__ == "__main__":
+    main()
