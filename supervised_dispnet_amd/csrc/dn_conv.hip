@@ -477,25 +477,26 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
   }
   __syncthreads();
 
-  // per-thread staging assignment: K group g (4 floats) of rows r0 + 32*i; per row a bit mask of the taps that land inside
+  // per-thread staging assignment: K group g (4 floats) of rows r0 + 32*i; per row a bit mask of the taps that land inside.
+  // The row coordinates are recomputed at each operand set-up instead of being kept live through the main loops.
   const int g = tid & 7, r0 = tid >> 3;
-  int rn[AR], rby[AR], rbx[AR];
-  unsigned vmask[AR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
+  auto row_coords = [&](int i, int* n, int* by, int* bx) {
     const int m = m0 + r0 + 32 * i;
-    const bool live = m < p.M;
     unsigned gx, gy;
-    const unsigned t = fastdiv(live ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
-    rn[i] = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
-    rby[i] = (int)gy * p.sy;
-    rbx[i] = (int)gx * p.sx;
-    vmask[i] = live ? 0xffffffffu : 0u;
-  }
+    const unsigned t = fastdiv(m < p.M ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+    *n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+    *by = (int)gy * p.sy;
+    *bx = (int)gx * p.sx;
+  };
+  unsigned vmask[AR];
   {
+    int rn[AR], rby[AR], rbx[AR];
     unsigned inside[AR];
 #pragma unroll
-    for (int i = 0; i < AR; ++i) inside[i] = 0u;
+    for (int i = 0; i < AR; ++i) {
+      row_coords(i, &rn[i], &rby[i], &rbx[i]);
+      inside[i] = 0u;
+    }
     for (int j = 0; j < ntaps; ++j) {
       const int tp = taps[j];
       const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
@@ -504,7 +505,7 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
         inside[i] |= ((unsigned)(rby[i] + dy) < (unsigned)p.IH && (unsigned)(rbx[i] + dx) < (unsigned)p.IW) ? (1u << j) : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < AR; ++i) vmask[i] &= inside[i];
+    for (int i = 0; i < AR; ++i) vmask[i] = (m0 + r0 + 32 * i) < p.M ? inside[i] : 0u;
   }
 
   f32x16 acc[MI][NI];
@@ -539,45 +540,62 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
   int buf = 0;
   for (int s = 0; s < p.n_in; ++s) {
     const KOperand& S = p.in[s];
-    auto run_operand = [&](auto aff_tag) {
+    // UNI  : C % 32 == 0 -- a chunk is (one tap, 32 channels): tap and channel base are block-uniform scalars.
+    // !UNI : C in {4, 8, 16} -- a chunk is 32/C whole taps: the thread's K group sits in tap j0 + gt at channel ct, both fixed
+    //        per thread up to the uniform chunk base j0, so the tap word / validity bit / offset are per-thread VGPR values.
+    auto run_operand = [&](auto aff_tag, auto uni_tag) {
       constexpr bool HA = decltype(aff_tag)::value;
+      constexpr bool UNI = decltype(uni_tag)::value;
       // ---- operand set-up (block-uniform scalars + per-row base offsets)
       const char* base = reinterpret_cast<const char*>(S.p);
       const char* scp = reinterpret_cast<const char*>(S.scale);
       const char* shp = reinterpret_cast<const char*>(S.shift);
       const int sh = (int)S.sh, sw = (int)S.sw;
-      const int cpt = S.C >> 5;                       // chunks per tap
-      const int nch = ntaps * cpt;
+      const int cpt = S.C >> 5;                       // UNI: chunks per tap
+      const int tpc = UNI ? 1 : 32 / S.C;             // !UNI: taps per chunk
+      const int nch = UNI ? ntaps * cpt : (ntaps + tpc - 1) / tpc;
+      const int gt = UNI ? 0 : (g * 4) / S.C;         // !UNI: this thread's tap within the chunk ...
+      const int ct = UNI ? g * 4 : (g * 4) % S.C;     //       ... and its channel
       unsigned rowoffB[AR];
 #pragma unroll
-      for (int i = 0; i < AR; ++i) rowoffB[i] = (unsigned)((rn[i] * (int)S.sn + rby[i] * sh + rbx[i] * sw + g * 4) * 4);
+      for (int i = 0; i < AR; ++i) {
+        int rn, rby, rbx;
+        row_coords(i, &rn, &rby, &rbx);
+        rowoffB[i] = (unsigned)((rn * (int)S.sn + rby * sh + rbx * sw + ct) * 4);
+      }
 
       f32x4 av[AR], bv[BR], sc4, sh4;
       bool aok[AR];
       // cursor = the chunk whose loads are issued next: index cn = (tap j, chunk-in-tap cc); its tap word is fetched from LDS
       // one iteration ahead and kept in a VGPR until decoded, so the scalar unit never waits inside the MFMA stream
-      int cn = 0, j = 0, cc = 0;
-      int tapv = taps[0];
+      int cn = 0, j = 0, cc = 0;          // UNI: j = tap, cc = chunk within the tap; !UNI: j = first tap of the chunk
+      int tapv = taps[UNI ? 0 : gt];
       unsigned soffB = 0, jbit = 0, coffB = 0;
       const char* wcur = wrow;
 
       auto cursor_decode = [&]() {
-        const int tapword = __builtin_amdgcn_readfirstlane(tapv);
+        const int tapword = UNI ? __builtin_amdgcn_readfirstlane(tapv) : tapv;
         const int dy = (int)(short)(tapword & 0xffff), dx = tapword >> 16;
         soffB = (unsigned)((dy * sh + dx * sw + cc * 32) * 4);
-        jbit = 1u << j;
-        coffB = (unsigned)((cc * 32 + g * 4) * 4);
+        const int jt = j + gt;
+        jbit = jt < ntaps ? 1u << jt : 0u;
+        coffB = (unsigned)((cc * 32 + ct) * 4);
         wcur = wrow;
       };
       auto cursor_advance = [&]() {      // clamps at the last chunk (the final iteration re-fetches it into the idle buffer: no branch)
         const bool more = cn + 1 < nch;
-        const int cc1 = cc + 1;
-        const bool wrap = cc1 == cpt;
         cn += more ? 1 : 0;
-        cc = more ? (wrap ? 0 : cc1) : cc;
-        j = (more && wrap) ? j + 1 : j;
+        if constexpr (UNI) {
+          const int cc1 = cc + 1;
+          const bool wrap = cc1 == cpt;
+          cc = more ? (wrap ? 0 : cc1) : cc;
+          j = (more && wrap) ? j + 1 : j;
+        } else {
+          j = more ? j + tpc : j;
+        }
         wrow += more ? kChunk * 4 : 0;
-        tapv = taps[j];
+        const int jt = j + gt;
+        tapv = taps[jt < 32 ? jt : 31];
       };
       auto load_a = [&](int i) {
         aok[i] = (vmask[i] & jbit) != 0u;
@@ -655,9 +673,74 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
       }
       wrow += kChunk * 4;        // the cursor stopped on this operand's last chunk; the next operand's weights follow it
     };
+    // Anything else (C = 1 disparity piece, the 3-channel NCHW image, upsampled or odd-width operands): plain gather, one
+    // barrier per chunk, no overlap.  These operands contribute one or two chunks to layers that are HBM-bound anyway.
+    auto run_operand_generic = [&]() {
+      const int nch = (ntaps * S.C + kChunk - 1) / kChunk;
+      int rn[AR], rby[AR], rbx[AR];
+#pragma unroll
+      for (int i = 0; i < AR; ++i) row_coords(i, &rn[i], &rby[i], &rbx[i]);
+      for (int cl = 0; cl < nch; ++cl) {
+        const int kl = cl * kChunk + g * 4;
+        int jv = 0, cv = 0;
+        f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, sh4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        bool aff = false;
+        if (S.vec) {
+          jv = kl / S.C;
+          cv = kl - jv * S.C;
+          if (S.scale != nullptr && jv < ntaps) {
+            sc4 = *reinterpret_cast<const f32x4*>(S.scale + cv);
+            sh4 = *reinterpret_cast<const f32x4*>(S.shift + cv);
+            aff = true;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          AGroup a = gather4(S, kl, ntaps, taps, rn[i], rby[i], rbx[i], (m0 + r0 + 32 * i) < p.M, p.IH, p.IW, jv, cv, 0);
+          f32x4 v = a.v;
+          if (aff) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * sc4[e] + sh4[e]);
+          }
+          if (!a.ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(AsB + buf * ABUF + stA + i * ROWS32) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+          *reinterpret_cast<f32x4*>(BsB + buf * BBUF + stA + i * ROWS32) = *reinterpret_cast<const f32x4*>(wrow + boffB[i]);
+        wrow += kChunk * 4;
+        __syncthreads();
+        const char* Ab = AsB + buf * ABUF + frA;
+        const char* Bb = BsB + buf * BBUF + frB;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          f32x4 fa[MI], fb[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * ROWS32 + kg * 32);
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn) fb[jn] = *reinterpret_cast<const f32x4*>(Bb + jn * ROWS32 + kg * 32);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[jn][kk], acc[i][jn], 0, 0, 0);
+        }
+        buf ^= 1;      // the next chunk fills the other buffer; the barrier above orders it against this chunk's readers
+      }
+      __syncthreads();
+    };
     if (ntaps == 0) continue;       // empty phase of a strided scatter (e.g. 1x1 stride 2): the result is bias/activation only
-    if (S.scale != nullptr) run_operand(std::true_type{});
-    else run_operand(std::false_type{});
+    const bool fast = S.vec && S.small && S.up == 0;
+    if (fast && S.C % 32 == 0) {
+      if (S.scale != nullptr) run_operand(std::true_type{}, std::true_type{});
+      else run_operand(std::false_type{}, std::true_type{});
+    } else if (fast && (S.C == 4 || S.C == 8 || S.C == 16)) {
+      if (S.scale != nullptr) run_operand(std::true_type{}, std::false_type{});
+      else run_operand(std::false_type{}, std::false_type{});
+    } else {
+      run_operand_generic();
+    }
   }
   conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
 }
@@ -1229,7 +1312,7 @@ static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
 
 template <int BNW, int WNn, int WKk>
 static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
-  if (p.uni32 && p.allvec && !getenv("DN_NO_U32"))
+  if (p.wg_uniform && p.allvec && !getenv("DN_NO_U32"))
     return p.any_affine ? launch_wgrad_u32<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_u32<BNW, WNn, WKk, false>(p, stream);
   return p.allvec ? launch_wgrad_v<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_v<BNW, WNn, WKk, false>(p, stream);
 }
@@ -1329,11 +1412,11 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     o.small = ((long long)fwd->N * o.sn < (1ll << 31)) ? 1 : 0;
     p.allvec = (o.vec && o.small) ? 1 : 0;
     p.any_affine = 0;
-    p.uni32 = (p.allvec && co % 32 == 0 && p.ph[0].ntaps <= 32 && (long long)fwd->N * o.sn * 4 + 64 < (1ll << 31)) ? 1 : 0;
+    p.wg_uniform = (p.allvec && co % 32 == 0 && p.ph[0].ntaps <= 32 && (long long)fwd->N * o.sn * 4 + 64 < (1ll << 31)) ? 1 : 0;
   }
   // the G operand must be float4-addressable with int32 offsets too
   if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0 && (long long)p.M * p.Ntot < (1ll << 31))) p.allvec = 0;
-  if (!p.allvec || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.uni32 = 0;
+  if (!p.allvec || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.wg_uniform = 0;
   hipStream_t s = as_stream(stream);
   switch (p.BN) {
     case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;

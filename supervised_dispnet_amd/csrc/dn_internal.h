@@ -82,8 +82,9 @@ struct IgemmParams {
   int splits, m_per_split;
   unsigned mGW, mGH;             // fastdiv magics of GW, GH
   int allvec;                    // every operand takes the float4 fast path (and g, for wgrad)
-  int uni32;                     // additionally: every operand has C % 32 == 0, no upsample, < 2 GiB span, <= 32 taps
-                                 //   -> block-uniform tap/channel per K chunk, buffer loads with hardware range check
+  int uni32;                     // fast plan: <= 32 taps per phase, zero padding, >= 1 operand the scheduled loaders take
+                                 //   (C % 32 == 0 or C in {4,8,16}, float4-addressable, no upsample, < 2 GiB span)
+  int wg_uniform;                // every operand: C % 32 == 0, float4-addressable, no upsample (weight-gradient fast path)
   int any_affine;                // some operand carries a pending BN-apply + ReLU
   int reflect;                   // gather with ReflectionPad2d index mapping instead of zero fill
 };

@@ -233,20 +233,22 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   p->mGW = fastdiv_magic((unsigned)p->GW);
   p->mGH = fastdiv_magic((unsigned)p->GH);
   p->allvec = 1;
-  p->uni32 = 1;
+  p->uni32 = 1;          // "fast plan": <= 32 taps per phase, zero padding, at least one operand the fast loaders take
   p->any_affine = 0;
   for (int z = 0; z < p->nphases; ++z)
     if (p->ph[z].ntaps > 32) p->uni32 = 0;
+  int n_fast = 0, n_uniform = 0;
   for (int i = 0; i < p->n_in; ++i) {
     const KOperand& o = p->in[i];
     if (o.scale != nullptr) p->any_affine = 1;
-    const long long span = (long long)p->N * (o.sn < 0 ? -o.sn : o.sn) + 16;
-    if (!(o.C % 32 == 0 && o.up == 0 && o.sc == 1 && span * 4 < (1ll << 31))) p->uni32 = 0;
-    // (the conv-transpose wgrad operand is filled in by the caller, which re-evaluates allvec)
-    p->in[i].small = offsets_fit_int32(p->in[i], p->N, p->IH, p->IW) ? 1 : 0;
+    // (the conv-transpose wgrad operand is filled in by the caller, which re-evaluates these flags)
+    p->in[i].small = offsets_fit_int32(p->in[i], p->N, p->IH, p->IW) && ((long long)p->N * (o.sn < 0 ? -o.sn : o.sn) + 16) * 4 < (1ll << 31) ? 1 : 0;
     if (!(p->in[i].vec && p->in[i].small)) p->allvec = 0;
+    if (p->in[i].vec && p->in[i].small && o.up == 0 && (o.C % 32 == 0 || o.C == 4 || o.C == 8 || o.C == 16)) ++n_fast;
+    if (p->in[i].vec && p->in[i].small && o.up == 0 && o.C % 32 == 0) ++n_uniform;
   }
-  if (!p->allvec || p->reflect) p->uni32 = 0;
+  if (n_fast == 0 || p->reflect) p->uni32 = 0;
+  p->wg_uniform = (p->uni32 && n_uniform == p->n_in) ? 1 : 0;   // weight-gradient fast path: every chunk block-uniform
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;

