@@ -1281,6 +1281,10 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
                "result %d must be pixel-dense (NHWC with a channel stride)", i);
   }
   hipStream_t s = as_stream(stream);
+  if (!getenv("DN_NO_DIRECT")) {
+    if (head_fwd_eligible(d, p)) return launch_head_fwd(p, s);
+    if (head_dgrad_eligible(d, p)) return launch_head_dgrad(p, s);
+  }
   switch (p.BN) {
     case 128: return launch_conv<128, 128, 64, 64>(p, s);
     case 64: return launch_conv<128, 64, 64, 32>(p, s);
@@ -1375,7 +1379,9 @@ size_t dn_conv_wgrad_workspace_bytes(const dn_conv_desc* fwd) {
   IgemmParams p;
   if (build_plan(fwd, true, &p) != DN_OK) return 0;
   choose_splits(&p);
-  return (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
+  size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
+  if (head_wgrad_eligible(fwd, p) && head_wgrad_workspace_bytes(p) > need) need = head_wgrad_workspace_bytes(p);
+  return need;
 }
 
 int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
@@ -1384,6 +1390,11 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
   int rc = build_plan(fwd, true, &p);
   if (rc != DN_OK) return rc;
   DN_REQUIRE(dy != nullptr && dw != nullptr && workspace != nullptr, DN_ERR_BAD_ARG, "null pointer");
+  if (head_wgrad_eligible(fwd, p) && workspace_bytes >= head_wgrad_workspace_bytes(p) && !getenv("DN_NO_DIRECT")) {
+    DN_REQUIRE(p.in[0].p != nullptr, DN_ERR_BAD_ARG, "operand 0 has no data");
+    p.g = dy;
+    return launch_head_wgrad(p, dw, reinterpret_cast<float*>(workspace), as_stream(stream));
+  }
   choose_splits(&p);
   const size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
   DN_REQUIRE(workspace_bytes >= need, DN_ERR_WORKSPACE, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);

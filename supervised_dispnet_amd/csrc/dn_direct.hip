@@ -1,0 +1,224 @@
+// Direct (matrix-core-free) kernels for the one-channel disparity heads -- predict_disp, models/Disp_vgg_BN.py:66-70:
+// conv3x3(C -> 1) + alpha*sigmoid + beta -- forward, input gradient and weight gradient.  2*9*C flops per pixel against
+// 4*C bytes of input: arithmetic intensity ~4.4 flop/B, i.e. HBM-bound; on the implicit-GEMM path the single
+// output column is padded to a 32-wide MFMA tile (97 % of the matrix work wasted, 0.3-0.7 ms per launch at 128x416 b32).
+// Here: one thread per (pixel, 4-channel group), NHWC float4 loads, the 9*C weights in LDS, wave shuffles for the reductions.
+// Dispatch happens inside dn_conv2d_fwd / dn_conv2d_dgrad / dn_conv2d_wgrad (same ABI, same packed-weight layout).
+#include "dn_internal.h"
+
+namespace dn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float head_act(float v, int act, float p0, float p1) {
+  switch (act) {
+    case DN_ACT_RELU: return v > 0.f ? v : 0.f;
+    case DN_ACT_LEAKY: return v > 0.f ? v : v * p0;
+    case DN_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.f);
+    case DN_ACT_SIGMOID_AFFINE: return p0 / (1.f + expf(-v)) + p1;
+    default: return v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------- forward
+// y[pix] = act(bias + sum_{tap, c} x[pix*s + tap][c] * w[tap][c]);  packed weights row 0 is exactly w[tap][c] (k = tap*C + c).
+// Lanes: the C/4 channel groups of a pixel are adjacent lanes (LG = log2(C/4)); the partial dot products are combined with
+// xor-shuffles inside the group.  Block = 256 threads = 256 >> LG pixels.
+__global__ void __launch_bounds__(256) head_fwd_kernel(const IgemmParams p, int LG) {
+  extern __shared__ float wsm[];                     // [ntaps][C]
+  const KOperand& S = p.in[0];
+  const int C = S.C, ntaps = p.ph[0].ntaps;
+  for (int i = threadIdx.x; i < ntaps * C; i += 256) wsm[i] = p.w[i];
+  __syncthreads();
+  const int cg = threadIdx.x & ((1 << LG) - 1);
+  const long long pix = (long long)blockIdx.x * (256 >> LG) + (threadIdx.x >> LG);
+  const bool live = pix < p.M;
+  unsigned gx, gy;
+  const unsigned t = fastdiv_dev(live ? (unsigned)pix : 0u, (unsigned)p.GW, p.mGW, &gx);
+  const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
+  const int by = (int)gy * p.sy, bx = (int)gx * p.sx;
+  float acc = 0.f;
+  for (int j = 0; j < ntaps; ++j) {
+    const int iy = by + p.tdy[j], ix = bx + p.tdx[j];
+    if (live && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(S.p + (long long)n * S.sn + (long long)iy * S.sh + (long long)ix * S.sw + cg * 4);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + cg * 4);
+      acc += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+    }
+  }
+  for (int d = 1; d < (1 << LG); d <<= 1) acc += __shfl_xor(acc, d);
+  if (live && cg == 0) {
+    const KResult& R = p.out[0];
+    float v = head_act(acc + (p.bias ? p.bias[0] : 0.f), p.act, p.act_p0, p.act_p1);
+    float* o = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
+    if (R.accumulate) v += *o;
+    *o = v;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------- input gradient
+// dx[q][c] (+)= sum_tap dy[q + tap'] * w[c][tap];  the dgrad plan's packed weights are [c][Kp] with k = tap index and the
+// tap tables already hold the flipped offsets.  One thread per (pixel, 4-channel group): 9 scalar dy reads, one 16-byte store.
+__global__ void __launch_bounds__(256) head_dgrad_kernel(const IgemmParams p, int LG, int Kp) {
+  extern __shared__ float wsm[];                     // [ntaps][Ntot]   (transposed on the way in)
+  const int C = p.Ntot, ntaps = p.ph[0].ntaps;
+  for (int i = threadIdx.x; i < ntaps * C; i += 256) {
+    const int c = i / ntaps, j = i - c * ntaps;
+    wsm[j * C + c] = p.w[(long long)c * Kp + j];
+  }
+  __syncthreads();
+  const KOperand& G = p.in[0];
+  const int cg = threadIdx.x & ((1 << LG) - 1);
+  const long long pix = (long long)blockIdx.x * (256 >> LG) + (threadIdx.x >> LG);
+  if (pix >= p.M) return;
+  unsigned gx, gy;
+  const unsigned t = fastdiv_dev((unsigned)pix, (unsigned)p.GW, p.mGW, &gx);
+  const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < ntaps; ++j) {
+    const int iy = (int)gy + p.tdy[j], ix = (int)gx + p.tdx[j];
+    if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+      const float g = G.p[(long long)n * G.sn + (long long)iy * G.sh + (long long)ix * G.sw];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + cg * 4);
+      acc += g * w;
+    }
+  }
+  const KResult& R = p.out[0];
+  f32x4* o = reinterpret_cast<f32x4*>(R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw + cg * 4);
+  if (R.accumulate) acc += *o;
+  *o = acc;
+}
+
+// -------------------------------------------------------------------------------------------------- weight gradient
+// dw[c][tap] = sum_pix dy[pix - tap_offset] * x[pix][c]  (x read ONCE, the 9 dy neighbours come from L1).
+// Thread = (pixel lane, 4-channel group) with 9 float4 accumulators; pixels strided over the grid; lanes of one channel group
+// are folded with xor-shuffles, waves through LDS; each block writes one partial [ntaps][C] slab, head_wgrad_reduce_kernel
+// sums the slabs in a fixed order (deterministic) into the framework layout [1][C][R][S].
+constexpr int kHeadMaxTaps = 9;
+
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const IgemmParams p, int LG, float* __restrict__ slabs) {
+  __shared__ float red[4][kHeadMaxTaps * 4 * 64];
+  const KOperand& S = p.in[0];
+  const int C = S.C, ntaps = p.ph[0].ntaps;
+  const int cg = threadIdx.x & ((1 << LG) - 1);
+  const int lanes_per_px = 1 << LG, px_per_block = 256 >> LG;
+  f32x4 acc[kHeadMaxTaps];
+#pragma unroll
+  for (int j = 0; j < kHeadMaxTaps; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // x pixel q = (n, iy, ix) pairs with dy at the output position (oy, ox) for which oy*s + tdy = iy, i.e. stride-1 heads: oy = iy - tdy
+  const long long npix = (long long)p.N * p.IH * p.IW;
+  for (long long q = (long long)blockIdx.x * px_per_block + (threadIdx.x >> LG); q < npix; q += (long long)gridDim.x * px_per_block) {
+    const int ix = (int)(q % p.IW);
+    const long long tq = q / p.IW;
+    const int iy = (int)(tq % p.IH), n = (int)(tq / p.IH);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(S.p + (long long)n * S.sn + (long long)iy * S.sh + (long long)ix * S.sw + cg * 4);
+#pragma unroll
+    for (int j = 0; j < kHeadMaxTaps; ++j) {
+      if (j < ntaps) {
+        const int oy = iy - p.tdy[j], ox = ix - p.tdx[j];
+        if ((unsigned)oy < (unsigned)p.GH && (unsigned)ox < (unsigned)p.GW) acc[j] += p.g[((long long)n * p.GH + oy) * p.GW + ox] * x;
+      }
+    }
+  }
+  // fold the pixel lanes of this wave (lanes that share cg differ in bits >= LG)
+#pragma unroll
+  for (int j = 0; j < kHeadMaxTaps; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[j][e];
+      for (int d = lanes_per_px; d < 64; d <<= 1) v += __shfl_xor(v, d);
+      acc[j][e] = v;
+    }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < lanes_per_px) {
+#pragma unroll
+    for (int j = 0; j < kHeadMaxTaps; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][(j * 4 + e) * 64 + lane] = acc[j][e];
+  }
+  __syncthreads();
+  float* slab = slabs + (long long)blockIdx.x * ntaps * C;
+  for (int i = threadIdx.x; i < ntaps * C; i += 256) {
+    const int j = i / C, c = i - j * C;
+    const int idx = (j * 4 + (c & 3)) * 64 + (c >> 2);
+    slab[i] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+  }
+}
+
+// one block per weight element: 256 threads fold the slabs in a fixed tree (deterministic), no serial 1024-long chain
+__global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const IgemmParams p, const float* __restrict__ slabs, int nslabs,
+                                                                float* __restrict__ dw) {
+  __shared__ float part[4];
+  const int C = p.in[0].C, ntaps = p.ph[0].ntaps;
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nslabs; b += 256) s += slabs[(long long)b * ntaps * C + i];
+  for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int j = i / C, c = i - j * C;
+    dw[((long long)c * p.R + p.tr[j]) * p.S + p.ts[j]] = (part[0] + part[1]) + (part[2] + part[3]);      // [1][C][R][S]
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------- dispatch
+static int log2_exact(int v) {
+  for (int l = 0; l <= 6; ++l)
+    if ((1 << l) == v) return l;
+  return -1;
+}
+
+static bool plain_vec_operand(const KOperand& o) { return o.vec && o.up == 0 && o.scale == nullptr && o.C % 4 == 0 && log2_exact(o.C / 4) >= 0; }
+
+constexpr int kHeadSlabs = 1024;
+
+bool head_fwd_eligible(const dn_conv_desc* d, const IgemmParams& p) {
+  return d->kind == DN_CONV_FWD && p.Ntot == 1 && p.n_in == 1 && p.n_out == 1 && p.nphases == 1 && !p.reflect && p.bn_partial == nullptr &&
+         plain_vec_operand(p.in[0]) && p.ph[0].ntaps * p.in[0].C * sizeof(float) <= 48 * 1024;
+}
+
+int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
+  const int LG = log2_exact(p.in[0].C / 4);
+  const int px = 256 >> LG;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((p.M + px - 1) / px), dim3(256), p.ph[0].ntaps * p.in[0].C * sizeof(float), stream, p, LG);
+  return check_launch("head_fwd_kernel");
+}
+
+bool head_dgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
+  return d->kind == DN_CONV_DGRAD && p.n_in == 1 && p.in[0].C == 1 && p.in[0].up == 0 && p.in[0].scale == nullptr && p.n_out == 1 &&
+         p.nphases == 1 && !p.reflect && p.Ntot % 4 == 0 && log2_exact(p.Ntot / 4) >= 0 && p.act == DN_ACT_NONE && p.bias == nullptr &&
+         (reinterpret_cast<uintptr_t>(p.out[0].p) & 15) == 0 && p.out[0].sw % 4 == 0 && p.out[0].sh % 4 == 0 && p.out[0].sn % 4 == 0 &&
+         p.ph[0].ntaps * p.Ntot * sizeof(float) <= 48 * 1024 && p.osy == 1;
+}
+
+int launch_head_dgrad(const IgemmParams& p, hipStream_t stream) {
+  const int LG = log2_exact(p.Ntot / 4);
+  const int px = 256 >> LG;
+  hipLaunchKernelGGL(head_dgrad_kernel, dim3((p.M + px - 1) / px), dim3(256), p.ph[0].ntaps * p.Ntot * sizeof(float), stream, p, LG,
+                     p.ph[0].nchunks * kChunk);
+  return check_launch("head_dgrad_kernel");
+}
+
+bool head_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p) {
+  return fwd->kind == DN_CONV_FWD && p.Ntot == 1 && p.n_in == 1 && !p.reflect && plain_vec_operand(p.in[0]) && p.in[0].C <= 256 &&
+         p.ph[0].ntaps <= kHeadMaxTaps && p.sy == 1 && p.sx == 1;
+}
+
+size_t head_wgrad_workspace_bytes(const IgemmParams& p) { return (size_t)kHeadSlabs * p.ph[0].ntaps * p.in[0].C * sizeof(float); }
+
+int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStream_t stream) {
+  const int LG = log2_exact(p.in[0].C / 4);
+  const int px = 256 >> LG;
+  const long long npix = (long long)p.N * p.IH * p.IW;
+  int blocks = (int)((npix + px - 1) / px);
+  if (blocks > kHeadSlabs) blocks = kHeadSlabs;
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, p, LG, workspace);
+  int rc = check_launch("head_wgrad_kernel");
+  if (rc != DN_OK) return rc;
+  const int tot = p.ph[0].ntaps * p.in[0].C;
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(tot), dim3(256), 0, stream, p, workspace, blocks, dw);
+  return check_launch("head_wgrad_reduce_kernel");
+}
+
+}  // namespace dn

@@ -94,4 +94,24 @@ static inline unsigned fastdiv_magic(unsigned d) { return d <= 1 ? 0xFFFFFFFFu :
 
 int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p);
 
+// floor(n/d) on the device with the plan's magic (estimate is exact or one low; branch-free fix-up); *rem = n - q*d
+__device__ __forceinline__ unsigned fastdiv_dev(unsigned n, unsigned d, unsigned M, unsigned* rem) {
+  unsigned q = __umulhi(n, M);
+  unsigned r = n - q * d;
+  const bool fix = r >= d;
+  q += fix ? 1u : 0u;
+  r -= fix ? d : 0u;
+  *rem = r;
+  return q;
+}
+
+// dn_direct.hip: matrix-core-free kernels for the one-channel disparity heads, dispatched from the conv entry points
+bool head_fwd_eligible(const dn_conv_desc* d, const IgemmParams& p);
+int launch_head_fwd(const IgemmParams& p, hipStream_t stream);
+bool head_dgrad_eligible(const dn_conv_desc* d, const IgemmParams& p);
+int launch_head_dgrad(const IgemmParams& p, hipStream_t stream);
+bool head_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
+size_t head_wgrad_workspace_bytes(const IgemmParams& p);
+int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStream_t stream);
+
 }  // namespace dn

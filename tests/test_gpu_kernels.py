@@ -62,6 +62,9 @@ CONV_CASES = [
     ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
     ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
     ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
+    ("3x3_head_16",       (16,),        (False,),          1, 3, 1, 1, False, 0, 3, 17, 23, ACT_SIGMOID_AFFINE, False),
+    ("3x3_head_128",      (128,),       (False,),          1, 3, 1, 1, False, 0, 2, 5, 9, ACT_SIGMOID_AFFINE, False),
+    ("3x3_8_8",           (8,),         (False,),          24, 3, 1, 1, False, 0, 2, 9, 11, ACT_LEAKY, False),
     ("7x7_s2",            (3,),         (False,),          32, 7, 2, 3, False, 0, 2, 20, 28, ACT_RELU, False),
     ("5x5_s2",            (32,),        (False,),          64, 5, 2, 2, False, 0, 2, 18, 22, ACT_RELU, False),
     ("3x3_s2_odd",        (64,),        (False,),          128, 3, 2, 1, False, 0, 2, 13, 7, ACT_RELU, False),
