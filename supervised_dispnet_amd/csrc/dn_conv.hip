@@ -12,6 +12,7 @@
 #include <atomic>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #include "dn_internal.h"
 
@@ -433,6 +434,16 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_kernel(const IgemmParams p)
   conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
 }
 
+// compile-time loop: the body is instantiated once per index, so register arrays indexed by it never become dynamic
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // ------------------------------------------------------------------------------------- forward family, uniform fast path
 // uni32 plans (every operand: C % 32 == 0, float4-addressable, no upsample, < 2 GiB; <= 32 taps; zero padding): a K chunk
 // never straddles a tap or an operand, so (operand, tap, channel base) are BLOCK-UNIFORM per chunk and live on the scalar
@@ -677,33 +688,67 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
     // barrier per chunk, no overlap.  These operands contribute one or two chunks to layers that are HBM-bound anyway.
     auto run_operand_generic = [&]() {
       const int nch = (ntaps * S.C + kChunk - 1) / kChunk;
+      // scalar operands are gathered PIXEL-major: thread = (row tid % BM, K slice tid / BM), so for one K element the lanes
+      // of a wave read neighbouring pixels (coalesced for the NCHW image and for 1-channel maps); float4 operands that the
+      // scheduled loaders do not take (odd widths, upsampled) keep the K-group-major assignment.
+      constexpr int KPT = kChunk / (256 / BM);             // K elements per thread per chunk (pixel-major)
+      const int prow = tid % BM, pk0 = (tid / BM) * KPT;
+      int pn, pby, pbx;
+      {
+        const int m = m0 + prow;
+        unsigned gx, gy;
+        const unsigned t = fastdiv(m < p.M ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+        pn = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+        pby = (int)gy * p.sy;
+        pbx = (int)gx * p.sx;
+      }
+      const bool plive = (m0 + prow) < p.M;
       int rn[AR], rby[AR], rbx[AR];
 #pragma unroll
       for (int i = 0; i < AR; ++i) row_coords(i, &rn[i], &rby[i], &rbx[i]);
       for (int cl = 0; cl < nch; ++cl) {
-        const int kl = cl * kChunk + g * 4;
-        int jv = 0, cv = 0;
-        f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, sh4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        bool aff = false;
-        if (S.vec) {
-          jv = kl / S.C;
-          cv = kl - jv * S.C;
+        if (!S.vec) {
+          float vals[KPT];
+#pragma unroll
+          for (int e = 0; e < KPT; ++e) {
+            const int k = cl * kChunk + pk0 + e;
+            unsigned c;
+            const int j = (int)fastdiv((unsigned)k, (unsigned)S.C, S.mC, &c);
+            float v = 0.f;
+            if (j < ntaps) {
+              const int tp = taps[j];
+              const int iy = pby + (int)(short)(tp & 0xffff), ix = pbx + (tp >> 16);
+              if (plive && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+                v = S.p[(long long)pn * S.sn + (long long)(iy >> S.up) * S.sh + (long long)(ix >> S.up) * S.sw + (long long)c * S.sc];
+                if (S.scale) v = fmaxf(0.f, v * S.scale[c] + S.shift[c]);
+              }
+            }
+            vals[e] = v;
+          }
+#pragma unroll
+          for (int e = 0; e < KPT; e += 4)
+            *reinterpret_cast<f32x4*>(AsB + buf * ABUF + (prow * LDK + pk0 + e) * 4) = f32x4{vals[e], vals[e + 1], vals[e + 2], vals[e + 3]};
+        } else {
+          const int kl = cl * kChunk + g * 4;
+          const int jv = kl / S.C, cv = kl - jv * S.C;
+          f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, sh4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          bool aff = false;
           if (S.scale != nullptr && jv < ntaps) {
             sc4 = *reinterpret_cast<const f32x4*>(S.scale + cv);
             sh4 = *reinterpret_cast<const f32x4*>(S.shift + cv);
             aff = true;
           }
-        }
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-          AGroup a = gather4(S, kl, ntaps, taps, rn[i], rby[i], rbx[i], (m0 + r0 + 32 * i) < p.M, p.IH, p.IW, jv, cv, 0);
-          f32x4 v = a.v;
-          if (aff) {
+          for (int i = 0; i < AR; ++i) {
+            AGroup a = gather4(S, kl, ntaps, taps, rn[i], rby[i], rbx[i], (m0 + r0 + 32 * i) < p.M, p.IH, p.IW, jv, cv, 0);
+            f32x4 v = a.v;
+            if (aff) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * sc4[e] + sh4[e]);
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * sc4[e] + sh4[e]);
+            }
+            if (!a.ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(AsB + buf * ABUF + stA + i * ROWS32) = v;
           }
-          if (!a.ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(AsB + buf * ABUF + stA + i * ROWS32) = v;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)
@@ -971,11 +1016,14 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const IgemmParams p
   }
 }
 
-// ------------------------------------------------------------------------------- weight gradient, uniform fast path
-// uni32 plans: each of the 4 K chunks of this block's k tile sits in ONE (operand, tap, channel base) -- block-uniform and
-// loop-invariant (the loop runs over pixels), so it lives in SGPRs.  Hand-scheduled like igemm_conv_u32_kernel: the next
-// 32-pixel step's loads and address arithmetic are dealt under the first MFMAs of the current step, the LDS fragment reads
-// one K pair ahead of their MFMAs, the store stage under the last MFMAs.
+// ------------------------------------------------------------------------------------ weight gradient, fast path
+// The 4 K chunks of this block's k tile are LOOP-INVARIANT (the loop runs over pixels), so everything about them is decided
+// once: a chunk of a float4-addressable operand (any C % 4 == 0) gives each thread one (tap, channel) for its K group -- kept
+// as per-thread registers, block-uniform when C % 32 == 0; a chunk of a scalar operand (the 1-channel disparity piece, the
+// 3-channel NCHW image) gives it four (tap, channel) pairs and is gathered pixel-major so the loads coalesce.  Hand-scheduled
+// like igemm_conv_u32_kernel: the next 32-pixel step's loads and address arithmetic are dealt under the first MFMAs of the
+// current step, the LDS fragment reads one pixel pair ahead of their MFMAs, the store stage under the last MFMAs.  The chunk
+// kind tests are block-uniform branches inside the slots; they do not disturb the slot order.
 template <int BNW, int WNn, int WKk, bool AFF>
 __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmParams p) {
   constexpr int BKW = 128;
@@ -994,43 +1042,61 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
   const int ntaps = ph.ntaps, nchunks = ph.nchunks, Kp = nchunks * kChunk;
   const int m_begin = blockIdx.z * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
-  const int g = tid & 7, r = tid >> 3;  // staging: row r of the 32-pixel step, 4-float group g
+  const int g = tid & 7, r = tid >> 3;      // float4 staging: row r of the 32-pixel step, K group g
+  const int g2 = tid >> 5, r2 = tid & 31;   // scalar-chunk staging: pixel-major (lanes = consecutive pixels), K group g2
 
-  // block-uniform descriptors of the 4 K chunks
+  // chunk descriptors (block-uniform part in SGPRs, per-thread tap / channel in VGPRs)
   const char* qbase[4];
-  int qsn[4], qsh[4], qsw[4], qdy[4], qdx[4], qtapB[4];
-  unsigned qc0B[4];
-  bool qlive[4];
+  int qsn[4], qsh[4], qsw[4], qsc[4], qup[4];
+  bool qvec[4], qscal[4];
+  int qtap[4];            // vec chunk: this thread's (dy | dx << 16), or 0x80008000 when its K group is past the last tap
+  unsigned qoffB[4];      // vec chunk: this thread's channel byte offset
+  int qst[4][4];          // scalar chunk: per element (dy & 0xff) | (dx & 0xff) << 8 | channel << 16, or -1 when dead
   f32x4 xsc[4], xsh[4];
   float qfloor[4];
+  bool any_scalar = false;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int kc = kt * 4 + q;
     int kcl = 0;
-    const int s = kc < nchunks ? select_operand(p, ntaps, kc, &kcl) : 0;
+    const bool live = kc < nchunks;
+    const int s = live ? select_operand(p, ntaps, kc, &kcl) : 0;
     const KOperand& S = p.in[s];
-    unsigned c0;
-    const int j = (int)fastdiv((unsigned)(kcl * kChunk), (unsigned)S.C, S.mC, &c0);
-    qlive[q] = kc < nchunks && j < ntaps;
-    const int jj = qlive[q] ? j : 0;
     qbase[q] = reinterpret_cast<const char*>(S.p);
     qsn[q] = __builtin_amdgcn_readfirstlane((int)S.sn);
     qsh[q] = __builtin_amdgcn_readfirstlane((int)S.sh);
     qsw[q] = __builtin_amdgcn_readfirstlane((int)S.sw);
-    qdy[q] = __builtin_amdgcn_readfirstlane((int)p.tdy[jj]);
-    qdx[q] = __builtin_amdgcn_readfirstlane((int)p.tdx[jj]);
-    qtapB[q] = (qdy[q] * qsh[q] + qdx[q] * qsw[q] + (int)c0) * 4;       // scalar part of the gather offset (bytes)
-    qc0B[q] = (unsigned)((c0 + g * 4) * 4);
-    if constexpr (AFF) {
-      const bool has_aff = S.scale != nullptr;
-      const f32x4 l1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.scale : S.p) + qc0B[q]);
-      const f32x4 l2 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.shift : S.p) + qc0B[q]);
+    qsc[q] = __builtin_amdgcn_readfirstlane((int)S.sc);
+    qup[q] = __builtin_amdgcn_readfirstlane(S.up);
+    qvec[q] = live && S.vec;
+    qscal[q] = live && !S.vec;
+    any_scalar = any_scalar || qscal[q];
+    {
+      unsigned c;
+      const int j = (int)fastdiv((unsigned)(kcl * kChunk + g * 4), (unsigned)S.C, S.mC, &c);
+      const bool ok = qvec[q] && j < ntaps;
+      const int jj = ok ? j : 0;
+      qtap[q] = ok ? (((int)p.tdy[jj] & 0xffff) | ((int)p.tdx[jj] << 16)) : (int)0x80008000;
+      qoffB[q] = ok ? c * 4u : 0u;
+      if constexpr (AFF) {
+        const bool has_aff = ok && S.scale != nullptr;
+        const f32x4 l1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.scale : S.p) + qoffB[q]);
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.shift : S.p) + qoffB[q]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xsc[q][e] = has_aff ? l1[e] : 1.f;
-        xsh[q][e] = has_aff ? l2[e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          xsc[q][e] = has_aff ? l1[e] : 1.f;
+          xsh[q][e] = has_aff ? l2[e] : 0.f;
+        }
+        qfloor[q] = has_aff ? 0.f : -__builtin_huge_valf();
       }
-      qfloor[q] = has_aff ? 0.f : -__builtin_huge_valf();
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned c;
+      const int j = (int)fastdiv((unsigned)(kcl * kChunk + g2 * 4 + e), (unsigned)S.C, S.mC, &c);
+      const bool ok = qscal[q] && j < ntaps;
+      const int jj = ok ? j : 0;
+      qst[q][e] = ok ? (((int)p.tdy[jj] & 0xff) | (((int)p.tdx[jj] & 0xff) << 8) | ((int)c << 16)) : -1;
     }
   }
 
@@ -1043,11 +1109,9 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const char* gbase = reinterpret_cast<const char*>(p.g);
-  const bool gcol_ok[1] = {true};
-  (void)gcol_ok;
   f32x4 gv[GR], xv[4];
-  bool xok[4], rowvalid = false;
-  int pn = 0, pby = 0, pbx = 0;
+  bool xok[4], rowvalid = false, rowvalid2 = false;
+  int pn = 0, pby = 0, pbx = 0, pn2 = 0, pby2 = 0, pbx2 = 0;
   unsigned goffB = 0;
 
   auto decode_pixel = [&](int mbase) {
@@ -1060,6 +1124,14 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
     pby = (int)gy * p.sy;
     pbx = (int)gx * p.sx;
     goffB = (mm * (unsigned)p.Ntot + (unsigned)(n0 + g * 4)) * 4u;
+    if (any_scalar) {
+      const int m2 = mbase + r2;
+      rowvalid2 = m2 < m_end;
+      const unsigned t2 = fastdiv(rowvalid2 ? (unsigned)m2 : 0u, (unsigned)p.GW, p.mGW, &gx);
+      pn2 = (int)fastdiv(t2, (unsigned)p.GH, p.mGH, &gy);
+      pby2 = (int)gy * p.sy;
+      pbx2 = (int)gx * p.sx;
+    }
   };
   auto load_g = [&](int i) {
     // columns past Ntot only exist in the last n tile of a padded Ntot: clamp the address, zero at the store stage
@@ -1067,17 +1139,33 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
     gv[i] = *reinterpret_cast<const f32x4*>(gbase + (ok ? goffB + 128u * i : 0u));
   };
   auto load_x = [&](int q) {
-    const int iy = pby + qdy[q], ix = pbx + qdx[q];
-    xok[q] = (int)rowvalid & (int)qlive[q] & (int)((unsigned)iy < (unsigned)p.IH) & (int)((unsigned)ix < (unsigned)p.IW);
-    unsigned off = (unsigned)((pn * qsn[q] + pby * qsh[q] + pbx * qsw[q] + g * 4) * 4 + qtapB[q]);
-    asm volatile("" : "+v"(off));            // keep the address arithmetic unconditional (no exec-masked region, no branch)
-    off = xok[q] ? off : 0u;
-    xv[q] = *reinterpret_cast<const f32x4*>(qbase[q] + off);
+    if (qscal[q]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = qst[q][e];
+        const int iy = pby2 + (int)(signed char)(d & 0xff), ix = pbx2 + (int)(signed char)((d >> 8) & 0xff);
+        const bool ok = (int)rowvalid2 & (int)(d >= 0) & (int)((unsigned)iy < (unsigned)p.IH) & (int)((unsigned)ix < (unsigned)p.IW);
+        unsigned off = (unsigned)((pn2 * qsn[q] + (iy >> qup[q]) * qsh[q] + (ix >> qup[q]) * qsw[q] + (d >> 16) * qsc[q]) * 4);
+        asm volatile("" : "+v"(off));
+        off = ok ? off : 0u;
+        const float v = *reinterpret_cast<const float*>(qbase[q] + off);
+        xv[q][e] = ok ? v : 0.f;
+      }
+      xok[q] = true;
+    } else {
+      const int tp = qtap[q];
+      const int iy = pby + (int)(short)(tp & 0xffff), ix = pbx + (tp >> 16);
+      xok[q] = (int)rowvalid & (int)qvec[q] & (int)((unsigned)iy < (unsigned)p.IH) & (int)((unsigned)ix < (unsigned)p.IW);
+      unsigned off = (unsigned)((pn * qsn[q] + (iy >> qup[q]) * qsh[q] + (ix >> qup[q]) * qsw[q]) * 4) + qoffB[q];
+      asm volatile("" : "+v"(off));            // keep the address arithmetic unconditional (no exec-masked region, no branch)
+      off = xok[q] ? off : 0u;
+      xv[q] = *reinterpret_cast<const f32x4*>(qbase[q] + off);
+    }
   };
   char* GsB = reinterpret_cast<char*>(Gs);
   char* XsB = reinterpret_cast<char*>(Xs);
   constexpr int GBUF = 32 * BNW * 4, XBUF = 32 * BKW * 4;
-  const int stG = (r * BNW + g * 4) * 4, stX = (r * BKW + g * 4) * 4;
+  const int stG = (r * BNW + g * 4) * 4, stX = (r * BKW + g * 4) * 4, stX2 = (r2 * BKW + g2 * 4) * 4;
   bool rowvalid_st = false;      // validity of the row whose data sits in gv/xv (snapshotted at load time)
   auto store_g = [&](int b, int i) {
     f32x4 v = gv[i];
@@ -1088,13 +1176,17 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
   };
   auto store_x = [&](int b, int q) {
     f32x4 v = xv[q];
+    if (qscal[q]) {
+      *reinterpret_cast<f32x4*>(XsB + b * XBUF + stX2 + q * 128) = v;      // zero fill already applied per element
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = v[e];
-      if constexpr (AFF) t = fmaxf(qfloor[q], fmaf(t, xsc[q][e], xsh[q][e]));
-      v[e] = xok[q] ? t : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        float t = v[e];
+        if constexpr (AFF) t = fmaxf(qfloor[q], fmaf(t, xsc[q][e], xsh[q][e]));
+        v[e] = xok[q] ? t : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(XsB + b * XBUF + stX + q * 128) = v;
     }
-    *reinterpret_cast<f32x4*>(XsB + b * XBUF + stX + q * 128) = v;
   };
 
   constexpr int NM = 16 * NI * KI;                 // MFMAs per 32-pixel step
@@ -1130,11 +1222,11 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
 #pragma unroll
     for (int j = 0; j < KI; ++j) fb[0][j] = *reinterpret_cast<const float*>(Xb + j * 128);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const int s2 = m / PS, ij = m % PS;
-      const int i = ij / KI, j = ij % KI;
-      const int cur = s2 & 1, nxt = cur ^ 1;
+    static_for<NM>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int s2 = m / PS, ij = m % PS;
+      constexpr int i = ij / KI, j = ij % KI;
+      constexpr int cur = s2 & 1, nxt = cur ^ 1;
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       // ---- side work of this slot
       if (m == 0) { decode_pixel(mnext); }
@@ -1158,7 +1250,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
         else if (it < NS) store_x(buf ^ 1, it - GR);
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     __syncthreads();
   }
 
@@ -1316,7 +1408,7 @@ static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
 
 template <int BNW, int WNn, int WKk>
 static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
-  if (p.wg_uniform && p.allvec && !getenv("DN_NO_U32"))
+  if (p.wg_uniform && !getenv("DN_NO_U32"))
     return p.any_affine ? launch_wgrad_u32<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_u32<BNW, WNn, WKk, false>(p, stream);
   return p.allvec ? launch_wgrad_v<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_v<BNW, WNn, WKk, false>(p, stream);
 }
@@ -1327,7 +1419,7 @@ static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
 // 92 % slot use wins (fewer splits = fewer partial slabs for wgrad_reduce_kernel).
 static void choose_splits(IgemmParams* p) {
   const int tiles = ((p->ph[0].nchunks + 3) / 4) * (p->Npad / p->BN);
-  const int per_cu = p->BN >= 128 ? 2 : (p->BN >= 64 ? 3 : 4);
+  const int per_cu = p->BN >= 128 ? 2 : 3;      // LDS (128-wide) resp. registers (narrower tiles) limit the blocks per CU
   const int slots = 256 * per_cu;
   int max_by_work = (p->M + 255) / 256;  // at least 8 steps of 32 pixels per split
   if (max_by_work < 1) max_by_work = 1;
@@ -1427,7 +1519,8 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
   }
   // the G operand must be float4-addressable with int32 offsets too
   if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0 && (long long)p.M * p.Ntot < (1ll << 31))) p.allvec = 0;
-  if (!p.allvec || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.wg_uniform = 0;
+  // the G operand must be float4-addressable with 32-bit BYTE offsets for the fast kernel
+  if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0) || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.wg_uniform = 0;
   hipStream_t s = as_stream(stream);
   switch (p.BN) {
     case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;

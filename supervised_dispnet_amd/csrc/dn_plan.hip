@@ -247,8 +247,18 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     if (p->in[i].vec && p->in[i].small && o.up == 0 && (o.C % 32 == 0 || o.C == 4 || o.C == 8 || o.C == 16)) ++n_fast;
     if (p->in[i].vec && p->in[i].small && o.up == 0 && o.C % 32 == 0) ++n_uniform;
   }
-  if (n_fast == 0 || p->reflect) p->uni32 = 0;
-  p->wg_uniform = (p->uni32 && n_uniform == p->n_in) ? 1 : 0;   // weight-gradient fast path: every chunk block-uniform
+  (void)n_fast;
+  if (p->reflect) p->uni32 = 0;
+  for (int i = 0; i < p->n_in; ++i)
+    if (!p->in[i].small) p->uni32 = 0;
+  // weight-gradient fast path: <= 32 taps, zero padding, every operand within 2 GiB; float4 operands of any C % 4 == 0,
+  // scalar operands only without a pending affine, taps within a signed byte
+  p->wg_uniform = (!p->reflect && p->ph[0].ntaps <= 32) ? 1 : 0;
+  for (int i = 0; i < p->n_in; ++i) {
+    const KOperand& o = p->in[i];
+    if (!o.small || (!o.vec && o.scale != nullptr) || o.C >= 32768) p->wg_uniform = 0;
+  }
+  (void)n_uniform;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;
