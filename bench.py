@@ -93,10 +93,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" IS RCCL on ROCm (xGMI); DN_DIST_BACKEND=gloo only exists to exercise this path with 2 ranks on ONE GPU
+        backend = os.environ.get("DN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__
     if rank == 0:
@@ -150,6 +156,10 @@ def main():
 
     # ---- instrumented steps (not part of `value`): HIP events around every implicit-GEMM launch
     roofline = None
+    if args.profile_steps > 0 and rank != 0:
+        for _ in range(args.profile_steps):      # the steps carry collectives: every rank takes them, rank 0 records
+            step()
+        torch.cuda.synchronize()
     if rank == 0 and args.profile_steps > 0:
         engine.PROFILE = []
         for _ in range(args.profile_steps):
@@ -173,7 +183,7 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         name, (fl, sec, n) = dom
         roofline = {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(name),
                     "launches_per_step": n // args.profile_steps, "avg_launch_ms": sec / n * 1e3,
                     "avg_launch_gflop": fl / n / 1e9,
                     "by_kernel": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / args.profile_steps * 1e3,
@@ -205,6 +215,21 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` (read + write) from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, corrected and calibrated as profiles/*pmc_traffic.json states), or None.
+    The counters cannot be collected from inside this process, so the latest committed summary is reported."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return (k["read_bytes"] + k["write_bytes"]) if k else None
+    except Exception:
+        return None
 
 
 def _quiet_init(net):

@@ -41,6 +41,7 @@ enum dn_status {
 
 int dn_version(void);                 /* ABI version, bumped on any signature/struct change */
 const char* dn_last_error(void);      /* thread-local, valid until the next failing call on this thread */
+const char* dn_last_kernel(void);     /* thread-local: name (as rocprofv3 prints it) of the main kernel the last conv-family call launched */
 int dn_device_arch_ok(void);          /* 1 if the current HIP device is gfx950, 0 otherwise, <0 on error */
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -46,6 +46,7 @@ _i32, _i64, _f, _d, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_
 SIGNATURES = {
     "dn_version": (C.c_int, []),
     "dn_last_error": (C.c_char_p, []),
+    "dn_last_kernel": (C.c_char_p, []),
     "dn_device_arch_ok": (C.c_int, []),
     "dn_conv_packed_weight_elems": (_i64, [_P(ConvDesc)]),
     "dn_conv_pack_weights": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),

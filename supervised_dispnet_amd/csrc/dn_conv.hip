@@ -1339,6 +1339,7 @@ static int launch_conv_v(const IgemmParams& p, hipStream_t stream) {
   if (rc != DN_OK) return rc;
   dim3 grid((p.M + BM - 1) / BM, p.Npad / BN, p.nphases);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  set_last_kernel("dn::igemm_conv_kernel<%d, %d, %d, %d, %s>", BM, BN, WM, WN, ALLVEC ? "true" : "false");
   return check_launch("igemm_conv_kernel");
 }
 
@@ -1350,6 +1351,7 @@ static int launch_conv_u32(const IgemmParams& p, hipStream_t stream) {
   if (rc != DN_OK) return rc;
   dim3 grid((p.M + BM - 1) / BM, p.Npad / BN, p.nphases);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  set_last_kernel("dn::igemm_conv_u32_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
   return check_launch("igemm_conv_u32_kernel");
 }
 
@@ -1392,6 +1394,7 @@ static int launch_wgrad_v(const IgemmParams& p, hipStream_t stream) {
   if (rc != DN_OK) return rc;
   dim3 grid((p.ph[0].nchunks + 3) / 4, p.Npad / BNW, p.splits);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  set_last_kernel("dn::igemm_wgrad_kernel<%d, %d, %d, %s>", BNW, WNn, WKk, ALLVEC ? "true" : "false");
   return check_launch("igemm_wgrad_kernel");
 }
 
@@ -1403,6 +1406,7 @@ static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
   if (rc != DN_OK) return rc;
   dim3 grid((p.ph[0].nchunks + 3) / 4, p.Npad / BNW, p.splits);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  set_last_kernel("dn::igemm_wgrad_u32_kernel<%d, %d, %d, %s>", BNW, WNn, WKk, AFF ? "true" : "false");
   return check_launch("igemm_wgrad_u32_kernel");
 }
 

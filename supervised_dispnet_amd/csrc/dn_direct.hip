@@ -182,6 +182,7 @@ int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
   const int LG = log2_exact(p.in[0].C / 4);
   const int px = 256 >> LG;
   hipLaunchKernelGGL(head_fwd_kernel, dim3((p.M + px - 1) / px), dim3(256), p.ph[0].ntaps * p.in[0].C * sizeof(float), stream, p, LG);
+  set_last_kernel("dn::head_fwd_kernel");
   return check_launch("head_fwd_kernel");
 }
 
@@ -197,6 +198,7 @@ int launch_head_dgrad(const IgemmParams& p, hipStream_t stream) {
   const int px = 256 >> LG;
   hipLaunchKernelGGL(head_dgrad_kernel, dim3((p.M + px - 1) / px), dim3(256), p.ph[0].ntaps * p.Ntot * sizeof(float), stream, p, LG,
                      p.ph[0].nchunks * kChunk);
+  set_last_kernel("dn::head_dgrad_kernel");
   return check_launch("head_dgrad_kernel");
 }
 
@@ -214,6 +216,7 @@ int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStre
   int blocks = (int)((npix + px - 1) / px);
   if (blocks > kHeadSlabs) blocks = kHeadSlabs;
   hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, p, LG, workspace);
+  set_last_kernel("dn::head_wgrad_kernel");
   int rc = check_launch("head_wgrad_kernel");
   if (rc != DN_OK) return rc;
   const int tot = p.ph[0].ntaps * p.in[0].C;

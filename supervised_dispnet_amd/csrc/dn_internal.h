@@ -9,6 +9,7 @@
 namespace dn {
 
 void set_error(const char* fmt, ...);
+void set_last_kernel(const char* fmt, ...);   // name (as rocprofv3 prints it) of the main kernel the last conv-family call launched
 int check_launch(const char* what);
 
 static inline hipStream_t as_stream(dn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -16,6 +16,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[160] = "";
+
+void set_last_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -276,9 +285,11 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 2; }
+int dn_version(void) { return 3; }
 
 const char* dn_last_error(void) { return dn::g_err; }
+
+const char* dn_last_kernel(void) { return dn::g_kernel; }
 
 int dn_device_arch_ok(void) {
   int dev = 0;

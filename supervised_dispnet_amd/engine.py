@@ -54,7 +54,8 @@ class _Timed(object):
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.tag))
+            launched = _lib.load().dn_last_kernel().decode(errors="replace")     # what the library actually ran (rocprofv3 name)
+            PROFILE.append((launched or self.name, self.flops, self.e0, self.e1, self.tag))
         return False
 
 
