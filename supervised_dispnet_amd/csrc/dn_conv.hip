@@ -226,7 +226,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmParams& p, f32x16 (&acc
       for (int w = 0; w < BM / WM; ++w) m2 += red[w * BN + tid];
       const int n = n0 + tid;
       if (n < p.Ntot) {
-        float* dst = p.bn_partial + ((long long)blockIdx.x * p.Ntot + n) * 2;
+        float* dst = p.bn_partial + ((long long)(m0 / BM) * p.Ntot + n) * 2;
         dst[0] = tot;
         dst[1] = m2;
       }
@@ -469,7 +469,14 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Hardware places block b on XCD b % 8 (each XCD has its own 4 MiB L2): XCD x takes the CONTIGUOUS
+  // range [x*per, (x+1)*per) of logical tiles, enumerated N-tile fastest, so the N tiles that re-read one A row block and
+  // the neighbouring row blocks that share its halo rows are resident on the same L2 at the same time.
+  const int MT = (p.M + BM - 1) / BM, NT = p.Npad / BN;
+  const int per = (MT * NT + 7) >> 3;
+  const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;      // grid is rounded up to a multiple of 8 (block-uniform exit)
+  const int m0 = (q / NT) * BM, n0 = (q % NT) * BN;
   const KPhase ph = p.ph[blockIdx.z];
   const int ntaps = ph.ntaps;
   const int Kp = ph.nchunks * kChunk;
@@ -644,6 +651,9 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
       cursor_advance();
       __syncthreads();
 
+      // (A variant with the store stage mid-iteration, the barrier right after the chunk's last fragment read and the next
+      //  chunk's first K group fetched under the last MFMAs measured the same 127-128 TFLOP/s: with two waves per SIMD the
+      //  partner wave already covers the LDS latency behind the barrier.  The simpler order is kept.)
       for (int c = 0; c < nch; ++c) {
         cursor_decode();                       // chunk min(c+1, nch-1); uses the tap word fetched during the previous iteration
 
@@ -655,30 +665,30 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
 #pragma unroll
         for (int jn = 0; jn < NI; ++jn) fb[0][jn] = *reinterpret_cast<const f32x4*>(Bb + jn * ROWS32);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-          const int kg = m / PK, q = m % PK;
-          const int kk = q / (MI * NI), ij = q % (MI * NI);
-          const int i = ij / NI, jn = ij % NI;
-          const int cur = kg & 1, nxt = cur ^ 1;
+        static_for<NM>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int kg = m / PK, q = m % PK;
+          constexpr int kk = q / (MI * NI), ij = q % (MI * NI);
+          constexpr int i = ij / NI, jn = ij % NI;
+          constexpr int cur = kg & 1, nxt = cur ^ 1;
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][kk], fb[cur][jn][kk], acc[i][jn], 0, 0, 0);
           // ---- side work of this slot
-          if (m < AR) load_a(m);
-          if (HA && m == AR) load_aff();
-          if (m >= AR + (HA ? 1 : 0) && m < AR + (HA ? 1 : 0) + BR) load_b(m - AR - (HA ? 1 : 0));
-          if (kg < 3 && q >= F0 && q < F0 + NF) {
-            const int f = q - F0;
-            if (f < MI) fa[nxt][f] = *reinterpret_cast<const f32x4*>(Ab + f * ROWS32 + (kg + 1) * 32);
+          if constexpr (m < AR) load_a(m);
+          if constexpr (HA && m == AR) load_aff();
+          if constexpr (m >= AR + (HA ? 1 : 0) && m < AR + (HA ? 1 : 0) + BR) load_b(m - AR - (HA ? 1 : 0));
+          if constexpr (kg < 3 && q >= F0 && q < F0 + NF) {
+            constexpr int f = q - F0;
+            if constexpr (f < MI) fa[nxt][f] = *reinterpret_cast<const f32x4*>(Ab + f * ROWS32 + (kg + 1) * 32);
             else fb[nxt][f - MI] = *reinterpret_cast<const f32x4*>(Bb + (f - MI) * ROWS32 + (kg + 1) * 32);
           }
-          if (m == (PK + 1 > AR + 1 + BR ? PK + 1 : AR + 1 + BR)) cursor_advance();   // after this chunk's loads are issued
-          if (m >= S0 && (m - S0) % SSTEP == 0) {
-            const int it = (m - S0) / SSTEP;
-            if (it < AR) store_a(buf ^ 1, it);
-            else if (it < NS) store_b(buf ^ 1, it - AR);
+          if constexpr (m == (PK + 1 > AR + 1 + BR ? PK + 1 : AR + 1 + BR)) cursor_advance();   // after this chunk's loads are issued
+          if constexpr (m >= S0 && (m - S0) % SSTEP == 0) {
+            constexpr int it = (m - S0) / SSTEP;
+            if constexpr (it < AR) store_a(buf ^ 1, it);
+            else if constexpr (it < NS) store_b(buf ^ 1, it - AR);
           }
           __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         __syncthreads();
         buf ^= 1;
       }
@@ -1037,10 +1047,17 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WAVES_K, wk = wave % WAVES_K;
-  const int kt = blockIdx.x, n0 = blockIdx.y * BNW;
   const KPhase ph = p.ph[0];
   const int ntaps = ph.ntaps, nchunks = ph.nchunks, Kp = nchunks * kChunk;
-  const int m_begin = blockIdx.z * p.m_per_split;
+  // XCD-aware order (see igemm_conv_u32_kernel): the k tiles and n tiles of ONE pixel split are consecutive logical tiles
+  // on one XCD, so they run side by side on one L2 and the split's G / X pixels come over the fabric once, not once per tile.
+  const int KT = (nchunks + 3) / 4, NTn = p.Npad / BNW;
+  const int total = KT * NTn * p.splits;
+  const int per = (total + 7) >> 3;
+  const int lq = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || lq >= total) return;
+  const int kt = lq % KT, n0 = ((lq / KT) % NTn) * BNW, split = lq / (KT * NTn);
+  const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int g = tid & 7, r = tid >> 3;      // float4 staging: row r of the 32-pixel step, K group g
   const int g2 = tid >> 5, r2 = tid & 31;   // scalar-chunk staging: pixel-major (lanes = consecutive pixels), K group g2
@@ -1254,7 +1271,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
     __syncthreads();
   }
 
-  float* ws = p.ws + (long long)blockIdx.z * p.Npad * Kp;
+  float* ws = p.ws + (long long)split * p.Npad * Kp;
 #pragma unroll
   for (int j = 0; j < KI; ++j) {
     const int k = kt * BKW + wk * WKk + j * 32 + (lane & 31);
@@ -1349,7 +1366,8 @@ static int launch_conv_u32(const IgemmParams& p, hipStream_t stream) {
   auto kernel = igemm_conv_u32_kernel<BM, BN, WM, WN>;
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
-  dim3 grid((p.M + BM - 1) / BM, p.Npad / BN, p.nphases);
+  const int tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+  dim3 grid((tiles + 7) / 8 * 8, 1, p.nphases);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::igemm_conv_u32_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
   return check_launch("igemm_conv_u32_kernel");
@@ -1404,7 +1422,8 @@ static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
   auto kernel = igemm_wgrad_u32_kernel<BNW, WNn, WKk, AFF>;
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
-  dim3 grid((p.ph[0].nchunks + 3) / 4, p.Npad / BNW, p.splits);
+  const int total = ((p.ph[0].nchunks + 3) / 4) * (p.Npad / BNW) * p.splits;
+  dim3 grid((total + 7) / 8 * 8);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::igemm_wgrad_u32_kernel<%d, %d, %d, %s>", BNW, WNn, WKk, AFF ? "true" : "false");
   return check_launch("igemm_wgrad_u32_kernel");
