@@ -1397,9 +1397,14 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     if (head_fwd_eligible(d, p)) return launch_head_fwd(p, s);
     if (head_dgrad_eligible(d, p)) return launch_head_dgrad(p, s);
   }
+  // Few row tiles (the 4x13 / 8x26 decoder levels at b32: 13-52 tiles of 128 rows) leave most of the 256 CUs without a block;
+  // 64-row tiles double the block count at the same per-wave MFMA density along N.  Not with batch statistics: the
+  // bn_partial layout is per 128-row tile.
+  const long long blocks128 = (long long)((p.M + 127) / 128) * (p.Npad / p.BN) * p.nphases;
+  const bool small_m = p.uni32 && p.bn_partial == nullptr && blocks128 <= 208 && !getenv("DN_NO_BM64");
   switch (p.BN) {
-    case 128: return launch_conv<128, 128, 64, 64>(p, s);
-    case 64: return launch_conv<128, 64, 64, 32>(p, s);
+    case 128: return small_m ? launch_conv_u32<64, 128, 32, 64>(p, s) : launch_conv<128, 128, 64, 64>(p, s);
+    case 64: return small_m ? launch_conv_u32<64, 64, 32, 32>(p, s) : launch_conv<128, 64, 64, 32>(p, s);
     default: return launch_conv<128, 32, 32, 32>(p, s);
   }
 }

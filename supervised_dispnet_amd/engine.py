@@ -353,18 +353,19 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
             _lib.call("dn_upsample2x_nearest_bwd_nhwc", cur.data_ptr(), N, a.H, a.W, a.C, a.grad.data_ptr(), 0 if first else 1, _stream())
 
 
-def colsum(partial, rows, Cn, stride=1, offset=0):
-    out = torch.empty(Cn, dtype=torch.float32, device=partial.device)
+def colsum(partial, rows, Cn, stride=1, offset=0, out=None):
+    if out is None:
+        out = torch.empty(Cn, dtype=torch.float32, device=partial.device)
     _lib.call("dn_colsum_finalize", partial.data_ptr(), rows, Cn, stride, offset, out.data_ptr(), _stream())
     return out
 
 
-def act_bwd(g, y_post, act, p0, p1, rows, Cn):
-    """g <- g * act'(y_post) in place; returns the bias gradient (column sums of the result)."""
+def act_bwd(g, y_post, act, p0, p1, rows, Cn, out=None):
+    """g <- g * act'(y_post) in place; returns the bias gradient (column sums of the result), written into `out` if given."""
     nblk = _lib.load().dn_reduce_blocks(rows, Cn)
     partial = torch.empty((nblk, Cn), dtype=torch.float32, device=g.device)
     _lib.call("dn_act_bwd_reduce", g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn, partial.data_ptr(), _stream())
-    return colsum(partial, nblk, Cn)
+    return colsum(partial, nblk, Cn, out=out)
 
 
 class GradSink:
@@ -391,6 +392,20 @@ class GradSink:
                 GradSink.reducer.grad_ready(param)
         else:
             self.grads[id(param)] = g
+
+    def put_zero(self, param):
+        """A gradient that is identically zero.  An arena slice that nothing ever writes stays at its initial zeros, so with
+        an arena this is bookkeeping only (no fill launch every step)."""
+        dst = getattr(param, "_dn_grad_view", None)
+        if dst is not None:
+            if not getattr(param, "_dn_zero_grad_slot", False):
+                dst.zero_()
+                param._dn_zero_grad_slot = True
+            self.grads[id(param)] = None
+            if GradSink.reducer is not None:
+                GradSink.reducer.grad_ready(param)
+        else:
+            self.grads[id(param)] = torch.zeros_like(param)
 
     def get(self, param):
         return self.grads.get(id(param))
@@ -435,8 +450,13 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
                 y.partial_rows = nblk
                 _lib.call("dn_bn_relu_bwd_reduce", g.data_ptr(), y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(),
                           y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn, y.partial.data_ptr(), _stream())
-            dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
+            # written straight into the optimizer arena's gradient slices when there is one (no copy launches)
+            dgamma = sink.dest(bn.weight)
+            dbeta = sink.dest(bn.bias)
+            if dgamma is None:
+                dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
+            if dbeta is None:
+                dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
             _lib.call("dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(),
                       bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn,
                       dgamma.data_ptr(), dbeta.data_ptr(), _stream())
@@ -447,7 +467,7 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
         # g is now dL/d(conv output).  The conv bias sits in front of a BatchNorm: its gradient is identically zero in
         # exact arithmetic (BN removes the mean); the reference's value is rounding noise.  We store exact zeros.
         if layer.m.bias is not None:
-            sink.put(layer.m.bias, torch.zeros(Cn, dtype=torch.float32, device=dev))
+            sink.put_zero(layer.m.bias)
         sink.put(layer.m.weight, conv_wgrad(layer, [x_piece], g, (OH, OW), out=sink.dest(layer.m.weight)))
         conv_dgrad(layer, g, xa.N, OH, OW, [x_piece], (xa.H, xa.W))
         y.grad = None
@@ -504,7 +524,7 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
         if y.grad is None:
             return
         g = y.grad
-        db = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout)
+        db = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout, out=sink.dest(layer.m.bias) if layer.m.bias is not None else None)
         if layer.m.bias is not None:
             sink.put(layer.m.bias, db)
         sink.put(layer.m.weight, conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight)))
