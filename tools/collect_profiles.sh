@@ -1,0 +1,9 @@
+#!/bin/bash
+# Copy the judged summaries of a gpu_profile_round.sh run from gpurun_out/ (scratch) into profiles/ (tracked).
+# usage: bash tools/collect_profiles.sh <tag>
+tag=${1:?tag}
+cp gpurun_out/bench_$tag.json profiles/${tag}_bench.json
+grep -v amdgpu.ids gpurun_out/bench_$tag.err > profiles/${tag}_per_layer.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --profile-steps 0 --no-cpu-baseline (7 steps, Disp_vgg_BN b32 128x416)"; head -45 gpurun_out/prof_$tag/${tag}_kernel_stats.csv; } > profiles/${tag}_kernel_stats.csv
+[ -f gpurun_out/pmc_${tag}_traffic.json ] && cp gpurun_out/pmc_${tag}_traffic.json profiles/${tag}_pmc_traffic.json
+ls -la profiles | grep $tag
