@@ -1397,6 +1397,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     if (head_fwd_eligible(d, p)) return launch_head_fwd(p, s);
     if (head_dgrad_eligible(d, p)) return launch_head_dgrad(p, s);
   }
+  if (wino_eligible(d, p)) return launch_wino_conv(p, s);
   // Few row tiles (the 4x13 / 8x26 decoder levels at b32: 13-52 tiles of 128 rows) leave most of the 256 CUs without a block;
   // 64-row tiles double the block count at the same per-wave MFMA density along N.  Not with batch statistics: the
   // bn_partial layout is per 128-row tile.
@@ -1481,6 +1482,7 @@ int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed,
   int rc = build_plan(d, false, &p);
   if (rc != DN_OK) return rc;
   DN_REQUIRE(w != nullptr && w_packed != nullptr, DN_ERR_BAD_ARG, "null weight pointer");
+  if (wino_eligible(d, p)) return launch_wino_pack(p, w, w_packed, as_stream(stream));
   const KPhase& last = p.ph[p.nphases - 1];
   const long long total = last.w_off + (long long)p.Npad * last.nchunks * kChunk;
   if (total == 0) return DN_OK;

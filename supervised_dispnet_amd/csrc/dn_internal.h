@@ -88,6 +88,9 @@ struct IgemmParams {
   int wg_uniform;                // every operand: C % 32 == 0, float4-addressable, no upsample (weight-gradient fast path)
   int any_affine;                // some operand carries a pending BN-apply + ReLU
   int reflect;                   // gather with ReflectionPad2d index mapping instead of zero fill
+  // Winograd F(2x2,3x3) launches only (dn_winograd.hip)
+  int T, TH, TW;                 // 2x2 output tiles: total, per image column / row
+  unsigned mTW, mTH;             // fastdiv magics
 };
 
 // floor(n / d) for 0 <= n < 2^31 with a precomputed magic (see fastdiv_magic); branch-free
@@ -114,5 +117,11 @@ int launch_head_dgrad(const IgemmParams& p, hipStream_t stream);
 bool head_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
 size_t head_wgrad_workspace_bytes(const IgemmParams& p);
 int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStream_t stream);
+
+// dn_winograd.hip: Winograd F(2x2,3x3) forward / input-gradient of the 3x3 stride-1 pad-1 layers with 16-aligned channels
+bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p);
+long long wino_packed_elems(const IgemmParams& p);
+int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream);
+int launch_wino_conv(IgemmParams& p, hipStream_t stream);
 
 }  // namespace dn

@@ -308,6 +308,7 @@ int dn_device_arch_ok(void) {
 int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (dn::build_plan(d, false, &p) != DN_OK) return -1;
+  if (dn::wino_eligible(d, p)) return dn::wino_packed_elems(p);
   const dn::KPhase& last = p.ph[p.nphases - 1];
   return last.w_off + (int64_t)p.Npad * last.nchunks * dn::kChunk;
 }

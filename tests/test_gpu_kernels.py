@@ -59,6 +59,9 @@ CONV_CASES = [
     ("3x3_64_64",         (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 12, 20, ACT_NONE, False),
     ("3x3_first_nchw",    (3,),         (False,),          64, 3, 1, 1, False, 0, 2, 16, 24, ACT_NONE, False),
     ("3x3_128_256_bnload", (128,),      (False,),          256, 3, 1, 1, False, 0, 2, 8, 12, ACT_NONE, True),
+    ("3x3_wino_cat",      (32, 64),     (False, False),    96, 3, 1, 1, False, 0, 3, 10, 14, ACT_LEAKY, False),
+    ("3x3_wino_cat_aff",  (64, 16),     (False, False),    64, 3, 1, 1, False, 0, 2, 6, 10, ACT_RELU, True),
+    ("3x3_wino_512",      (512,),       (False,),          128, 3, 1, 1, False, 0, 1, 8, 26, ACT_NONE, False),
     ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
     ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
     ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
@@ -139,7 +142,8 @@ def test_conv_family_fwd_bwd(case):
         close(name + ":dx%d" % i, nchw(pc.act.grad), t.grad, rtol=5e-4, atol_rel=5e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 12, 3, 64, 64), (2, 16, 8, 64, 128, 128)], ids=["c3_64_64", "c64_128_128"])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 3, 64, 64), (2, 16, 8, 64, 128, 128), (3, 10, 14, 16, 64, 96)],
+                         ids=["c3_64_64", "c64_128_128", "c16_64_96_ragged"])
 def test_conv_bn_pool_block(shape):
     """conv -> BN(train) -> ReLU -> conv -> BN -> ReLU -> MaxPool, forward + full backward vs torch modules (CPU)."""
     N, H, W, c0, c1, c2 = shape
@@ -181,6 +185,35 @@ def test_conv_bn_pool_block(shape):
     # conv bias in front of BN: exact zeros here, rounding noise in the reference
     assert float(sink.get(dev_mods[0].bias).abs().max()) == 0.0
     assert float(ref[0].bias.grad.abs().max()) < 1e-4
+
+
+def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
+    """3x3/s1/p1 layers with 16-aligned channels run dn::wino_conv_kernel (forward and input gradient); the same call with
+    DN_NO_WINOGRAD=1 runs the direct implicit GEMM: both agree to fp32 round-off (F(2x2,3x3) has the same error level)."""
+    torch.manual_seed(4)
+    N, H, W, cin, cout = 2, 12, 20, 64, 128
+    mod = nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+    x = torch.randn(N, H, W, cin, device=DEV)
+    dy = torch.randn(N, H, W, cout, device=DEV)
+    res = {}
+    for tag, env in (("wino", None), ("direct", "1")):
+        if env is None:
+            monkeypatch.delenv("DN_NO_WINOGRAD", raising=False)
+        else:
+            monkeypatch.setenv("DN_NO_WINOGRAD", env)
+        engine.bump_param_epoch()
+        layer = engine.ConvLayer(mod)
+        xa = engine.Act(x.clone(), N, H, W, cin)
+        y, _, _ = engine.conv_forward(layer, [engine.Piece(xa)], ACT_LEAKY, 0.1, 0.0)
+        kf = _lib.load().dn_last_kernel().decode()
+        engine.conv_dgrad(layer, dy, N, H, W, [engine.Piece(xa)], (H, W))
+        kd = _lib.load().dn_last_kernel().decode()
+        torch.cuda.synchronize()
+        res[tag] = (y, xa.grad, kf, kd)
+    assert "wino_conv_kernel" in res["wino"][2] and "wino_conv_kernel" in res["wino"][3]
+    assert "igemm" in res["direct"][2] and "igemm" in res["direct"][3]
+    close("wino_vs_direct:y", res["wino"][0], res["direct"][0], rtol=1e-4, atol_rel=1e-5)
+    close("wino_vs_direct:dx", res["wino"][1], res["direct"][1], rtol=1e-4, atol_rel=1e-5)
 
 
 def test_bilinear_up2_matches_interpolate():
