@@ -31,11 +31,19 @@ namespace dn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <class F, int... I>
+__device__ __forceinline__ void wino_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  wino_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 constexpr int WBT = 64;            // tiles per block
 constexpr int WBN = 64;            // output channels per block
 constexpr int WKC = 16;            // channels per staged chunk (two 8-k MFMA groups)
 constexpr int WZLD = 72;           // padded row (floats) of the cross-wave exchange tile: rows 4 apart land 32 banks apart
-constexpr size_t kWinoLds = (size_t)2 * 2 * 16 * WBT * 8 * sizeof(float);   // A ring: [buf][sub][pos][tile][8] = 128 KiB
 
 __device__ __forceinline__ float wino_act(float v, int act, float p0, float p1) {
   switch (act) {
@@ -56,6 +64,12 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (p.nphases != 1 || p.ph[0].ntaps != 9) return false;
   if (p.Ntot < 64 || (p.Ntot & 3)) return false;
   if ((long long)p.M * 4 >= (1ll << 31)) return false;
+  {
+    // a block always computes 64 tiles x 64 output channels: not worth it (and not better than the direct kernel's 64-row tiles)
+    // when padding eats the 2.25x, e.g. the 12-tile deep layers of a 64x96 test image
+    const long long T = p.M / 4, Tpad = (T + WBT - 1) / WBT * WBT, Npad = (p.Ntot + WBN - 1) / WBN * WBN;
+    if (T * p.Ntot * 10 < Tpad * Npad * 6) return false;
+  }
   for (int i = 0; i < p.n_in; ++i) {
     const KOperand& o = p.in[i];
     if (!o.vec || !o.small || o.up != 0 || (o.C % WKC) != 0) return false;
@@ -77,7 +91,8 @@ static int wino_ktot(const IgemmParams& p) {
 
 static int wino_npad(const IgemmParams& p) { return (p.Ntot + WBN - 1) / WBN * WBN; }
 
-long long wino_packed_elems(const IgemmParams& p) { return (long long)wino_ktot(p) * wino_npad(p) * 16; }
+// + one 16-channel chunk of slack: the kernel's B stream prefetches three steps past the last one
+long long wino_packed_elems(const IgemmParams& p) { return (long long)(wino_ktot(p) + WKC) * wino_npad(p) * 16; }
 
 // ------------------------------------------------------------------------------------------------ weight transform
 // wp[k/8][pos][n/32][lane][e] = U_pos[n][k],  k = 8*(k/8) + 4*(lane >> 5) + e,  n = 32*(n/32) + (lane & 31):  exactly the
@@ -91,7 +106,7 @@ __global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ 
     const int pos = (int)(rest & 15), kc8 = (int)(rest >> 4);
     const int k = kc8 * 8 + (lane >> 5) * 4 + e, n = nsub * 32 + (lane & 31);
     float u = 0.f;
-    if (n < p.Ntot) {
+    if (n < p.Ntot && k < (p.n_is_dim0 ? p.D1 : p.D0)) {       // (the slack chunk past the last k is zeros)
       float g[3][3];
       const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + k) : ((long long)k * p.D1 + n)) * 9;
 #pragma unroll
@@ -127,22 +142,55 @@ int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------ the convolution
-__global__ void __launch_bounds__(256, 1) wino_conv_kernel(const IgemmParams p) {
+// What the matrix pipe shares (measured, tools/ubench/mfma_issue.hip): v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 FMA
+// lanes, so every vector instruction a SIMD issues -- from this wave or from its partner -- takes its cycles away from the
+// MFMAs (~2.4 cycles per plain fp32 op, ~8 per VOP3 v_cndmask with an SGPR mask, 13-27 per LDS store / global load).  Only
+// LATENCY overlaps (memory, LDS, barriers), and only with a second wave on the SIMD.  Hence: as few vector instructions
+// per MFMA as possible (hardware zero fill through buffer descriptors instead of select, no masking after the fact unless a
+// BatchNorm is pending), conflict-free LDS rows, and two tile heights:
+//   MTW = 2 : 64 tiles per block, 256 accumulator registers, one block per CU (least L2 traffic per MFMA),
+//   MTW = 1 : 32 tiles per block, 128 accumulator registers, two blocks per CU (a partner wave covers the stalls and one
+//             block's epilogue runs under the other's main loop).
+template <int MTW>
+struct WinoCfg {
+  static constexpr int BT = 32 * MTW;                 // tiles per block
+  static constexpr int HALFB = BT * 16 + 32;          // bytes of one [tile][4 k] plane (+8 banks)
+  static constexpr int POSB = 2 * HALFB;              // one position: k 0-3 plane, k 4-7 plane
+  static constexpr int SUBB = 16 * POSB + 64;         // one 8-k group: 16 positions (+16 banks)
+  static constexpr int BUFB = 2 * SUBB;               // one 16-channel chunk
+  static constexpr size_t LDS = (size_t)2 * BUFB;     // double-buffered ring
+};
+
+__device__ __forceinline__ f32x4 buffer_load_x4(__amdgpu_buffer_rsrc_t r, int voffset) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, 0, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+template <int MTW, bool HA, int DBG>
+__global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const IgemmParams p) {
+  using Cfg = WinoCfg<MTW>;
+  constexpr int BT = Cfg::BT, HALFB = Cfg::HALFB, POSB = Cfg::POSB, SUBB = Cfg::SUBB, BUFB = Cfg::BUFB;
   extern __shared__ __align__(16) float smem[];
+  char* smemB = reinterpret_cast<char*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order (see igemm_conv_u32_kernel): contiguous logical tile ranges per XCD, N tile fastest
-  const int MT = (p.T + WBT - 1) / WBT, NT = p.Npad / WBN;
+  const int MT = (p.T + BT - 1) / BT, NT = p.Npad / WBN;
   const int per = (MT * NT + 7) >> 3;
   const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;
   const int mb = q / NT, nb = q % NT;
+  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  if (DBG & 4) t0 = clock64();
 
-  // ---- staging role: one 4x4 patch of 4 channels per thread and chunk
-  const int st_tile = tid >> 2, cg = tid & 3;
+  // ---- staging role: one 4x4 patch of 4 channels per thread and chunk.  MTW == 1 has 128 patches per chunk: waves {0,1}
+  //      stage the even chunks, waves {2,3} the odd ones.
+  const int st_tile = MTW == 2 ? (tid >> 2) : ((tid & 127) >> 2), cg = tid & 3;
+  const int my_parity = MTW == 2 ? 0 : (wave >> 1);
   unsigned pmask = 0;            // bit 4a+b: patch pixel (a, b) lies inside the image (and the tile exists)
   int pn, py, px;
   {
-    const int t = mb * WBT + st_tile;
+    const int t = mb * BT + st_tile;
     unsigned tx, ty;
     const unsigned r = fastdiv_dev(t < p.T ? (unsigned)t : 0u, (unsigned)p.TW, p.mTW, &tx);
     pn = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
@@ -154,199 +202,224 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(const IgemmParams p) 
       for (int b = 0; b < 4; ++b)
         pmask |= (t < p.T && (unsigned)(py + a) < (unsigned)p.IH && (unsigned)(px + b) < (unsigned)p.IW) ? (1u << (4 * a + b)) : 0u;
   }
-  int rowoffB[DN_MAX_OPERANDS];   // byte offset of patch pixel (0,0), channel 4*cg, per operand
-#pragma unroll
-  for (int s = 0; s < DN_MAX_OPERANDS; ++s) {
-    const KOperand& S = p.in[s < p.n_in ? s : 0];
-    rowoffB[s] = (pn * (int)S.sn + py * (int)S.sh + px * (int)S.sw + cg * 4) * 4;
-  }
 
-  // total chunks over the concatenated K axis
-  int nchunks = 0;
-  for (int s = 0; s < p.n_in; ++s) nchunks += p.in[s].C / WKC;
-
-  // load cursor: (operand ls, chunk lc within it)
-  int ls = 0, lc = 0;
-  f32x4 v[16];
-  f32x4 sc4, sh4;
-  float relu_floor = 0.f;
-  auto load_patch = [&]() {
-    const KOperand& S = p.in[ls];
-    const char* base = reinterpret_cast<const char*>(S.p);
-    const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
-    const int off0 = (ls == 0 ? rowoffB[0] : (ls == 1 ? rowoffB[1] : rowoffB[2])) + lc * (WKC * 4);
-    const bool has_aff = S.scale != nullptr;
-    const int coff = (lc * WKC + cg * 4) * 4;
-    const f32x4 l1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.scale : S.p) + (has_aff ? coff : 0));
-    const f32x4 l2 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(has_aff ? S.shift : S.p) + (has_aff ? coff : 0));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sc4[e] = has_aff ? l1[e] : 1.f;
-      sh4[e] = has_aff ? l2[e] : 0.f;
-    }
-    relu_floor = has_aff ? 0.f : -__builtin_huge_valf();
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const bool ok = (pmask >> (4 * a + b)) & 1u;
-        const int off = ok ? off0 + a * shB + b * swB : 0;
-        v[4 * a + b] = *reinterpret_cast<const f32x4*>(base + off);
-      }
-  };
-  auto advance_cursor = [&]() {     // clamps on the last chunk (the final iteration re-fetches it into the idle buffer)
-    const int nch = p.in[ls].C / WKC;
-    const bool last_of_op = lc + 1 == nch;
-    const bool last = last_of_op && (ls + 1 == p.n_in);
-    lc = last ? lc : (last_of_op ? 0 : lc + 1);
-    ls = (!last && last_of_op) ? ls + 1 : ls;
-  };
-  // BatchNorm-apply + ReLU (or identity), zero halo, B^T d B, 16 float4 into LDS
-  auto transform_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const bool ok = (pmask >> i) & 1u;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = fmaxf(relu_floor, fmaf(v[i][e], sc4[e], sh4[e]));
-        v[i][e] = ok ? t : 0.f;
-      }
-    }
-    f32x4 r[16];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {       // rows: B^T d
-      r[0 + b] = v[0 + b] - v[8 + b];
-      r[4 + b] = v[4 + b] + v[8 + b];
-      r[8 + b] = v[8 + b] - v[4 + b];
-      r[12 + b] = v[4 + b] - v[12 + b];
-    }
-    float* dst = smem + (size_t)((buf * 2 + (cg >> 1)) * 16) * (WBT * 8) + st_tile * 8 + (cg & 1) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {       // columns: (B^T d) B
-      const f32x4 c0 = r[4 * i + 0] - r[4 * i + 2];
-      const f32x4 c1 = r[4 * i + 1] + r[4 * i + 2];
-      const f32x4 c2 = r[4 * i + 2] - r[4 * i + 1];
-      const f32x4 c3 = r[4 * i + 1] - r[4 * i + 3];
-      *reinterpret_cast<f32x4*>(dst + (4 * i + 0) * (WBT * 8)) = c0;
-      *reinterpret_cast<f32x4*>(dst + (4 * i + 1) * (WBT * 8)) = c1;
-      *reinterpret_cast<f32x4*>(dst + (4 * i + 2) * (WBT * 8)) = c2;
-      *reinterpret_cast<f32x4*>(dst + (4 * i + 3) * (WBT * 8)) = c3;
-    }
-  };
-
-  // ---- B fragments straight from the packed weights
-  const int NS = p.Npad / 32;
-  const float* wbase = p.w + ((size_t)(4 * wave) * NS + 2 * nb) * 256 + lane * 4;   // + kc8 * 16*NS*256 + j * NS*256 + nn * 256
-  const size_t wstep8 = (size_t)16 * NS * 256;
-  f32x4 breg[2][4][2];
-  auto load_b = [&](int which, int kc8) {
-    const float* wsrc = wbase + (size_t)kc8 * wstep8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int nn = 0; nn < 2; ++nn) breg[which][j][nn] = *reinterpret_cast<const f32x4*>(wsrc + ((size_t)j * NS + nn) * 256);
-  };
-
-  f32x16 acc[4][2][2];
+  f32x16 acc[4][MTW][2];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][m][nn][e] = 0.f;
 
-  const int frA = ((4 * wave) * WBT + (lane & 31)) * 8 + (lane >> 5) * 4;   // + (buf*2+sub)*16*WBT*8 + j*WBT*8 + m*32*8
-  auto compute = [&](int buf, int sub, int which) {
-    const float* Ab = smem + (size_t)((buf * 2 + sub) * 16) * (WBT * 8) + frA;
+  // B fragments straight from the packed weights: wcur -> this wave's slice of the current 16-k chunk
+  const int NS = p.Npad / 32;
+  const char* wcur = reinterpret_cast<const char*>(p.w + ((size_t)(4 * wave) * NS + 2 * nb) * 256 + lane * 4);
+  const size_t wstep8B = (size_t)16 * NS * 1024;        // bytes per 8-k group (all 16 positions, all couts)
+  const unsigned wjB = (unsigned)NS * 1024u;            // bytes between two positions j of one 8-k group
+  // B ring: the fragments of (8-k group, position j) step g live in breg[g & 3] and are requested three steps (24 / 48 MFMAs)
+  // ahead; the stream runs on across chunks and operands (the packed buffer carries one chunk of slack at its end)
+  f32x4 breg[4][2];
+  auto load_b = [&](int slot) {
+    breg[slot][0] = *reinterpret_cast<const f32x4*>(wcur);
+    breg[slot][1] = *reinterpret_cast<const f32x4*>(wcur + 1024);
+  };
+  auto advance_b = [&](int j_loaded) { wcur += j_loaded == 3 ? wstep8B - 3 * (size_t)wjB : (size_t)wjB; };
+  load_b(0);
+  advance_b(0);
+  load_b(1);
+  advance_b(1);
+  load_b(2);
+  advance_b(2);
+  const int stA = (cg >> 1) * SUBB + (cg & 1) * HALFB + st_tile * 16;         // staging store offset in a buffer (+ pos * POSB)
+  const int frA = (4 * wave) * POSB + (lane >> 5) * HALFB + (lane & 31) * 16;  // fragment read offset in an 8-k group
+
+  // slot schedule (compile-time): NSL slots per 16-channel chunk, one MFMA each; H = first slot of the second 8-k group
+  constexpr int NSL = 64 * MTW, H = NSL / 2, GRP = 8 * MTW;     // GRP = MFMAs per (8-k group, position j)
+  constexpr int S_V = 1, S_AFF = 17, S_T = H + 8;   // patch loads | scale/shift | transform + LDS stores
+  constexpr int ROWS_AT = S_T + 16, COLS_AT = ROWS_AT + 4;
+  constexpr int COLS_PER_SLOT = (NSL - COLS_AT) >= 8 ? 1 : 2;
+
+  int buf = 0, gchunk = 0;       // gchunk: chunk counter over the whole concatenated K axis (staging parity for MTW == 1)
+  for (int s = 0; s < p.n_in; ++s) {
+    const KOperand& S = p.in[s];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+    const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
+    const int nch = S.C / WKC;
+    const int off0 = (pn * (int)S.sn + py * (int)S.sh + px * (int)S.sw + cg * 4) * 4;
+    const bool op_aff = S.scale != nullptr;
+    const char* scp = reinterpret_cast<const char*>(op_aff ? S.scale : S.p) + (op_aff ? cg * 16 : 0);
+    const char* shp = reinterpret_cast<const char*>(op_aff ? S.shift : S.p) + (op_aff ? cg * 16 : 0);
+    f32x4 v[16], sc4, sh4, fa[2][MTW];
+    float relu_floor = 0.f;
+    int cnB = 0;                       // byte offset (channels) of the chunk whose loads are issued next
+
+    auto load_v = [&](int i) {
+      const int a = i >> 2, b = i & 3;
+      const bool ok = (pmask >> i) & 1u;
+      int off = off0 + cnB + a * shB + b * swB;
+      asm volatile("" : "+v"(off));
+      off = ok ? off : -1;                               // past num_records: the buffer load returns zeros
+      v[i] = buffer_load_x4(rsrc, off);
+    };
+    auto load_aff = [&]() {
+      if constexpr (HA) {
+        const f32x4 l1 = *reinterpret_cast<const f32x4*>(scp + (op_aff ? cnB : 0));
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(shp + (op_aff ? cnB : 0));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + j * (WBT * 8));
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + j * (WBT * 8) + 32 * 8);
+        for (int e = 0; e < 4; ++e) {                     // an operand without a pending BatchNorm: identity, no floor
+          sc4[e] = op_aff ? l1[e] : 1.f;
+          sh4[e] = op_aff ? l2[e] : 0.f;
+        }
+        relu_floor = op_aff ? 0.f : -__builtin_huge_valf();
+      }
+    };
+    auto affine_piece = [&](int i) {
+      if constexpr (HA) {
+        const float fm = (float)((pmask >> i) & 1u);      // a pending BatchNorm makes relu(shift) out of a zero-filled pixel
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        acc[j][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], breg[which][j][0][kk], acc[j][0][0], 0, 0, 0);
-        acc[j][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], breg[which][j][1][kk], acc[j][0][1], 0, 0, 0);
-        acc[j][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], breg[which][j][0][kk], acc[j][1][0], 0, 0, 0);
-        acc[j][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], breg[which][j][1][kk], acc[j][1][1], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(relu_floor, fmaf(v[i][e], sc4[e], sh4[e])) * fm;
+      }
+    };
+    auto row_piece = [&](int b) {                      // B^T d, in place: rows (0,1,2,3) <- (d0-d2, d1+d2, d2-d1, d1-d3)
+      const f32x4 d0 = v[0 + b], d1 = v[4 + b], d2 = v[8 + b];
+      v[0 + b] = d0 - d2;
+      v[4 + b] = d1 + d2;
+      v[8 + b] = d2 - d1;
+      v[12 + b] = d1 - v[12 + b];
+    };
+    auto col_piece = [&](int b2, int i, int half) {    // (B^T d) B and the LDS stores of transform row i
+      char* dst = smemB + b2 * BUFB + stA + (4 * i) * POSB;
+      if (half == 0) {
+        *reinterpret_cast<f32x4*>(dst + 0 * POSB) = v[4 * i + 0] - v[4 * i + 2];
+        *reinterpret_cast<f32x4*>(dst + 1 * POSB) = v[4 * i + 1] + v[4 * i + 2];
+      } else {
+        *reinterpret_cast<f32x4*>(dst + 2 * POSB) = v[4 * i + 2] - v[4 * i + 1];
+        *reinterpret_cast<f32x4*>(dst + 3 * POSB) = v[4 * i + 1] - v[4 * i + 3];
+      }
+    };
+
+    // ---- pipeline fill for this operand (one exposed memory latency + transform per operand)
+    if (MTW == 2 || my_parity == (gchunk & 1)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) load_v(i);
+      load_aff();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) affine_piece(i);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) row_piece(b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        col_piece(buf, i, 0);
+        col_piece(buf, i, 1);
       }
     }
-  };
-
-  // ---- pipeline
-  load_patch();
-  load_b(0, 0);
-  transform_store(0);
-  advance_cursor();
-  __syncthreads();
-  const int last8 = 2 * nchunks - 1;
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    load_patch();                                  // chunk min(c+1, nchunks-1)
-    load_b(1, 2 * c + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(buf, 0, 0);
-    load_b(0, 2 * c + 2 < last8 ? 2 * c + 2 : last8);
-    compute(buf, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    transform_store(buf ^ 1);
-    advance_cursor();
     __syncthreads();
+    if (DBG & 4) t1 = clock64();
+
+    for (int c = 0; c < nch; ++c) {
+      const bool more = c + 1 < nch;
+      cnB = (more ? c + 1 : c) * (WKC * 4);            // the last chunk re-fetches itself into the idle buffer: no branch
+      const char* Ab = smemB + buf * BUFB + frA;
+#pragma unroll
+      for (int mm = 0; mm < MTW; ++mm) fa[0][mm] = *reinterpret_cast<const f32x4*>(Ab + mm * 512);
+      auto body = [&](auto stage_tag) __attribute__((always_inline)) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NSL>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int grp = m / GRP, qq = m % GRP;          // grp = (8-k group, position j)
+          constexpr int sub = grp / 4, j = grp % 4;
+          constexpr int kk = qq / (2 * MTW), mm = (qq / 2) % MTW, nn = qq % 2;
+          constexpr int cur = grp & 1, nxt = cur ^ 1;
+          acc[j][mm][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mm][kk], breg[grp & 3][nn][kk], acc[j][mm][nn], 0, 0, 0);
+          // ---- side work of this slot
+          if constexpr (grp < 7 && qq >= 2 && qq < 2 + MTW) {
+            constexpr int g1 = grp + 1;
+            fa[nxt][qq - 2] = *reinterpret_cast<const f32x4*>(Ab + (g1 / 4) * SUBB + (g1 % 4) * POSB + (qq - 2) * 512);
+          }
+          if constexpr (qq == 0) {            // B fragments three steps ahead (step grp + 3 has j = (grp + 3) & 3)
+            load_b((grp + 3) & 3);
+            advance_b((grp + 3) & 3);
+          }
+          if constexpr (STAGE && m >= S_V && m < S_V + 16) load_v(m - S_V);
+          if constexpr (STAGE && m == S_AFF) load_aff();
+          if constexpr (STAGE && m >= S_T && m < S_T + 16) affine_piece(m - S_T);
+          if constexpr (STAGE && m >= ROWS_AT && m < ROWS_AT + 4) row_piece(m - ROWS_AT);
+          if constexpr (STAGE && m >= COLS_AT && m < COLS_AT + 8 / COLS_PER_SLOT) {
+#pragma unroll
+            for (int u = 0; u < COLS_PER_SLOT; ++u) {
+              constexpr int dummy = 0;
+              const int piece = (m - COLS_AT) * COLS_PER_SLOT + u + dummy;
+              col_piece(buf ^ 1, piece / 2, piece % 2);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+      if (MTW == 2 || my_parity == ((gchunk + 1) & 1)) body(std::true_type{});
+      else body(std::false_type{});
+      __syncthreads();
+      buf ^= 1;
+      ++gchunk;
+    }
   }
 
+  if (DBG & 4) t2 = clock64();
   // ---- output transform.  Along j in registers:  Z[b] = sum_j A^T[b][j] M[i][j],  A^T = (1 1 1 0 / 0 1 -1 -1)
-  f32x16 Z[2][2][2];
+  f32x16 Z[2][MTW][2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MTW; ++m)
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
       Z[0][m][nn] = acc[0][m][nn] + acc[1][m][nn] + acc[2][m][nn];
       Z[1][m][nn] = acc[1][m][nn] - acc[2][m][nn] - acc[3][m][nn];
     }
-  // Along i across the four waves through LDS (one half b at a time: 4 x 64 x 72 floats = 72 KiB)
-  const int c4 = tid & 15, tg = tid >> 4;          // final role: couts 4*c4..+3 of tiles tg + 16*k, k = 0..3
-  f32x4 Y[4][2][2];                                // [k][a][b]
+  // Along i across the four waves through LDS (one half b at a time: 4 x BT x 72 floats)
+  constexpr int NK = 2 * MTW;                      // final role: couts 4*c4..+3 of tiles tg + 16*k, k = 0..NK-1
+  const int c4 = tid & 15, tg = tid >> 4;
+  f32x4 Y[NK][2][2];                               // [k][a][b]
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          smem[(wave * WBT + row) * WZLD + 32 * nn + (lane & 31)] = Z[b][m][nn][r];
+          smem[(wave * BT + row) * WZLD + 32 * nn + (lane & 31)] = Z[b][m][nn][r];
         }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int tile = tg + 16 * k;
-      const f32x4 z0 = *reinterpret_cast<const f32x4*>(smem + (0 * WBT + tile) * WZLD + 4 * c4);
-      const f32x4 z1 = *reinterpret_cast<const f32x4*>(smem + (1 * WBT + tile) * WZLD + 4 * c4);
-      const f32x4 z2 = *reinterpret_cast<const f32x4*>(smem + (2 * WBT + tile) * WZLD + 4 * c4);
-      const f32x4 z3 = *reinterpret_cast<const f32x4*>(smem + (3 * WBT + tile) * WZLD + 4 * c4);
+      const f32x4 z0 = *reinterpret_cast<const f32x4*>(smem + (0 * BT + tile) * WZLD + 4 * c4);
+      const f32x4 z1 = *reinterpret_cast<const f32x4*>(smem + (1 * BT + tile) * WZLD + 4 * c4);
+      const f32x4 z2 = *reinterpret_cast<const f32x4*>(smem + (2 * BT + tile) * WZLD + 4 * c4);
+      const f32x4 z3 = *reinterpret_cast<const f32x4*>(smem + (3 * BT + tile) * WZLD + 4 * c4);
       Y[k][0][b] = z0 + z1 + z2;
       Y[k][1][b] = z1 - z2 - z3;
     }
   }
 
-  // ---- batch statistics of the pre-bias result: partial row 2*mb + m covers tiles [32(2mb+m), +32) = 128 pixels;
+  // ---- batch statistics of the pre-bias result: partial row MTW*mb + m covers tiles [32(MTW*mb+m), +32) = 128 pixels;
   //      (sum, M2 about the group's own mean), merged by dn_bn_finalize
   const int n_first = nb * WBN + 4 * c4;
   if (p.bn_partial != nullptr) {
-    float* red = smem + 4 * WBT * WZLD;            // [2 m][4 waves][64 couts], then gmean [2][64]
-    float* gmean = red + 2 * 4 * 64;
-    int gcount[2];
+    float* red = smem + 4 * BT * WZLD;             // [MTW][4 waves][64 couts], then gmean [MTW][64]
+    float* gmean = red + MTW * 4 * 64;
+    int gcount[MTW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      int left = p.T - (mb * WBT + 32 * m);
+    for (int m = 0; m < MTW; ++m) {
+      int left = p.T - (mb * BT + 32 * m);
       gcount[m] = left < 0 ? 0 : (left > 32 ? 32 : left);
     }
-    f32x4 s[2];
+    f32x4 s[MTW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MTW; ++m) {
       s[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -360,21 +433,21 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(const IgemmParams p) 
         s[m][e] += __shfl_xor(s[m][e], 32);
       }
     }
-    __syncthreads();
     if (lane < 16) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(red + (m * 4 + wave) * 64 + 4 * c4) = s[m];
+      for (int m = 0; m < MTW; ++m) *reinterpret_cast<f32x4*>(red + (m * 4 + wave) * 64 + 4 * c4) = s[m];
     }
     __syncthreads();
     float tot = 0.f;
-    if (tid < 128) {
+    if (tid < 64 * MTW) {
       const int m = tid >> 6, col = tid & 63;
       tot = red[(m * 4 + 0) * 64 + col] + red[(m * 4 + 1) * 64 + col] + red[(m * 4 + 2) * 64 + col] + red[(m * 4 + 3) * 64 + col];
-      gmean[tid] = gcount[m] > 0 ? tot / (float)(4 * gcount[m]) : 0.f;
+      const int gc = m == 0 ? gcount[0] : gcount[MTW - 1];
+      gmean[tid] = gc > 0 ? tot / (float)(4 * gc) : 0.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MTW; ++m) {
       const f32x4 mu = *reinterpret_cast<const f32x4*>(gmean + m * 64 + 4 * c4);
       f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -399,15 +472,16 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(const IgemmParams p) 
     __syncthreads();
     if (lane < 16) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(red + (m * 4 + wave) * 64 + 4 * c4) = s[m];
+      for (int m = 0; m < MTW; ++m) *reinterpret_cast<f32x4*>(red + (m * 4 + wave) * 64 + 4 * c4) = s[m];
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < 64 * MTW) {
       const int m = tid >> 6, col = tid & 63;
       const float m2 = red[(m * 4 + 0) * 64 + col] + red[(m * 4 + 1) * 64 + col] + red[(m * 4 + 2) * 64 + col] + red[(m * 4 + 3) * 64 + col];
       const int n = nb * WBN + col;
-      if (n < p.Ntot && gcount[m] > 0) {
-        float* dst = p.bn_partial + ((long long)(2 * mb + m) * p.Ntot + n) * 2;
+      const int gc = m == 0 ? gcount[0] : gcount[MTW - 1];
+      if (n < p.Ntot && gc > 0) {
+        float* dst = p.bn_partial + ((long long)(MTW * mb + m) * p.Ntot + n) * 2;
         dst[0] = tot;
         dst[1] = m2;
       }
@@ -426,8 +500,8 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(const IgemmParams p) 
     f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr) bias = *reinterpret_cast<const f32x4*>(p.bias + n_first);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int t = mb * WBT + tg + 16 * k;
+    for (int k = 0; k < NK; ++k) {
+      const int t = mb * BT + tg + 16 * k;
       if (t < p.T) {
         unsigned tx, ty;
         const unsigned r = fastdiv_dev((unsigned)t, (unsigned)p.TW, p.mTW, &tx);
@@ -447,6 +521,29 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(const IgemmParams p) 
       }
     }
   }
+  if (DBG & 4) {
+    t3 = clock64();
+    if (tid == 0) {
+      long long* o = reinterpret_cast<long long*>(p.ws) + (size_t)blockIdx.x * 4;
+      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+    }
+  }
+}
+
+template <int MTW, bool HA, int DBG>
+static int launch_wino_variant(const IgemmParams& p, hipStream_t stream) {
+  using Cfg = WinoCfg<MTW>;
+  auto kernel = wino_conv_kernel<MTW, HA, DBG>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(wino_conv_kernel, %zu): %s", Cfg::LDS, hipGetErrorString(e));
+    return DN_ERR_LAUNCH;
+  }
+  const int tiles = ((p.T + Cfg::BT - 1) / Cfg::BT) * (p.Npad / WBN);
+  dim3 grid((tiles + 7) / 8 * 8);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), Cfg::LDS, stream, p);
+  set_last_kernel("dn::wino_conv_kernel<%d, %s, %d>", MTW, HA ? "true" : "false", DBG);
+  return check_launch("wino_conv_kernel");
 }
 
 int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
@@ -456,16 +553,17 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.TW = p.OW / 2;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds);
-  if (e != hipSuccess) {
-    set_error("hipFuncSetAttribute(wino_conv_kernel, %zu): %s", kWinoLds, hipGetErrorString(e));
-    return DN_ERR_LAUNCH;
+  const char* dbg_env = getenv("DN_WINO_DBG");
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  const char* mtw_env = getenv("DN_WINO_MTW");
+  const int mtw = mtw_env ? atoi(mtw_env) : 2;
+  if (dbg == 4) {
+    p.ws = reinterpret_cast<float*>(strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0));
+    if (mtw == 1) return p.any_affine ? launch_wino_variant<1, true, 4>(p, stream) : launch_wino_variant<1, false, 4>(p, stream);
+    return p.any_affine ? launch_wino_variant<2, true, 4>(p, stream) : launch_wino_variant<2, false, 4>(p, stream);
   }
-  const int tiles = ((p.T + WBT - 1) / WBT) * (p.Npad / WBN);
-  dim3 grid((tiles + 7) / 8 * 8);
-  hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), kWinoLds, stream, p);
-  set_last_kernel("dn::wino_conv_kernel");
-  return check_launch("wino_conv_kernel");
+  if (mtw == 1) return p.any_affine ? launch_wino_variant<1, true, 0>(p, stream) : launch_wino_variant<1, false, 0>(p, stream);
+  return p.any_affine ? launch_wino_variant<2, true, 0>(p, stream) : launch_wino_variant<2, false, 0>(p, stream);
 }
 
 }  // namespace dn

@@ -19,7 +19,7 @@ for f in glob.glob("$out/pass*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"][:70]
-        if "igemm" not in k: continue
+        if "igemm" not in k and "wino" not in k: continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (f, r["Dispatch_Id"])
         if key not in seen and r["Counter_Name"] in ("SQ_WAVE_CYCLES", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"):
