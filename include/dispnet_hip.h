@@ -117,6 +117,11 @@ int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d);
 /* Re-lay the framework weight tensor for desc->kind.  `w` is nn.Conv2d.weight [Cout][Cin][R][S] for DN_CONV_*,
  * nn.ConvTranspose2d.weight [Cin][Cout][R][S] for DN_CONVT_*.  Run once per optimizer step per kind. */
 int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed, dn_stream_t stream);
+/* Which packed layout dn_conv_pack_weights produces for this descriptor: 0 = implicit-GEMM [phase][Npad][K chunks], 1 = Winograd
+ * F(2x2,3x3) transformed weights in MFMA fragment order (3x3 / stride 1 / pad 1 layers with 16-aligned channels and even
+ * extents that fill the kernel's tiles).  The layout depends on the geometry, not only on the weights: a caller that caches
+ * packed weights must key the cache on it (the same layer at another resolution may pick the other algorithm). */
+int32_t dn_conv_weight_layout(const dn_conv_desc* d);
 /* Number of row tiles (first dimension of bn_partial) the launch of this descriptor uses. */
 int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d);
 /* Enqueue the convolution described by d. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "dn_device_arch_ok": (C.c_int, []),
     "dn_conv_packed_weight_elems": (_i64, [_P(ConvDesc)]),
     "dn_conv_pack_weights": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
+    "dn_conv_weight_layout": (_i32, [_P(ConvDesc)]),
     "dn_conv_bn_partial_rows": (_i32, [_P(ConvDesc)]),
     "dn_conv2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),
     "dn_conv2d_dgrad": (C.c_int, [_P(ConvDesc), _vp]),

@@ -313,6 +313,12 @@ int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d) {
   return last.w_off + (int64_t)p.Npad * last.nchunks * dn::kChunk;
 }
 
+int32_t dn_conv_weight_layout(const dn_conv_desc* d) {
+  dn::IgemmParams p;
+  if (dn::build_plan(d, false, &p) != DN_OK) return -1;
+  return dn::wino_eligible(d, p) ? 1 : 0;
+}
+
 int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (dn::build_plan(d, false, &p) != DN_OK) return -1;

@@ -210,12 +210,13 @@ class ConvLayer:
     def packed(self, kind, desc):
         """Packed weights for `kind`, re-laid only when the parameter changed."""
         w = self.m.weight
+        lib = _lib.load()
+        layout = lib.dn_conv_weight_layout(C.byref(desc))     # direct or Winograd: depends on the geometry of this call
         key = (w.data_ptr(), w._version, PARAM_EPOCH, tuple(desc.in_[i].C for i in range(desc.n_in)),
                tuple(desc.out[i].C for i in range(desc.n_out)))
-        hit = self._packed.get(kind)
+        hit = self._packed.get((kind, layout))
         if hit is not None and hit[0] == key:
             return hit[1]
-        lib = _lib.load()
         n = lib.dn_conv_packed_weight_elems(C.byref(desc))
         if n < 0:
             raise _lib.DispnetHipError("dn_conv_packed_weight_elems: " + _lib.last_error())
@@ -224,7 +225,7 @@ class ConvLayer:
         if not wc.is_contiguous():
             wc = wc.contiguous()
         _lib.call("dn_conv_pack_weights", C.byref(desc), wc.data_ptr(), buf.data_ptr(), _stream())
-        self._packed[kind] = (key, buf)
+        self._packed[(kind, layout)] = (key, buf)
         return buf
 
 

@@ -59,9 +59,10 @@ CONV_CASES = [
     ("3x3_64_64",         (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 12, 20, ACT_NONE, False),
     ("3x3_first_nchw",    (3,),         (False,),          64, 3, 1, 1, False, 0, 2, 16, 24, ACT_NONE, False),
     ("3x3_128_256_bnload", (128,),      (False,),          256, 3, 1, 1, False, 0, 2, 8, 12, ACT_NONE, True),
-    ("3x3_wino_cat",      (32, 64),     (False, False),    96, 3, 1, 1, False, 0, 3, 10, 14, ACT_LEAKY, False),
-    ("3x3_wino_cat_aff",  (64, 16),     (False, False),    64, 3, 1, 1, False, 0, 2, 6, 10, ACT_RELU, True),
-    ("3x3_wino_512",      (512,),       (False,),          128, 3, 1, 1, False, 0, 1, 8, 26, ACT_NONE, False),
+    ("3x3_wino_cat",      (32, 64),     (False, False),    96, 3, 1, 1, False, 0, 3, 18, 22, ACT_LEAKY, False),
+    ("3x3_wino_cat_aff",  (64, 16),     (False, False),    64, 3, 1, 1, False, 0, 2, 20, 26, ACT_RELU, True),
+    ("3x3_wino_512",      (512,),       (False,),          128, 3, 1, 1, False, 0, 3, 8, 26, ACT_NONE, False),
+    ("3x3_wino_64_64",    (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 24, 44, ACT_NONE, False),
     ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
     ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
     ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
@@ -142,8 +143,8 @@ def test_conv_family_fwd_bwd(case):
         close(name + ":dx%d" % i, nchw(pc.act.grad), t.grad, rtol=5e-4, atol_rel=5e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 12, 3, 64, 64), (2, 16, 8, 64, 128, 128), (3, 10, 14, 16, 64, 96)],
-                         ids=["c3_64_64", "c64_128_128", "c16_64_96_ragged"])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 3, 64, 64), (2, 16, 8, 64, 128, 128), (3, 18, 22, 16, 64, 96)],
+                         ids=["c3_64_64", "c64_128_128", "c16_64_96_wino_ragged"])
 def test_conv_bn_pool_block(shape):
     """conv -> BN(train) -> ReLU -> conv -> BN -> ReLU -> MaxPool, forward + full backward vs torch modules (CPU)."""
     N, H, W, c0, c1, c2 = shape
@@ -191,7 +192,7 @@ def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
     """3x3/s1/p1 layers with 16-aligned channels run dn::wino_conv_kernel (forward and input gradient); the same call with
     DN_NO_WINOGRAD=1 runs the direct implicit GEMM: both agree to fp32 round-off (F(2x2,3x3) has the same error level)."""
     torch.manual_seed(4)
-    N, H, W, cin, cout = 2, 12, 20, 64, 128
+    N, H, W, cin, cout = 3, 18, 22, 64, 128
     mod = nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
     x = torch.randn(N, H, W, cin, device=DEV)
     dy = torch.randn(N, H, W, cout, device=DEV)
@@ -214,6 +215,31 @@ def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
     assert "igemm" in res["direct"][2] and "igemm" in res["direct"][3]
     close("wino_vs_direct:y", res["wino"][0], res["direct"][0], rtol=1e-4, atol_rel=1e-5)
     close("wino_vs_direct:dx", res["wino"][1], res["direct"][1], rtol=1e-4, atol_rel=1e-5)
+
+
+def test_winograd_error_vs_fp64(monkeypatch):
+    """Rounding of F(2x2,3x3) against the direct fp32 FMA chain, both measured against an fp64 convolution of the same
+    fp32 inputs: Winograd's transforms add a few ulps of the INPUT magnitude; stated bound: max error <= 4x the direct
+    kernel's + 2e-6 of the result's magnitude (measured ~1.5-2.5x)."""
+    torch.manual_seed(7)
+    N, H, W, cin, cout = 2, 32, 48, 128, 64
+    mod = nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+    x = torch.rand(N, H, W, cin, device=DEV)               # non-negative like a post-ReLU activation (the unfavourable case)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), mod.weight.detach().double().cpu(), mod.bias.detach().double().cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    errs = {}
+    for tag, env in (("wino", None), ("direct", "1")):
+        if env is None:
+            monkeypatch.delenv("DN_NO_WINOGRAD", raising=False)
+        else:
+            monkeypatch.setenv("DN_NO_WINOGRAD", env)
+        layer = engine.ConvLayer(mod)
+        y, _, _ = engine.conv_forward(layer, [engine.Piece(engine.Act(x, N, H, W, cin))])
+        torch.cuda.synchronize()
+        errs[tag] = float((y.double().cpu() - ref).abs().max())
+    scale = float(ref.abs().max())
+    print("max |err| vs fp64: winograd %.3g, direct %.3g (result magnitude %.3g)" % (errs["wino"], errs["direct"], scale))
+    assert errs["wino"] <= 4.0 * errs["direct"] + 2e-6 * scale
 
 
 def test_bilinear_up2_matches_interpolate():

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--layers", default=",".join(LAYERS))
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--affine", action="store_true", help="give the input a pending BatchNorm-apply + ReLU (forward / wgrad loaders)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in args.layers.split(","):
@@ -31,6 +32,9 @@ def main():
         mod = (nn.ConvTranspose2d(cin, cout, 4, 2, 1) if tr else nn.Conv2d(cin, cout, 3, 1, 1)).to(dev)
         layer = engine.ConvLayer(mod, transposed=tr)
         x = engine.Act(torch.randn(args.batch, H, W, cin, device=dev), args.batch, H, W, cin)
+        if args.affine:
+            x.scale = torch.rand(cin, device=dev) + 0.5
+            x.shift = torch.rand(cin, device=dev) - 0.5
         pieces = [engine.Piece(x)]
         y, _, _ = engine.conv_forward(layer, pieces)
         OH, OW = y.shape[1], y.shape[2]
