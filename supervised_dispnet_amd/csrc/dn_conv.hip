@@ -1503,6 +1503,7 @@ size_t dn_conv_wgrad_workspace_bytes(const dn_conv_desc* fwd) {
   choose_splits(&p);
   size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
   if (head_wgrad_eligible(fwd, p) && head_wgrad_workspace_bytes(p) > need) need = head_wgrad_workspace_bytes(p);
+  if (wino_wgrad_eligible(fwd, p) && wino_wgrad_workspace_bytes(p) > need) need = wino_wgrad_workspace_bytes(p);
   return need;
 }
 
@@ -1516,6 +1517,12 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     DN_REQUIRE(p.in[0].p != nullptr, DN_ERR_BAD_ARG, "operand 0 has no data");
     p.g = dy;
     return launch_head_wgrad(p, dw, reinterpret_cast<float*>(workspace), as_stream(stream));
+  }
+  if (wino_wgrad_eligible(fwd, p) && workspace_bytes >= wino_wgrad_workspace_bytes(p)) {
+    for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
+    p.g = dy;
+    p.ws = reinterpret_cast<float*>(workspace);
+    return launch_wino_wgrad(p, dw, as_stream(stream));
   }
   choose_splits(&p);
   const size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);

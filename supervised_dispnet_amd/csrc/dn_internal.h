@@ -123,5 +123,9 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p);
 long long wino_packed_elems(const IgemmParams& p);
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream);
 int launch_wino_conv(IgemmParams& p, hipStream_t stream);
+// dn_winograd_wgrad.hip: Winograd weight gradient of the same layers (operands and output channels multiples of 64)
+bool wino_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
+size_t wino_wgrad_workspace_bytes(const IgemmParams& p);
+int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream);
 
 }  // namespace dn

@@ -1,0 +1,446 @@
+// Winograd F(2x2, 3x3) weight gradient of the 3x3 / stride 1 / pad 1 layers on the CDNA4 fp32 matrix core (gfx950 only).
+//
+//   dU_p[co][ci] = sum over tiles t of  Gt_p[t][co] * V_p[t][ci]        p = 4i + j, the 16 positions of the transform domain
+//   Gt = A dY A^T  (2x2 output-gradient tile -> 4x4),   V = B^T d B  (4x4 input patch -> 4x4, the forward's input transform)
+//   dW(3x3) = G^T dU G                                                  (wino_wgrad_reduce_kernel, with the split sum)
+//
+// 16 GEMMs whose reduction runs over the TILES: 2.25x fewer multiply-accumulates than sum over pixels of dy * x.  Both
+// operands are transformed on the fly, so the staging work per MFMA is what decides (fp32 MFMAs share the SIMD's FMA lanes
+// with every vector instruction, dn_winograd.hip): one block = 64 co x 64 ci x 16 positions, 8 waves (two per SIMD, 128
+// accumulator registers each: wave w owns positions 4(w>>1) + 2(w&1) + {0,1}), 8 tiles per chunk.
+//   * LDS: [buffer][G | V][position][tile][64 channels]: staging stores are b128 along the channels (a wave writes 1 KiB
+//     contiguous), fragment reads are b32 with the 32 lanes of a half-wave on 32 consecutive channels (conflict-free both).
+//   * Staging is spread in time and over the waves: waves 0-3 prepare the even chunks, waves 4-7 the odd ones; a wave issues
+//     its global loads while chunk c is multiplied, transforms and stores them while chunk c+1 is, and the data is consumed as
+//     chunk c+2.  Two waves of each group take input patches (16 loads, BatchNorm-apply + ReLU, 32 adds), two take
+//     output-gradient tiles (4 loads, 12 adds); the groups swap these roles so that every SIMD carries one of each.
+//   * Zero halo / tile tail through buffer descriptors (loads past num_records return 0); the sign of A's last row is
+//     folded into the final 16 -> 9 transform instead of negating in the loop.
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+#include "dn_internal.h"
+
+namespace dn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class F, int... I>
+__device__ __forceinline__ void wg_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  wg_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+constexpr int GTC = 8;                        // tiles per chunk
+constexpr int G_ROWB = 64 * 4;                // one tile row: 64 channels
+constexpr int G_PLANE = GTC * G_ROWB;         // one position: [8 tiles][64 channels] = 2 KiB
+constexpr int G_OPB = 16 * G_PLANE;           // one operand (G or V) of one buffer = 32 KiB
+constexpr int G_BUFB = 2 * G_OPB;             // G then V
+constexpr size_t kWgLds = (size_t)2 * G_BUFB; // 128 KiB
+
+__device__ __forceinline__ f32x4 wg_buffer_load(__amdgpu_buffer_rsrc_t r, int voffset) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, 0, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+bool wino_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
+  if (getenv("DN_NO_WINOGRAD") || getenv("DN_NO_WINOGRAD_WGRAD")) return false;
+  if (d->kind != DN_CONV_FWD) return false;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
+  if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
+  if (p.ph[0].ntaps != 9) return false;
+  if (p.Ntot % 64 != 0) return false;
+  if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) return false;
+  if (p.M / 4 < 256) return false;
+  for (int i = 0; i < p.n_in; ++i) {
+    const KOperand& o = p.in[i];
+    if (!o.vec || !o.small || o.up != 0 || (o.C % 64) != 0) return false;
+    if (o.scale != nullptr && ((reinterpret_cast<uintptr_t>(o.scale) | reinterpret_cast<uintptr_t>(o.shift)) & 15)) return false;
+  }
+  return true;
+}
+
+static int wg_ktot(const IgemmParams& p) {
+  int k = 0;
+  for (int i = 0; i < p.n_in; ++i) k += p.in[i].C;
+  return k;
+}
+
+// pixel (tile) splits: whole rounds of 256 resident blocks, at least 16 chunks per split
+static void wg_choose_splits(const IgemmParams& p, int* splits, int* tiles_per_split) {
+  const int T = p.M / 4, chunks = (T + GTC - 1) / GTC;
+  const int tb = (p.Ntot / 64) * (wg_ktot(p) / 64);
+  int max_by_work = chunks / 16;
+  if (max_by_work < 1) max_by_work = 1;
+  int best = 1;
+  double best_util = 0.0;
+  for (int R = 1; R <= 4; ++R) {
+    int sp = (R * 256) / tb;
+    if (sp < 1) continue;
+    if (sp > max_by_work) sp = max_by_work;
+    const double util = (double)tb * sp / ((double)((tb * sp + 255) / 256) * 256);
+    if (util > best_util + 1e-9) {
+      best_util = util;
+      best = sp;
+    }
+    if (util >= 0.92) break;
+  }
+  const int cps = (chunks + best - 1) / best;
+  *tiles_per_split = cps * GTC;
+  *splits = (chunks + cps - 1) / cps;
+}
+
+constexpr int kWgFold = 16;   // splits summed per thread by the first reduction stage
+
+size_t wino_wgrad_workspace_bytes(const IgemmParams& p) {
+  int splits, tps;
+  wg_choose_splits(p, &splits, &tps);
+  const size_t slab16 = (size_t)16 * p.Ntot * wg_ktot(p);
+  const size_t stage2 = splits > kWgFold ? (size_t)((splits + kWgFold - 1) / kWgFold) * slab16 : 0;
+  return ((size_t)splits * slab16 + stage2) * sizeof(float);
+}
+
+// first stage of the split sum when there are many splits (narrow layers: few (co, ci) blocks, hundreds of tile splits):
+// out[g][pos][idx] = sum of splits [16g, 16g+16)  -- fixed order, deterministic
+__global__ void wino_wgrad_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, long long slab16, int splits) {
+  const int groups = (splits + kWgFold - 1) / kWgFold;
+  const long long total = (long long)groups * slab16;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx / slab16);
+    const long long e = idx - (long long)g * slab16;
+    const int z1 = min(splits, (g + 1) * kWgFold);
+    float s = 0.f;
+    for (int z = g * kWgFold; z < z1; ++z) s += ws[(long long)z * slab16 + e];
+    out[idx] = s;
+  }
+}
+
+template <bool HA>
+__global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p) {
+  extern __shared__ __align__(16) float smem[];
+  char* smemB = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Ktot = p.D1, Cout = p.Ntot;
+  const int CB = Cout / 64, KB = Ktot / 64;
+  // XCD-aware order: the (co, ci) blocks of one tile split are consecutive logical blocks on one XCD (they share its G / V tiles)
+  const int total = CB * KB * p.splits;
+  const int per = (total + 7) >> 3;
+  const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || q >= total) return;
+  const int cib = q % KB, cob = (q / KB) % CB, split = q / (KB * CB);
+  const int T = p.T;
+  const int t_begin = split * p.m_per_split;
+  const int t_end = min(T, t_begin + p.m_per_split);
+  const int nchunks = (t_end - t_begin + GTC - 1) / GTC;
+
+  // the input operand this ci block lies in (operands are multiples of 64 channels wide)
+  int s_op = 0;
+#pragma unroll
+  for (int i = 1; i < DN_MAX_OPERANDS; ++i)
+    if (i < p.n_in && cib * 64 >= p.in[i].ch_off) s_op = i;
+  const KOperand& S = p.in[s_op];
+  const int c_in_op = cib * 64 - S.ch_off;
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+
+  // ---- roles
+  const int group = wave >> 2, wq = wave & 3;
+  const bool roleV = (wq < 2) != (group == 1);
+  const int item_t = (wq & 1) * 4 + (lane >> 4);        // tile within the chunk
+  const int item_c = (lane & 15) * 4;                   // channel within the 64-wide block
+  const int stB = item_t * G_ROWB + item_c * 4;         // staging store offset inside a position plane
+  const int pos0 = 4 * (wave >> 1) + 2 * (wave & 1);    // this wave's two positions
+  const int frB = pos0 * G_PLANE + (lane >> 5) * G_ROWB + (lane & 31) * 4;   // fragment read offset (+ pp*G_PLANE + ks*2*G_ROWB + h*128)
+
+  f32x16 acc[2][2][2];       // [pp][h (co half)][nn (ci half)]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][c][e] = 0.f;
+
+  // ---- staging state
+  f32x4 v[16];               // V role: the 4x4 patch; G role: v[0..3] = the 2x2 gradient tile
+  f32x4 sc4, sh4;
+  unsigned pmask = 0;
+  const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
+  const int gpixB = Cout * 4, growB = p.OW * Cout * 4;
+  if constexpr (HA) {
+    const bool op_aff = S.scale != nullptr;
+    const f32x4 l1 = *reinterpret_cast<const f32x4*>((op_aff ? S.scale : S.p) + (op_aff ? c_in_op + item_c : 0));
+    const f32x4 l2 = *reinterpret_cast<const f32x4*>((op_aff ? S.shift : S.p) + (op_aff ? c_in_op + item_c : 0));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc4[e] = op_aff ? l1[e] : 1.f;
+      sh4[e] = op_aff ? l2[e] : 0.f;
+    }
+  }
+  const float relu_floor = (HA && S.scale != nullptr) ? 0.f : -__builtin_huge_valf();
+  int off0 = 0;
+
+  auto decode = [&](int target) {          // item of chunk `target`: tile -> offsets and masks
+    const int t = t_begin + target * GTC + item_t;
+    const bool live = t < t_end;
+    unsigned tx, ty;
+    const unsigned r = fastdiv_dev(live ? (unsigned)t : 0u, (unsigned)p.TW, p.mTW, &tx);
+    const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
+    if (roleV) {
+      const int py = 2 * (int)ty - 1, px = 2 * (int)tx - 1;
+      off0 = (n * (int)S.sn + py * (int)S.sh + px * (int)S.sw + c_in_op + item_c) * 4;
+      unsigned m = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          m |= (live && (unsigned)(py + a) < (unsigned)p.IH && (unsigned)(px + b) < (unsigned)p.IW) ? (1u << (4 * a + b)) : 0u;
+      pmask = m;
+    } else {
+      off0 = live ? (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 64 + item_c) * 4 : -1;
+    }
+  };
+  auto load_v = [&](int i) {
+    const int a = i >> 2, b = i & 3;
+    const bool ok = (pmask >> i) & 1u;
+    int off = off0 + a * shB + b * swB;
+    asm volatile("" : "+v"(off));
+    off = ok ? off : -1;
+    v[i] = wg_buffer_load(rsrcX, off);
+  };
+  auto load_g = [&](int i) {
+    int off = off0 + (i >> 1) * growB + (i & 1) * gpixB;
+    asm volatile("" : "+v"(off));
+    off = off0 < 0 ? -1 : off;
+    v[i] = wg_buffer_load(rsrcG, off);
+  };
+  auto affine_piece = [&](int i) {
+    if constexpr (HA) {
+      const float fm = (float)((pmask >> i) & 1u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(relu_floor, fmaf(v[i][e], sc4[e], sh4[e])) * fm;
+    }
+  };
+  auto row_piece = [&](int b) {                      // B^T d, in place
+    const f32x4 d0 = v[0 + b], d1 = v[4 + b], d2 = v[8 + b];
+    v[0 + b] = d0 - d2;
+    v[4 + b] = d1 + d2;
+    v[8 + b] = d2 - d1;
+    v[12 + b] = d1 - v[12 + b];
+  };
+  auto col_piece = [&](int b2, int i, int half) {    // (B^T d) B and the LDS stores of transform row i
+    char* dst = smemB + b2 * G_BUFB + G_OPB + stB + (4 * i) * G_PLANE;
+    if (half == 0) {
+      *reinterpret_cast<f32x4*>(dst + 0 * G_PLANE) = v[4 * i + 0] - v[4 * i + 2];
+      *reinterpret_cast<f32x4*>(dst + 1 * G_PLANE) = v[4 * i + 1] + v[4 * i + 2];
+    } else {
+      *reinterpret_cast<f32x4*>(dst + 2 * G_PLANE) = v[4 * i + 2] - v[4 * i + 1];
+      *reinterpret_cast<f32x4*>(dst + 3 * G_PLANE) = v[4 * i + 1] - v[4 * i + 3];
+    }
+  };
+  // gradient tile y[a][b] = v[2a+b] -> u (rows): u0 = y0., u1 = y0. + y1., u2 = y0. - y1., u3 = y1.  (sign of A's last row dropped)
+  // stored as v[4 + 2i + b]; then g[i][.] = (u_i0, u_i0 + u_i1, u_i0 - u_i1, u_i1)
+  auto g_rows = [&]() {
+    v[4] = v[0];
+    v[5] = v[1];
+    v[6] = v[0] + v[2];
+    v[7] = v[1] + v[3];
+    v[8] = v[0] - v[2];
+    v[9] = v[1] - v[3];
+    v[10] = v[2];
+    v[11] = v[3];
+  };
+  auto g_cols = [&](int b2, int i) {
+    char* dst = smemB + b2 * G_BUFB + stB + (4 * i) * G_PLANE;
+    const f32x4 u0 = v[4 + 2 * i], u1 = v[5 + 2 * i];
+    *reinterpret_cast<f32x4*>(dst + 0 * G_PLANE) = u0;
+    *reinterpret_cast<f32x4*>(dst + 1 * G_PLANE) = u0 + u1;
+    *reinterpret_cast<f32x4*>(dst + 2 * G_PLANE) = u0 - u1;
+    *reinterpret_cast<f32x4*>(dst + 3 * G_PLANE) = u1;
+  };
+
+  // ---- pipeline fill: group 0 stages chunk 0 completely, group 1 loads chunk 1 (it is transformed while chunk 0 is multiplied)
+  decode(group);
+  if (roleV) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) load_v(i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_g(i);
+  }
+  if (group == 0) {
+    if (roleV) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) affine_piece(i);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) row_piece(b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        col_piece(0, i, 0);
+        col_piece(0, i, 1);
+      }
+    } else {
+      g_rows();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g_cols(0, i);
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop: 32 slots per chunk, one MFMA each; fragments (scalar LDS reads) one (k-step, position) group ahead
+  float fa[2][2], fb[2][2];
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    const bool loading = ((c - group) & 1) == 0;     // this wave: loads for chunk c+2, or transform + store of chunk c+1
+    const char* Gb = smemB + buf * G_BUFB + frB;
+    const char* Vb = Gb + G_OPB;
+    fa[0][0] = *reinterpret_cast<const float*>(Gb);
+    fa[0][1] = *reinterpret_cast<const float*>(Gb + 128);
+    fb[0][0] = *reinterpret_cast<const float*>(Vb);
+    fb[0][1] = *reinterpret_cast<const float*>(Vb + 128);
+    auto body = [&](auto rolev_tag, auto loading_tag) __attribute__((always_inline)) {
+      constexpr bool RV = decltype(rolev_tag)::value;
+      constexpr bool LD = decltype(loading_tag)::value;
+      if constexpr (LD) decode(c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      wg_static_for<32>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int g = m / 4, qq = m % 4;           // g = (k-step, position): 4 MFMAs
+        constexpr int pp = g & 1;
+        constexpr int h = qq >> 1, nn = qq & 1;
+        constexpr int cur = g & 1, nxt = cur ^ 1;
+        acc[pp][h][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][h], fb[cur][nn], acc[pp][h][nn], 0, 0, 0);
+        // ---- side work of this slot
+        if constexpr (g < 7) {
+          constexpr int g1 = g + 1;
+          constexpr int o = (g1 & 1) * G_PLANE + (g1 >> 1) * 2 * G_ROWB;
+          if constexpr (qq == 0) fa[nxt][0] = *reinterpret_cast<const float*>(Gb + o);
+          if constexpr (qq == 1) fa[nxt][1] = *reinterpret_cast<const float*>(Gb + o + 128);
+          if constexpr (qq == 2) fb[nxt][0] = *reinterpret_cast<const float*>(Vb + o);
+          if constexpr (qq == 3) fb[nxt][1] = *reinterpret_cast<const float*>(Vb + o + 128);
+        }
+        if constexpr (RV && LD) {
+          if constexpr (m >= 1 && m < 17) load_v(m - 1);
+        }
+        if constexpr (RV && !LD) {
+          if constexpr (m < 16) affine_piece(m);
+          if constexpr (m >= 16 && m < 20) row_piece(m - 16);
+          if constexpr (m >= 20 && m < 28) col_piece(buf ^ 1, (m - 20) / 2, (m - 20) % 2);
+        }
+        if constexpr (!RV && LD) {
+          if constexpr (m >= 1 && m < 5) load_g(m - 1);
+        }
+        if constexpr (!RV && !LD) {
+          if constexpr (m == 0) g_rows();
+          if constexpr (m >= 2 && m < 10 && (m % 2) == 0) g_cols(buf ^ 1, (m - 2) / 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    if (roleV) {
+      if (loading) body(std::true_type{}, std::true_type{});
+      else body(std::true_type{}, std::false_type{});
+    } else {
+      if (loading) body(std::false_type{}, std::true_type{});
+      else body(std::false_type{}, std::false_type{});
+    }
+    __syncthreads();
+  }
+
+  // ---- partial dU of this split: ws[split][pos][co][ci]
+  float* ws = p.ws + ((size_t)split * 16 + pos0) * (size_t)Cout * Ktot;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = cob * 64 + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = cib * 64 + 32 * nn + (lane & 31);
+          ws[(size_t)pp * Cout * Ktot + (size_t)row * Ktot + col] = acc[pp][h][nn][r];
+        }
+}
+
+// dU = sum over splits (with the sign of A's last row restored), dW = G^T dU G, written in the framework layout [co][ci][3][3]
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits) {
+  const long long slab = (long long)Cout * Ktot;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < slab; idx += (long long)gridDim.x * blockDim.x) {
+    float u[4][4];
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += ws[((long long)z * 16 + pos) * slab + idx];
+      const int i = pos >> 2, j = pos & 3;
+      u[i][j] = ((i == 3) != (j == 3)) ? -s : s;
+    }
+    // t[r][j] = sum_i G[i][r] u[i][j],  G = (1 0 0 / .5 .5 .5 / .5 -.5 .5 / 0 0 1)
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+      t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+      t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+    float* o = dw + idx * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      o[r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+      o[r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
+      o[r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+    }
+  }
+}
+
+int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
+  int splits, tps;
+  wg_choose_splits(p, &splits, &tps);
+  p.splits = splits;
+  p.m_per_split = tps;
+  p.T = p.M / 4;
+  p.TH = p.GH / 2;
+  p.TW = p.GW / 2;
+  p.OH = p.GH;
+  p.OW = p.GW;
+  p.mTW = fastdiv_magic((unsigned)p.TW);
+  p.mTH = fastdiv_magic((unsigned)p.TH);
+  auto kernel = p.any_affine ? wino_wgrad_kernel<true> : wino_wgrad_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLds);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(wino_wgrad_kernel, %zu): %s", kWgLds, hipGetErrorString(e));
+    return DN_ERR_LAUNCH;
+  }
+  const int Ktot = wg_ktot(p);
+  const int total = (p.Ntot / 64) * (Ktot / 64) * splits;
+  hipLaunchKernelGGL(kernel, dim3((total + 7) / 8 * 8), dim3(512), kWgLds, stream, p);
+  set_last_kernel("dn::wino_wgrad_kernel<%s>", p.any_affine ? "true" : "false");
+  int rc = check_launch("wino_wgrad_kernel");
+  if (rc != DN_OK) return rc;
+  const long long slab = (long long)p.Ntot * Ktot;
+  const float* src = p.ws;
+  int nsrc = splits;
+  if (splits > kWgFold) {
+    float* folded = p.ws + (size_t)splits * 16 * slab;
+    const int groups = (splits + kWgFold - 1) / kWgFold;
+    const long long total = (long long)groups * 16 * slab;
+    int fb = (int)((total + 255) / 256);
+    if (fb > 16384) fb = 16384;
+    hipLaunchKernelGGL(wino_wgrad_fold_kernel, dim3(fb), dim3(256), 0, stream, p.ws, folded, 16 * slab, splits);
+    src = folded;
+    nsrc = groups;
+  }
+  int blocks = (int)((slab + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc);
+  return check_launch("wino_wgrad_reduce_kernel");
+}
+
+}  // namespace dn

@@ -61,7 +61,9 @@ CONV_CASES = [
     ("3x3_128_256_bnload", (128,),      (False,),          256, 3, 1, 1, False, 0, 2, 8, 12, ACT_NONE, True),
     ("3x3_wino_cat",      (32, 64),     (False, False),    96, 3, 1, 1, False, 0, 3, 18, 22, ACT_LEAKY, False),
     ("3x3_wino_cat_aff",  (64, 16),     (False, False),    64, 3, 1, 1, False, 0, 2, 20, 26, ACT_RELU, True),
-    ("3x3_wino_512",      (512,),       (False,),          128, 3, 1, 1, False, 0, 3, 8, 26, ACT_NONE, False),
+    ("3x3_wino_512",      (512,),       (False,),          128, 3, 1, 1, False, 0, 6, 8, 26, ACT_NONE, False),
+    ("3x3_wino_cat64_aff", (64, 128),   (False, False),    64, 3, 1, 1, False, 0, 2, 20, 30, ACT_LEAKY, True),
+    ("3x3_wino_cat64",    (128, 64),    (False, False),    128, 3, 1, 1, False, 0, 3, 18, 22, ACT_NONE, False),
     ("3x3_wino_64_64",    (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 24, 44, ACT_NONE, False),
     ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
     ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
@@ -143,8 +145,8 @@ def test_conv_family_fwd_bwd(case):
         close(name + ":dx%d" % i, nchw(pc.act.grad), t.grad, rtol=5e-4, atol_rel=5e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 12, 3, 64, 64), (2, 16, 8, 64, 128, 128), (3, 18, 22, 16, 64, 96)],
-                         ids=["c3_64_64", "c64_128_128", "c16_64_96_wino_ragged"])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 3, 64, 64), (2, 16, 8, 64, 128, 128), (3, 18, 22, 16, 64, 96), (2, 24, 44, 64, 64, 128)],
+                         ids=["c3_64_64", "c64_128_128", "c16_64_96_wino_ragged", "c64_64_128_wino_wgrad"])
 def test_conv_bn_pool_block(shape):
     """conv -> BN(train) -> ReLU -> conv -> BN -> ReLU -> MaxPool, forward + full backward vs torch modules (CPU)."""
     N, H, W, c0, c1, c2 = shape
@@ -209,12 +211,15 @@ def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
         kf = _lib.load().dn_last_kernel().decode()
         engine.conv_dgrad(layer, dy, N, H, W, [engine.Piece(xa)], (H, W))
         kd = _lib.load().dn_last_kernel().decode()
+        dw = engine.conv_wgrad(layer, [engine.Piece(xa)], dy, (H, W))
+        kw = _lib.load().dn_last_kernel().decode()
         torch.cuda.synchronize()
-        res[tag] = (y, xa.grad, kf, kd)
-    assert "wino_conv_kernel" in res["wino"][2] and "wino_conv_kernel" in res["wino"][3]
-    assert "igemm" in res["direct"][2] and "igemm" in res["direct"][3]
+        res[tag] = (y, xa.grad, kf, kd, dw, kw)
+    assert "wino_conv_kernel" in res["wino"][2] and "wino_conv_kernel" in res["wino"][3] and "wino_wgrad_kernel" in res["wino"][5]
+    assert "igemm" in res["direct"][2] and "igemm" in res["direct"][3] and "igemm" in res["direct"][5]
     close("wino_vs_direct:y", res["wino"][0], res["direct"][0], rtol=1e-4, atol_rel=1e-5)
     close("wino_vs_direct:dx", res["wino"][1], res["direct"][1], rtol=1e-4, atol_rel=1e-5)
+    close("wino_vs_direct:dw", res["wino"][4], res["direct"][4], rtol=1e-4, atol_rel=1e-5)
 
 
 def test_winograd_error_vs_fp64(monkeypatch):
