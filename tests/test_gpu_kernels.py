@@ -187,7 +187,7 @@ def test_conv_bn_pool_block(shape):
     close("dx", nchw(xa.grad), x.grad, rtol=1e-3, atol_rel=1e-4)
     # conv bias in front of BN: exact zeros here, rounding noise in the reference
     assert float(sink.get(dev_mods[0].bias).abs().max()) == 0.0
-    assert float(ref[0].bias.grad.abs().max()) < 1e-4
+    assert float(ref[0].bias.grad.abs().max()) < 1e-3      # pure rounding noise; its size depends on ATen's summation order
 
 
 def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
