@@ -102,16 +102,20 @@ long long wino_packed_elems(const IgemmParams& p) { return (long long)(wino_ktot
 // wp[k/8][pos][n/32][lane][e] = U_pos[n][k],  k = 8*(k/8) + 4*(lane >> 5) + e,  n = 32*(n/32) + (lane & 31):  exactly the
 // float4 a lane feeds to four consecutive v_mfma_f32_32x32x2_f32 as the B operand (the two half-waves hold k 0-3 / 4-7).
 __global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+  // one thread per (8-k group, 32-cout group, lane, e) = one (n, k) pair: 9 weight loads, all 16 positions written
+  const int Ktot = p.n_is_dim0 ? p.D1 : p.D0;
+  const long long npairs = total >> 4;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < npairs; idx += (long long)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-    long long rest = idx >> 8;
-    const int nsub = (int)(rest % NS);
-    rest /= NS;
-    const int pos = (int)(rest & 15), kc8 = (int)(rest >> 4);
+    const long long rest = idx >> 8;
+    const int nsub = (int)(rest % NS), kc8 = (int)(rest / NS);
     const int k = kc8 * 8 + (lane >> 5) * 4 + e, n = nsub * 32 + (lane & 31);
-    float u = 0.f;
-    if (n < p.Ntot && k < (p.n_is_dim0 ? p.D1 : p.D0)) {       // (the slack chunk past the last k is zeros)
-      float g[3][3];
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
+    if (n < p.Ntot && k < Ktot) {                           // (padding columns and the slack chunk past the last k are zeros)
       const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + k) : ((long long)k * p.D1 + n)) * 9;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -123,23 +127,32 @@ __global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ 
           for (int bb = 0; bb < 3; ++bb)
             if (aa == a && bb == b) g[aa][bb] = v;
       }
-      const int i = pos >> 2, j = pos & 3;
-      // rows of G: (1,0,0) (1/2,1/2,1/2) (1/2,-1/2,1/2) (0,0,1)
-      float t3[3];
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) {
-        const float g0 = g[0][bb], g1 = g[1][bb], g2 = g[2][bb];
-        t3[bb] = i == 0 ? g0 : (i == 1 ? 0.5f * (g0 + g1 + g2) : (i == 2 ? 0.5f * (g0 - g1 + g2) : g2));
-      }
-      u = j == 0 ? t3[0] : (j == 1 ? 0.5f * (t3[0] + t3[1] + t3[2]) : (j == 2 ? 0.5f * (t3[0] - t3[1] + t3[2]) : t3[2]));
     }
-    wp[idx] = u;
+    // U = G g G^T, rows of G: (1,0,0) (1/2,1/2,1/2) (1/2,-1/2,1/2) (0,0,1)
+    float t4[4][3];
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float g0 = g[0][bb], g1 = g[1][bb], g2 = g[2][bb];
+      t4[0][bb] = g0;
+      t4[1][bb] = 0.5f * (g0 + g1 + g2);
+      t4[2][bb] = 0.5f * (g0 - g1 + g2);
+      t4[3][bb] = g2;
+    }
+    float* dst = wp + ((long long)kc8 * 16 * NS + nsub) * 256 + lane * 4 + e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u0 = t4[i][0], u1 = 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]), u2 = 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]), u3 = t4[i][2];
+      dst[(long long)(4 * i + 0) * NS * 256] = u0;
+      dst[(long long)(4 * i + 1) * NS * 256] = u1;
+      dst[(long long)(4 * i + 2) * NS * 256] = u2;
+      dst[(long long)(4 * i + 3) * NS * 256] = u3;
+    }
   }
 }
 
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream) {
   const long long total = wino_packed_elems(p);
-  int blocks = (int)((total + 255) / 256);
+  int blocks = (int)(((total >> 4) + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
   return check_launch("wino_pack_kernel");
