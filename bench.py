@@ -9,9 +9,12 @@ One rank per GPU (RCCL over xGMI through torch.distributed "nccl"); weak scaling
 the only exchange is the bucketed gradient all-reduce overlapped with the encoder backward.  Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
-  roofline     -- for the dominant kernel (by time): algorithmic FLOP/s = sum over its launches of 2*MACs divided by the sum of
-                  its launch durations, measured with HIP events on the launch stream during extra instrumented steps that
-                  follow the timed region (so the events do not perturb `value`); peak = 157.3 TFLOP/s dense fp32 MFMA.
+  roofline     -- for the dominant kernel (by time): algorithmic FLOP/s = sum over its launches of 2*MACs of the DIRECT
+                  convolution divided by the sum of its launch durations, measured with HIP events on
+                  the launch stream during extra instrumented steps that follow the timed region (so the events do not
+                  perturb `value`); peak = 157.3 TFLOP/s dense fp32 MFMA.  The Winograd F(2x2,3x3) kernels execute 2.25x
+                  fewer multiply-accumulates than they are credited with, so their `frac` may exceed 1; `executed_frac` =
+                  frac / 2.25 is the share of the matrix peak their MFMAs actually occupy.
   cpu_baseline -- the CPU oracle (oracle/, a PyTorch-CPU restatement pinned to the reference's golden vectors; kind "port")
                   running the same training step on this box's host cores, on a bounded sample (small batch, few steps).
 """
@@ -182,8 +185,11 @@ def main():
         engine.PROFILE = None
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         name, (fl, sec, n) = dom
+        wino = "wino_" in name
         roofline = {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(name),
+                    "algorithm": "winograd F(2x2,3x3): 16/36 of the direct multiply-accumulates" if wino else "direct implicit GEMM",
+                    "executed_frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS / (2.25 if wino else 1.0),
                     "launches_per_step": n // args.profile_steps, "avg_launch_ms": sec / n * 1e3,
                     "avg_launch_gflop": fl / n / 1e9,
                     "by_kernel": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / args.profile_steps * 1e3,
