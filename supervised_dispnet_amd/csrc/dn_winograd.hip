@@ -309,9 +309,10 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     };
     auto affine_piece = [&](int i) {
       if constexpr (HA) {
-        const float fm = (float)((pmask >> i) & 1u);      // a pending BatchNorm makes relu(shift) out of a zero-filled pixel
+        // clamp to [floor, cap]: floor = 0 is the ReLU, cap = 0 re-zeroes a halo pixel the BatchNorm shift lifted (one v_med3 each)
+        const float cap = ((pmask >> i) & 1u) ? __builtin_huge_valf() : 0.f;
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[i][e] = fmaxf(relu_floor, fmaf(v[i][e], sc4[e], sh4[e])) * fm;
+        for (int e = 0; e < VW; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc4[e], sh4[e]), relu_floor, cap);
       }
     };
     auto row_piece = [&](int b) {                      // B^T d, in place: rows (0,1,2,3) <- (d0-d2, d1+d2, d2-d1, d1-d3)

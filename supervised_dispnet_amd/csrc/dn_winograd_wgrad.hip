@@ -121,7 +121,7 @@ __global__ void wino_wgrad_fold_kernel(const float* __restrict__ ws, float* __re
   }
 }
 
-template <bool HA>
+template <bool HA, int DBG>
 __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p) {
   extern __shared__ __align__(16) float smem[];
   char* smemB = reinterpret_cast<char*>(smem);
@@ -196,13 +196,10 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
     if (roleV) {
       const int py = 2 * (int)ty - 1, px = 2 * (int)tx - 1;
       off0 = (n * (int)S.sn + py * (int)S.sh + px * (int)S.sw + c_in_op + item_c) * 4;
-      unsigned m = 0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          m |= (live && (unsigned)(py + a) < (unsigned)p.IH && (unsigned)(px + b) < (unsigned)p.IW) ? (1u << (4 * a + b)) : 0u;
-      pmask = m;
+      // rows -1 / +2 and columns -1 / +2 of the patch are the only ones that can fall outside
+      unsigned cols = 0x6u | (px >= 0 ? 1u : 0u) | (px + 3 < p.IW ? 8u : 0u);
+      cols = live ? cols : 0u;
+      pmask = (py >= 0 ? cols : 0u) | (cols << 4) | (cols << 8) | (py + 3 < p.IH ? cols << 12 : 0u);
     } else {
       off0 = live ? (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 64 + item_c) * 4 : -1;
     }
@@ -223,9 +220,10 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
   };
   auto affine_piece = [&](int i) {
     if constexpr (HA) {
-      const float fm = (float)((pmask >> i) & 1u);
+      // clamp to [floor, cap]: floor = 0 is the ReLU, cap = 0 re-zeroes a halo pixel the BatchNorm shift lifted (one v_med3 each)
+      const float cap = ((pmask >> i) & 1u) ? __builtin_huge_valf() : 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(relu_floor, fmaf(v[i][e], sc4[e], sh4[e])) * fm;
+      for (int e = 0; e < 4; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc4[e], sh4[e]), relu_floor, cap);
     }
   };
   auto row_piece = [&](int b) {                      // B^T d, in place
@@ -308,7 +306,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
     auto body = [&](auto rolev_tag, auto loading_tag) __attribute__((always_inline)) {
       constexpr bool RV = decltype(rolev_tag)::value;
       constexpr bool LD = decltype(loading_tag)::value;
-      if constexpr (LD) decode(c + 2);
+      if constexpr (LD && !(DBG & 32)) decode(c + 2);
       __builtin_amdgcn_sched_barrier(0);
       wg_static_for<32>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
@@ -318,7 +316,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
         constexpr int cur = g & 1, nxt = cur ^ 1;
         acc[pp][h][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][h], fb[cur][nn], acc[pp][h][nn], 0, 0, 0);
         // ---- side work of this slot
-        if constexpr (g < 7) {
+        if constexpr (g < 7 && !(DBG & 16)) {
           constexpr int g1 = g + 1;
           constexpr int o = (g1 & 1) * G_PLANE + (g1 >> 1) * 2 * G_ROWB;
           if constexpr (qq == 0) fa[nxt][0] = *reinterpret_cast<const float*>(Gb + o);
@@ -327,19 +325,19 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
           if constexpr (qq == 3) fb[nxt][1] = *reinterpret_cast<const float*>(Vb + o + 128);
         }
         if constexpr (RV && LD) {
-          if constexpr (m >= 1 && m < 17) load_v(m - 1);
+          if constexpr (m >= 1 && m < 17 && !(DBG & 1)) load_v(m - 1);
         }
         if constexpr (RV && !LD) {
-          if constexpr (m < 16) affine_piece(m);
-          if constexpr (m >= 16 && m < 20) row_piece(m - 16);
-          if constexpr (m >= 20 && m < 28) col_piece(buf ^ 1, (m - 20) / 2, (m - 20) % 2);
+          if constexpr (m < 16 && !(DBG & 2)) affine_piece(m);
+          if constexpr (m >= 16 && m < 20 && !(DBG & 2)) row_piece(m - 16);
+          if constexpr (m >= 20 && m < 28 && !(DBG & 4)) col_piece(buf ^ 1, (m - 20) / 2, (m - 20) % 2);
         }
         if constexpr (!RV && LD) {
-          if constexpr (m >= 1 && m < 5) load_g(m - 1);
+          if constexpr (m >= 1 && m < 5 && !(DBG & 8)) load_g(m - 1);
         }
         if constexpr (!RV && !LD) {
-          if constexpr (m == 0) g_rows();
-          if constexpr (m >= 2 && m < 10 && (m % 2) == 0) g_cols(buf ^ 1, (m - 2) / 2);
+          if constexpr (m == 0 && !(DBG & 8)) g_rows();
+          if constexpr (m >= 2 && m < 10 && (m % 2) == 0 && !(DBG & 8)) g_cols(buf ^ 1, (m - 2) / 2);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -351,7 +349,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
       if (loading) body(std::false_type{}, std::true_type{});
       else body(std::false_type{}, std::false_type{});
     }
-    __syncthreads();
+    if (!(DBG & 64)) __syncthreads();
   }
 
   // ---- partial dU of this split: ws[split][pos][co][ci]
@@ -412,7 +410,19 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   p.OW = p.GW;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
-  auto kernel = p.any_affine ? wino_wgrad_kernel<true> : wino_wgrad_kernel<false>;
+  const char* dbg_env = getenv("DN_WINO_WG_DBG");
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  auto kernel = p.any_affine ? wino_wgrad_kernel<true, 0> : wino_wgrad_kernel<false, 0>;
+  switch (dbg) {
+    case 1: kernel = wino_wgrad_kernel<true, 1>; break;
+    case 3: kernel = wino_wgrad_kernel<true, 3>; break;
+    case 7: kernel = wino_wgrad_kernel<true, 7>; break;
+    case 15: kernel = wino_wgrad_kernel<true, 15>; break;
+    case 31: kernel = wino_wgrad_kernel<true, 31>; break;
+    case 63: kernel = wino_wgrad_kernel<true, 63>; break;
+    case 127: kernel = wino_wgrad_kernel<true, 127>; break;
+    default: break;
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLds);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino_wgrad_kernel, %zu): %s", kWgLds, hipGetErrorString(e));
