@@ -121,6 +121,14 @@ __global__ void wino_wgrad_fold_kernel(const float* __restrict__ ws, float* __re
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 wg_buffer_load2(__amdgpu_buffer_rsrc_t r, int voffset) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voffset, 0, 0);
+  return __builtin_bit_cast(f32x2, v);
+}
+
 template <bool HA, int DBG>
 __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p) {
   extern __shared__ __align__(16) float smem[];
@@ -149,11 +157,11 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
   const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
 
-  // ---- roles
-  const int group = wave >> 2, wq = wave & 3;
-  const bool roleV = (wq < 2) != (group == 1);
-  const int item_t = (wq & 1) * 4 + (lane >> 4);        // tile within the chunk
-  const int item_c = (lane & 15) * 4;                   // channel within the 64-wide block
+  // ---- staging role (the same for every thread): one input patch AND one gradient tile, two channels wide, of every other
+  //      chunk: waves 0-3 own the even chunks, waves 4-7 the odd ones
+  const int group = wave >> 2;
+  const int item_t = (tid & 255) >> 5;                  // tile within the chunk
+  const int item_c = (tid & 31) * 2;                    // channel pair within the 64-wide block
   const int stB = item_t * G_ROWB + item_c * 4;         // staging store offset inside a position plane
   const int pos0 = 4 * (wave >> 1) + 2 * (wave & 1);    // this wave's two positions
   const int frB = pos0 * G_PLANE + (lane >> 5) * G_ROWB + (lane & 31) * 4;   // fragment read offset (+ pp*G_PLANE + ks*2*G_ROWB + h*128)
@@ -168,127 +176,130 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][c][e] = 0.f;
 
-  // ---- staging state
-  f32x4 v[16];               // V role: the 4x4 patch; G role: v[0..3] = the 2x2 gradient tile
-  f32x4 sc4, sh4;
-  unsigned pmask = 0;
+  // ---- staging state: two patches in flight (vA / vB), one gradient tile (gv)
+  f32x2 vA[16], vB[16], gv[8];
+  unsigned pmA = 0, pmB = 0;
+  f32x2 sc2, sh2;
   const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
   const int gpixB = Cout * 4, growB = p.OW * Cout * 4;
   if constexpr (HA) {
     const bool op_aff = S.scale != nullptr;
-    const f32x4 l1 = *reinterpret_cast<const f32x4*>((op_aff ? S.scale : S.p) + (op_aff ? c_in_op + item_c : 0));
-    const f32x4 l2 = *reinterpret_cast<const f32x4*>((op_aff ? S.shift : S.p) + (op_aff ? c_in_op + item_c : 0));
+    const f32x2 l1 = *reinterpret_cast<const f32x2*>((op_aff ? S.scale : S.p) + (op_aff ? c_in_op + item_c : 0));
+    const f32x2 l2 = *reinterpret_cast<const f32x2*>((op_aff ? S.shift : S.p) + (op_aff ? c_in_op + item_c : 0));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sc4[e] = op_aff ? l1[e] : 1.f;
-      sh4[e] = op_aff ? l2[e] : 0.f;
+    for (int e = 0; e < 2; ++e) {
+      sc2[e] = op_aff ? l1[e] : 1.f;
+      sh2[e] = op_aff ? l2[e] : 0.f;
     }
   }
   const float relu_floor = (HA && S.scale != nullptr) ? 0.f : -__builtin_huge_valf();
-  int off0 = 0;
 
-  auto decode = [&](int target) {          // item of chunk `target`: tile -> offsets and masks
+  // tile of chunk `target` -> patch offset + validity mask (V) / tile offset (G)
+  auto decode_tile = [&](int target, unsigned* tx, unsigned* ty, int* n) -> bool {
     const int t = t_begin + target * GTC + item_t;
     const bool live = t < t_end;
+    const unsigned r = fastdiv_dev(live ? (unsigned)t : 0u, (unsigned)p.TW, p.mTW, tx);
+    *n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, ty);
+    return live;
+  };
+  auto load_patch = [&](f32x2 (&v)[16], unsigned& pm, int target) {
     unsigned tx, ty;
-    const unsigned r = fastdiv_dev(live ? (unsigned)t : 0u, (unsigned)p.TW, p.mTW, &tx);
-    const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
-    if (roleV) {
-      const int py = 2 * (int)ty - 1, px = 2 * (int)tx - 1;
-      off0 = (n * (int)S.sn + py * (int)S.sh + px * (int)S.sw + c_in_op + item_c) * 4;
-      // rows -1 / +2 and columns -1 / +2 of the patch are the only ones that can fall outside
-      unsigned cols = 0x6u | (px >= 0 ? 1u : 0u) | (px + 3 < p.IW ? 8u : 0u);
-      cols = live ? cols : 0u;
-      pmask = (py >= 0 ? cols : 0u) | (cols << 4) | (cols << 8) | (py + 3 < p.IH ? cols << 12 : 0u);
-    } else {
-      off0 = live ? (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 64 + item_c) * 4 : -1;
+    int n;
+    const bool live = decode_tile(target, &tx, &ty, &n);
+    const int py = 2 * (int)ty - 1, px = 2 * (int)tx - 1;
+    const int off0 = (n * (int)S.sn + py * (int)S.sh + px * (int)S.sw + c_in_op + item_c) * 4;
+    // rows -1 / +2 and columns -1 / +2 of the patch are the only ones that can fall outside
+    unsigned cols = 0x6u | (px >= 0 ? 1u : 0u) | (px + 3 < p.IW ? 8u : 0u);
+    cols = live ? cols : 0u;
+    pm = (py >= 0 ? cols : 0u) | (cols << 4) | (cols << 8) | (py + 3 < p.IH ? cols << 12 : 0u);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int off = off0 + (i >> 2) * shB + (i & 3) * swB;
+      asm volatile("" : "+v"(off));
+      off = ((pm >> i) & 1u) ? off : -1;
+      v[i] = wg_buffer_load2(rsrcX, off);
     }
   };
-  auto load_v = [&](int i) {
-    const int a = i >> 2, b = i & 3;
-    const bool ok = (pmask >> i) & 1u;
-    int off = off0 + a * shB + b * swB;
-    asm volatile("" : "+v"(off));
-    off = ok ? off : -1;
-    v[i] = wg_buffer_load(rsrcX, off);
+  auto load_grad = [&](int target) {
+    unsigned tx, ty;
+    int n;
+    const bool live = decode_tile(target, &tx, &ty, &n);
+    const int off0 = (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 64 + item_c) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = off0 + (i >> 1) * growB + (i & 1) * gpixB;
+      asm volatile("" : "+v"(off));
+      off = live ? off : -1;
+      gv[i] = wg_buffer_load2(rsrcG, off);
+    }
   };
-  auto load_g = [&](int i) {
-    int off = off0 + (i >> 1) * growB + (i & 1) * gpixB;
-    asm volatile("" : "+v"(off));
-    off = off0 < 0 ? -1 : off;
-    v[i] = wg_buffer_load(rsrcG, off);
-  };
-  auto affine_piece = [&](int i) {
+  auto affine_piece = [&](f32x2 (&v)[16], unsigned pm, int i) {
     if constexpr (HA) {
       // clamp to [floor, cap]: floor = 0 is the ReLU, cap = 0 re-zeroes a halo pixel the BatchNorm shift lifted (one v_med3 each)
-      const float cap = ((pmask >> i) & 1u) ? __builtin_huge_valf() : 0.f;
+      const float cap = ((pm >> i) & 1u) ? __builtin_huge_valf() : 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc4[e], sh4[e]), relu_floor, cap);
+      for (int e = 0; e < 2; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc2[e], sh2[e]), relu_floor, cap);
     }
   };
-  auto row_piece = [&](int b) {                      // B^T d, in place
-    const f32x4 d0 = v[0 + b], d1 = v[4 + b], d2 = v[8 + b];
+  auto row_piece = [&](f32x2 (&v)[16], int b) {                      // B^T d, in place
+    const f32x2 d0 = v[0 + b], d1 = v[4 + b], d2 = v[8 + b];
     v[0 + b] = d0 - d2;
     v[4 + b] = d1 + d2;
     v[8 + b] = d2 - d1;
     v[12 + b] = d1 - v[12 + b];
   };
-  auto col_piece = [&](int b2, int i, int half) {    // (B^T d) B and the LDS stores of transform row i
+  auto col_piece = [&](f32x2 (&v)[16], int b2, int i) {              // (B^T d) B and the LDS stores of transform row i
     char* dst = smemB + b2 * G_BUFB + G_OPB + stB + (4 * i) * G_PLANE;
-    if (half == 0) {
-      *reinterpret_cast<f32x4*>(dst + 0 * G_PLANE) = v[4 * i + 0] - v[4 * i + 2];
-      *reinterpret_cast<f32x4*>(dst + 1 * G_PLANE) = v[4 * i + 1] + v[4 * i + 2];
-    } else {
-      *reinterpret_cast<f32x4*>(dst + 2 * G_PLANE) = v[4 * i + 2] - v[4 * i + 1];
-      *reinterpret_cast<f32x4*>(dst + 3 * G_PLANE) = v[4 * i + 1] - v[4 * i + 3];
-    }
+    *reinterpret_cast<f32x2*>(dst + 0 * G_PLANE) = v[4 * i + 0] - v[4 * i + 2];
+    *reinterpret_cast<f32x2*>(dst + 1 * G_PLANE) = v[4 * i + 1] + v[4 * i + 2];
+    *reinterpret_cast<f32x2*>(dst + 2 * G_PLANE) = v[4 * i + 2] - v[4 * i + 1];
+    *reinterpret_cast<f32x2*>(dst + 3 * G_PLANE) = v[4 * i + 1] - v[4 * i + 3];
   };
-  // gradient tile y[a][b] = v[2a+b] -> u (rows): u0 = y0., u1 = y0. + y1., u2 = y0. - y1., u3 = y1.  (sign of A's last row dropped)
-  // stored as v[4 + 2i + b]; then g[i][.] = (u_i0, u_i0 + u_i1, u_i0 - u_i1, u_i1)
-  auto g_rows = [&]() {
-    v[4] = v[0];
-    v[5] = v[1];
-    v[6] = v[0] + v[2];
-    v[7] = v[1] + v[3];
-    v[8] = v[0] - v[2];
-    v[9] = v[1] - v[3];
-    v[10] = v[2];
-    v[11] = v[3];
-  };
+  // gradient tile y[a][b] = gv[2a+b] -> u (rows): u0 = y0., u1 = y0. + y1., u2 = y0. - y1., u3 = y1.  (sign of A's last row dropped);
+  // g[i][.] = (u_i0, u_i0 + u_i1, u_i0 - u_i1, u_i1)
   auto g_cols = [&](int b2, int i) {
     char* dst = smemB + b2 * G_BUFB + stB + (4 * i) * G_PLANE;
-    const f32x4 u0 = v[4 + 2 * i], u1 = v[5 + 2 * i];
-    *reinterpret_cast<f32x4*>(dst + 0 * G_PLANE) = u0;
-    *reinterpret_cast<f32x4*>(dst + 1 * G_PLANE) = u0 + u1;
-    *reinterpret_cast<f32x4*>(dst + 2 * G_PLANE) = u0 - u1;
-    *reinterpret_cast<f32x4*>(dst + 3 * G_PLANE) = u1;
+    f32x2 u0, u1;
+    if (i == 0) { u0 = gv[0]; u1 = gv[1]; }
+    else if (i == 1) { u0 = gv[0] + gv[2]; u1 = gv[1] + gv[3]; }
+    else if (i == 2) { u0 = gv[0] - gv[2]; u1 = gv[1] - gv[3]; }
+    else { u0 = gv[2]; u1 = gv[3]; }
+    *reinterpret_cast<f32x2*>(dst + 0 * G_PLANE) = u0;
+    *reinterpret_cast<f32x2*>(dst + 1 * G_PLANE) = u0 + u1;
+    *reinterpret_cast<f32x2*>(dst + 2 * G_PLANE) = u0 - u1;
+    *reinterpret_cast<f32x2*>(dst + 3 * G_PLANE) = u1;
+  };
+  auto stage_all = [&](f32x2 (&v)[16], unsigned pm, int b2) {        // affine + transform + store of a loaded patch (prologue)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) affine_piece(v, pm, i);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) row_piece(v, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) col_piece(v, b2, i);
   };
 
-  // ---- pipeline fill: group 0 stages chunk 0 completely, group 1 loads chunk 1 (it is transformed while chunk 0 is multiplied)
-  decode(group);
-  if (roleV) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) load_v(i);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) load_g(i);
-  }
+  // ---- pipeline: the patch of target chunk T is requested while chunk T-4 is multiplied, clamped + row-transformed during T-2,
+  //      column-transformed + stored during T-1; its gradient tile is requested during T-2 and stored during T-1.
+  //      Phase of a wave at chunk c: ph = (c - group) & 3:  0: request patch c+4 -> vA, gradient c+2; finish rows of vB (target c+2)
+  //                                                          1: store vB and the gradient (target c+1)
+  //                                                          2: request patch c+4 -> vB, gradient c+2; finish rows of vA (target c+2)
+  //                                                          3: store vA and the gradient (target c+1)
+  // prologue = the phases of chunks -4 .. -1
   if (group == 0) {
-    if (roleV) {
+    load_patch(vA, pmA, 0);
+    load_grad(0);
+    stage_all(vA, pmA, 0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) affine_piece(i);
+    for (int i = 0; i < 4; ++i) g_cols(0, i);
+    load_patch(vB, pmB, 2);           // phase 2 of chunk -2
+  } else {
+    load_patch(vA, pmA, 1);           // phase 0 of chunk -3
+    load_patch(vB, pmB, 3);           // phase 2 of chunk -1 (requests only; its rows are finished during chunk 1)
+    load_grad(1);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) row_piece(b);
+    for (int i = 0; i < 16; ++i) affine_piece(vA, pmA, i);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        col_piece(0, i, 0);
-        col_piece(0, i, 1);
-      }
-    } else {
-      g_rows();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) g_cols(0, i);
-    }
+    for (int b = 0; b < 4; ++b) row_piece(vA, b);
   }
   __syncthreads();
 
@@ -296,17 +307,24 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
   float fa[2][2], fb[2][2];
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    const bool loading = ((c - group) & 1) == 0;     // this wave: loads for chunk c+2, or transform + store of chunk c+1
+    const int ph = (c - group) & 3;
     const char* Gb = smemB + buf * G_BUFB + frB;
     const char* Vb = Gb + G_OPB;
     fa[0][0] = *reinterpret_cast<const float*>(Gb);
     fa[0][1] = *reinterpret_cast<const float*>(Gb + 128);
     fb[0][0] = *reinterpret_cast<const float*>(Vb);
     fb[0][1] = *reinterpret_cast<const float*>(Vb + 128);
-    auto body = [&](auto rolev_tag, auto loading_tag) __attribute__((always_inline)) {
-      constexpr bool RV = decltype(rolev_tag)::value;
-      constexpr bool LD = decltype(loading_tag)::value;
-      if constexpr (LD && !(DBG & 32)) decode(c + 2);
+    auto body = [&](auto ph_tag) __attribute__((always_inline)) {
+      constexpr int PH = decltype(ph_tag)::value;
+      constexpr bool REQ = (PH & 1) == 0;                  // request + finish-rows phase, else store phase
+      f32x2 (&vreq)[16] = PH == 0 ? vA : vB;               // PH 0: request into vA;  PH 2: into vB
+      unsigned& pmreq = PH == 0 ? pmA : pmB;
+      f32x2 (&vfin)[16] = (PH == 0 || PH == 1) ? vB : vA;  // PH 0: finish vB, PH 1: store vB;  PH 2 / 3: vA
+      const unsigned pmfin = (PH == 0 || PH == 1) ? pmB : pmA;
+      if constexpr (REQ && !(DBG & 32)) {
+        load_patch(vreq, pmreq, c + 4);
+        load_grad(c + 2);
+      }
       __builtin_amdgcn_sched_barrier(0);
       wg_static_for<32>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
@@ -324,30 +342,22 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
           if constexpr (qq == 2) fb[nxt][0] = *reinterpret_cast<const float*>(Vb + o);
           if constexpr (qq == 3) fb[nxt][1] = *reinterpret_cast<const float*>(Vb + o + 128);
         }
-        if constexpr (RV && LD) {
-          if constexpr (m >= 1 && m < 17 && !(DBG & 1)) load_v(m - 1);
+        if constexpr (REQ && !(DBG & 2)) {
+          if constexpr (m >= 8 && m < 24) affine_piece(vfin, pmfin, m - 8);
+          if constexpr (m >= 24 && m < 28) row_piece(vfin, m - 24);
         }
-        if constexpr (RV && !LD) {
-          if constexpr (m < 16 && !(DBG & 2)) affine_piece(m);
-          if constexpr (m >= 16 && m < 20 && !(DBG & 2)) row_piece(m - 16);
-          if constexpr (m >= 20 && m < 28 && !(DBG & 4)) col_piece(buf ^ 1, (m - 20) / 2, (m - 20) % 2);
-        }
-        if constexpr (!RV && LD) {
-          if constexpr (m >= 1 && m < 5 && !(DBG & 8)) load_g(m - 1);
-        }
-        if constexpr (!RV && !LD) {
-          if constexpr (m == 0 && !(DBG & 8)) g_rows();
-          if constexpr (m >= 2 && m < 10 && (m % 2) == 0 && !(DBG & 8)) g_cols(buf ^ 1, (m - 2) / 2);
+        if constexpr (!REQ && !(DBG & 4)) {
+          if constexpr (m < 8 && (m % 2) == 0) col_piece(vfin, buf ^ 1, m / 2);
+          if constexpr (m >= 8 && m < 16 && (m % 2) == 0) g_cols(buf ^ 1, (m - 8) / 2);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
     };
-    if (roleV) {
-      if (loading) body(std::true_type{}, std::true_type{});
-      else body(std::true_type{}, std::false_type{});
-    } else {
-      if (loading) body(std::false_type{}, std::true_type{});
-      else body(std::false_type{}, std::false_type{});
+    switch (ph) {
+      case 0: body(std::integral_constant<int, 0>{}); break;
+      case 1: body(std::integral_constant<int, 1>{}); break;
+      case 2: body(std::integral_constant<int, 2>{}); break;
+      default: body(std::integral_constant<int, 3>{}); break;
     }
     if (!(DBG & 64)) __syncthreads();
   }
