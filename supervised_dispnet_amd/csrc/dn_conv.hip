@@ -1504,6 +1504,7 @@ size_t dn_conv_wgrad_workspace_bytes(const dn_conv_desc* fwd) {
   size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
   if (head_wgrad_eligible(fwd, p) && head_wgrad_workspace_bytes(p) > need) need = head_wgrad_workspace_bytes(p);
   if (wino_wgrad_eligible(fwd, p) && wino_wgrad_workspace_bytes(p) > need) need = wino_wgrad_workspace_bytes(p);
+  if (thin_wgrad_eligible(fwd, p) && thin_wgrad_workspace_bytes(p) > need) need = thin_wgrad_workspace_bytes(p);
   return need;
 }
 
@@ -1523,6 +1524,12 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     p.g = dy;
     p.ws = reinterpret_cast<float*>(workspace);
     return launch_wino_wgrad(p, dw, as_stream(stream));
+  }
+  if (thin_wgrad_eligible(fwd, p) && workspace_bytes >= thin_wgrad_workspace_bytes(p)) {
+    for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
+    p.g = dy;
+    p.ws = reinterpret_cast<float*>(workspace);
+    return launch_thin_wgrad(p, dw, as_stream(stream));
   }
   choose_splits(&p);
   const size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);

@@ -128,4 +128,9 @@ bool wino_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
 size_t wino_wgrad_workspace_bytes(const IgemmParams& p);
 int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream);
 
+// dn_thin.hip: weight gradient of the thin full-resolution 3x3 layers (first encoder layer, iconv0) on 16x16x4 MFMAs from global memory
+bool thin_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
+size_t thin_wgrad_workspace_bytes(const IgemmParams& p);
+int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream);
+
 }  // namespace dn

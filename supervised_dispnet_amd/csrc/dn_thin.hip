@@ -1,0 +1,243 @@
+// Weight gradient of the THIN full-resolution 3x3 layers (gfx950 only): the first encoder layer (3 -> 64 on the NCHW image,
+// torchvision vgg16_bn features[0]) and iconv0 (16 + 1 -> 16, models/Disp_vgg_BN.py:105,185).  On the 32-wide implicit-GEMM
+// tiles these pad 16 output channels to 32 and every operand's taps*channels to a multiple of 32 (16+1 channels: 153 -> 192),
+// and their 1.7 M pixels x 16-64 gradient channels are read through LDS for 6-8 GFLOP of useful work: 0.5 ms per launch.
+//
+// Here:  dW[co][k] = sum over pixels of dy[pixel][co] * x[pixel + tap(k)][c(k)]  as 16x16x4 MFMAs straight from global memory:
+//   A = dy^T   (lane: co = lane & 15, pixel = lane >> 4)   one coalesced dword load per 16 output channels and 4 pixels,
+//   B = x      (lane: column k = lane & 15, pixel = lane >> 4)   one gathered dword load per 16 columns and 4 pixels; the
+//              columns are the framework's own [channel][3][3] order, operand by operand (a 16-column tile never straddles two
+//              operands, so the operand -- strides, nearest-x2 upsample, buffer descriptor -- is wave-uniform); halo and dead
+//              columns read zeros through the buffer bounds check.
+// A wave walks whole image rows, four pixels of one row per step, the next step's loads in flight under the current MFMAs; the
+// four waves of a block are summed through LDS and the blocks by a second, fixed-order pass (deterministic).
+#include <stdlib.h>
+
+#include "dn_internal.h"
+
+namespace dn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThinMaxTiles = 10;
+
+struct ThinTab {
+  int op[kThinMaxTiles];      // operand of this 16-column tile (-1: dead tile)
+  int e0[kThinMaxTiles];      // scalar-mode tile (tap < 0): first local column (c*9 + tap) inside its operand; else first channel
+  int tap[kThinMaxTiles];     // channel-mode tile (operands with C % 16 == 0): the tile is 16 consecutive channels of this tap, so
+                              //   a wave's gather is 64 contiguous bytes per pixel (the TA, one per CU, is what bounds this kernel)
+  int ntiles;
+};
+
+static bool thin_build_tab(const IgemmParams& p, ThinTab* tab) {
+  int nt = 0;
+  for (int s = 0; s < p.n_in; ++s) {
+    const int C = p.in[s].C;
+    if (C % 16 == 0 && p.in[s].sc == 1) {
+      for (int t = 0; t < 9; ++t)
+        for (int c0 = 0; c0 < C; c0 += 16) {
+          if (nt >= kThinMaxTiles) return false;
+          tab->op[nt] = s;
+          tab->e0[nt] = c0;
+          tab->tap[nt] = t;
+          ++nt;
+        }
+    } else {
+      for (int e = 0; e < C * 9; e += 16) {
+        if (nt >= kThinMaxTiles) return false;
+        tab->op[nt] = s;
+        tab->e0[nt] = e;
+        tab->tap[nt] = -1;
+        ++nt;
+      }
+    }
+  }
+  tab->ntiles = nt;
+  for (int j = nt; j < kThinMaxTiles; ++j) {
+    tab->op[j] = -1;
+    tab->e0[j] = 0;
+    tab->tap[j] = -1;
+  }
+  return true;
+}
+
+static bool thin_shape(const IgemmParams& p, int* ntc, int* nkt) {
+  ThinTab tab;
+  if (!thin_build_tab(p, &tab)) return false;
+  *ntc = p.Ntot / 16;
+  *nkt = tab.ntiles;
+  if (*ntc == 1 && *nkt <= 10) { *nkt = 10; return true; }
+  if (*ntc == 4 && *nkt <= 2) { *nkt = 2; return true; }
+  return false;
+}
+
+bool thin_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
+  if (getenv("DN_NO_THIN")) return false;
+  if (d->kind != DN_CONV_FWD) return false;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
+  if (d->IH != d->OH || d->IW != d->OW || (d->OW & 3)) return false;
+  if (p.Ntot % 16 != 0 || p.Ntot > 64) return false;
+  if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) return false;
+  for (int i = 0; i < p.n_in; ++i) {
+    const KOperand& o = p.in[i];
+    if (!o.small || o.scale != nullptr || o.C > 64) return false;
+  }
+  int ntc, nkt;
+  return thin_shape(p, &ntc, &nkt);
+}
+
+static int thin_blocks(const IgemmParams& p) {
+  const int rows = p.N * p.GH;
+  int blocks = (rows + 3) / 4;          // one image row per wave at least
+  if (blocks > 512) blocks = 512;       // two blocks per CU
+  return blocks;
+}
+
+size_t thin_wgrad_workspace_bytes(const IgemmParams& p) {
+  int ntc, nkt;
+  if (!thin_shape(p, &ntc, &nkt)) return 0;
+  return (size_t)thin_blocks(p) * ntc * 16 * nkt * 16 * sizeof(float);
+}
+
+template <int NTC, int NKT>
+__global__ void __launch_bounds__(256) thin_wgrad_kernel(const IgemmParams p, const ThinTab tab, int rows_per_wave) {
+  __shared__ float red[NTC * NKT * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, pp = lane >> 4;
+  const int gwave = blockIdx.x * 4 + wave;
+  const int OW = p.GW, OH = p.GH, Cout = p.Ntot;
+
+  // per-lane column constants, per tile: tap offsets, channel byte offset inside the operand, liveness
+  int cdy[NKT], cdx[NKT], ccb[NKT];
+  bool cval[NKT];
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    const int s = tab.op[j];
+    const KOperand& S = p.in[s < 0 ? 0 : s];
+    const bool chan_mode = tab.tap[j] >= 0;
+    const int e = tab.e0[j] + col;
+    const int c = chan_mode ? e : e / 9, tap = chan_mode ? tab.tap[j] : e - 9 * (e / 9);
+    cval[j] = s >= 0 && (chan_mode ? c < S.C : e < S.C * 9);
+    cdy[j] = tap / 3 - 1;
+    cdx[j] = tap - 3 * (tap / 3) - 1;
+    ccb[j] = c * (int)S.sc;
+  }
+  const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+
+  f32x4 acc[NTC][NKT];
+#pragma unroll
+  for (int i = 0; i < NTC; ++i)
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int rows = p.N * OH;
+  const int r_begin = gwave * rows_per_wave;
+  const int r_end = min(rows, r_begin + rows_per_wave);
+  const int steps_per_row = OW / 4;
+  const int nsteps = r_end > r_begin ? (r_end - r_begin) * steps_per_row : 0;
+
+  constexpr int D = 4;       // steps in flight: the gathers are latency-bound (a step is ~300 cycles of MFMA, a miss is thousands)
+  float a[D][NTC], b[D][NKT];
+  auto issue = [&](int which, int st) {
+    const int rr = st / steps_per_row;
+    const int x0 = (st - rr * steps_per_row) * 4;
+    const int r = r_begin + rr;
+    const int n = r / OH, y = r - n * OH;
+    const int m = r * OW + x0 + pp;
+#pragma unroll
+    for (int i = 0; i < NTC; ++i) a[which][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcG, (m * Cout + 16 * i + col) * 4, 0, 0));
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int s = tab.op[j];
+      const KOperand& S = p.in[s < 0 ? 0 : s];
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+      const int iy = y + cdy[j], ix = x0 + pp + cdx[j];
+      const bool ok = cval[j] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      int off = (n * (int)S.sn + (iy >> S.up) * (int)S.sh + (ix >> S.up) * (int)S.sw + ccb[j]) * 4;
+      off = ok ? off : -1;
+      b[which][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+    }
+  };
+  auto compute = [&](int which) {
+#pragma unroll
+    for (int i = 0; i < NTC; ++i)
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[which][i], b[which][j], acc[i][j], 0, 0, 0);
+  };
+  // software pipeline, D-1 steps ahead; steps past the end re-issue the last one (harmless) so the loop body has no branches
+  const int last = nsteps - 1;
+  if (nsteps > 0) {
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(d, d < last ? d : last);
+    for (int st = 0; st < nsteps; st += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int nx = st + d + D - 1;
+        issue((d + D - 1) % D, nx < last ? nx : last);
+        if (st + d < nsteps) compute(d);
+      }
+    }
+  }
+
+  // ---- block sum through LDS, then this block's partial [NTC*16 co][NKT*16 columns]
+  // C/D layout of the 16x16 tile: column = lane & 15, rows 4*(lane >> 4) + r
+  for (int w = 0; w < 4; ++w) {          // fixed order: deterministic
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < NTC; ++i)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = &red[(i * NKT + j) * 256 + (4 * pp + r) * 16 + col];
+            *dst = (w == 0 ? 0.f : *dst) + acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* out = p.ws + (size_t)blockIdx.x * (NTC * NKT * 256);
+  for (int e = tid; e < NTC * NKT * 256; e += 256) out[e] = red[e];
+}
+
+// dw[co][(ch_off + c)][tap] = sum over blocks of partial[(i*NKT + j)*256 + (co & 15)*16 + col]
+__global__ void thin_wgrad_reduce_kernel(const IgemmParams p, const ThinTab tab, const float* __restrict__ ws, float* __restrict__ dw, int nblocks,
+                                         int NTC, int NKT) {
+  const int total = NTC * NKT * 256;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int tile = e >> 8, within = e & 255;
+    const int i = tile / NKT, j = tile - i * NKT;
+    const int co = 16 * i + (within >> 4), col = within & 15;
+    const int s = tab.op[j];
+    if (s < 0) continue;
+    const KOperand& S = p.in[s];
+    const bool chan_mode = tab.tap[j] >= 0;
+    const int le = tab.e0[j] + col;
+    const int c = chan_mode ? le : le / 9, tap = chan_mode ? tab.tap[j] : le - 9 * (le / 9);
+    if (c >= S.C || co >= p.Ntot) continue;
+    float sum = 0.f;
+    for (int z = 0; z < nblocks; ++z) sum += ws[(size_t)z * total + e];
+    dw[((long long)co * p.D1 + S.ch_off + c) * 9 + tap] = sum;
+  }
+}
+
+int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
+  ThinTab tab;
+  int ntc, nkt;
+  if (!thin_build_tab(p, &tab) || !thin_shape(p, &ntc, &nkt)) {
+    set_error("thin wgrad: unsupported shape");
+    return DN_ERR_UNSUPPORTED;
+  }
+  const int blocks = thin_blocks(p);
+  const int rows = p.N * p.GH;
+  const int rpw = (rows + blocks * 4 - 1) / (blocks * 4);
+  if (ntc == 1) hipLaunchKernelGGL((thin_wgrad_kernel<1, 10>), dim3(blocks), dim3(256), 0, stream, p, tab, rpw);
+  else hipLaunchKernelGGL((thin_wgrad_kernel<4, 2>), dim3(blocks), dim3(256), 0, stream, p, tab, rpw);
+  set_last_kernel("dn::thin_wgrad_kernel<%d, %d>", ntc, nkt);
+  int rc = check_launch("thin_wgrad_kernel");
+  if (rc != DN_OK) return rc;
+  const int total = ntc * nkt * 256;
+  hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p, tab, p.ws, dw, blocks, ntc, nkt);
+  return check_launch("thin_wgrad_reduce_kernel");
+}
+
+}  // namespace dn

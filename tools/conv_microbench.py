@@ -16,6 +16,8 @@ LAYERS = {  # name: (cin, cout, H, W, transposed)
     "c512_512_8x26": (512, 512, 8, 26, False),
     "c768_256_8x26": (768, 256, 8, 26, False),
     "t512_256_4x13": (512, 256, 4, 13, True),
+    "c16_16_128x416": (16, 16, 128, 416, False),
+    "c32_16_128x416": (32, 16, 128, 416, False),
 }
 
 def main():
