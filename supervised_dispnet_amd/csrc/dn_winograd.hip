@@ -62,7 +62,7 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
   if (p.nphases != 1 || p.ph[0].ntaps != 9) return false;
-  if (p.Ntot < 64 || (p.Ntot & 3)) return false;
+  if (p.Ntot < 64) return false;
   if ((long long)p.M * 4 >= (1ll << 31)) return false;
   {
     // a block always computes 64 tiles x 64 output channels: not worth it (and not better than the direct kernel's 64-row tiles)
@@ -76,20 +76,22 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   }
   for (int i = 0; i < p.n_in; ++i) {
     const KOperand& o = p.in[i];
-    if (!o.vec || !o.small || o.up != 0 || (o.C % WKC) != 0) return false;
+    // a 1-channel piece (the upsampled disparity inside the decoder's concats, models/Disp_vgg_BN.py:176,182) rides along as a
+    // sixteen-wide chunk with one live channel; everything else must be 16-aligned float4-addressable channels
+    const bool scalar1 = o.C == 1 && o.small && o.scale == nullptr;
+    if (!scalar1 && (!o.vec || !o.small || o.up != 0 || (o.C % WKC) != 0)) return false;
     if (o.scale != nullptr && ((reinterpret_cast<uintptr_t>(o.scale) | reinterpret_cast<uintptr_t>(o.shift)) & 15)) return false;
   }
   for (int i = 0; i < p.n_out; ++i) {
-    const KResult& r = p.out[i];
-    if ((r.C & 3) || (r.sw & 3) || (reinterpret_cast<uintptr_t>(r.p) & 15) || !r.linear) return false;
+    if (!p.out[i].linear) return false;       // (results that are not float4-addressable take the element-wise store path)
   }
   if (p.bias != nullptr && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;
   return true;
 }
 
-static int wino_ktot(const IgemmParams& p) {
+static int wino_ktot(const IgemmParams& p) {      // K axis: the operands one after the other, each padded to whole 16-channel chunks
   int k = 0;
-  for (int i = 0; i < p.n_in; ++i) k += p.in[i].C;
+  for (int i = 0; i < p.n_in; ++i) k += (p.in[i].C + WKC - 1) / WKC * WKC;
   return k;
 }
 
@@ -103,7 +105,6 @@ long long wino_packed_elems(const IgemmParams& p) { return (long long)(wino_ktot
 // float4 a lane feeds to four consecutive v_mfma_f32_32x32x2_f32 as the B operand (the two half-waves hold k 0-3 / 4-7).
 __global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
   // one thread per (8-k group, 32-cout group, lane, e) = one (n, k) pair: 9 weight loads, all 16 positions written
-  const int Ktot = p.n_is_dim0 ? p.D1 : p.D0;
   const long long npairs = total >> 4;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < npairs; idx += (long long)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
@@ -115,8 +116,18 @@ __global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ 
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
-    if (n < p.Ntot && k < Ktot) {                           // (padding columns and the slack chunk past the last k are zeros)
-      const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + k) : ((long long)k * p.D1 + n)) * 9;
+    // k -> (operand, channel): operands are padded to whole 16-channel chunks on the K axis
+    int cc = -1, kb = 0;
+#pragma unroll
+    for (int s = 0; s < DN_MAX_OPERANDS; ++s) {
+      if (s < p.n_in) {
+        const int C = p.in[s].C;
+        if (k >= kb && k < kb + C) cc = p.in[s].ch_off + (k - kb);
+        kb += (C + WKC - 1) / WKC * WKC;
+      }
+    }
+    if (n < p.Ntot && cc >= 0) {                            // (padding rows / columns and the slack chunk past the last k are zeros)
+      const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + cc) : ((long long)cc * p.D1 + n)) * 9;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int a = p.tdy[t] + 1, b = p.tdx[t] + 1;       // filter tap applied to input offset (a-1, b-1)
@@ -277,7 +288,8 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     const KOperand& S = p.in[s];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
     const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
-    const int nch = S.C / WKC;
+    const int nch = (S.C + WKC - 1) / WKC;
+    const bool scalar1 = S.C == 1;         // 1-channel piece: dword gathers (with the nearest-x2 upsample), live in channel 0 only
     const int off0 = (pn * (int)S.sn + py * (int)S.sh + px * (int)S.sw + k0) * 4;
     const bool op_aff = S.scale != nullptr;
     const char* scp = reinterpret_cast<const char*>(op_aff ? S.scale : S.p) + (op_aff ? k0 * 4 : 0);
@@ -290,6 +302,16 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     auto load_v = [&](int i) {
       const int a = i >> 2, b = i & 3;
       const bool ok = (pmask >> i) & 1u;
+      if (scalar1) {
+        int off = (pn * (int)S.sn + ((py + a) >> S.up) * (int)S.sh + ((px + b) >> S.up) * (int)S.sw) * 4;
+        off = (ok && k0 == 0) ? off : -1;
+        const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        fV t;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) t[e] = e == 0 ? x : 0.f;
+        v[i] = t;
+        return;
+      }
       int off = off0 + cnB + a * shB + b * swB;
       asm volatile("" : "+v"(off));
       off = ok ? off : -1;                               // past num_records: the buffer load returns zeros
@@ -519,17 +541,26 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     }
   }
 
-  // ---- bias, activation, channel-split / accumulating float4 stores
+  // ---- bias, activation, channel-split / accumulating stores: float4 along the channels when the four columns lie in one
+  //      float4-addressable result, element-wise otherwise (the 1-channel disparity piece of a concat's input gradient)
   if (n_first < p.Ntot) {
     int seg = 0;
     if (p.n_out > 1 && n_first >= p.out[1].n_begin) seg = 1;
     if (p.n_out > 2 && n_first >= p.out[2].n_begin) seg = 2;
     const KResult& R = p.out[seg];
+    const bool fast4 = (n_first + 3 < R.n_begin + R.C) && ((R.n_begin | R.C) & 3) == 0 && (R.sw & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(R.p) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     float* obase = R.p + (n_first - R.n_begin);
     const long long sw = R.sw;
     const bool accumulate = R.accumulate != 0;
     f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bias = *reinterpret_cast<const f32x4*>(p.bias + n_first);
+    if (p.bias != nullptr) {
+      if (fast4) bias = *reinterpret_cast<const f32x4*>(p.bias + n_first);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[e] = n_first + e < p.Ntot ? p.bias[n_first + e] : 0.f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       const int t = mb * BT + tg + 16 * k;
@@ -542,12 +573,28 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            float* o = obase + (pix0 + (long long)a * p.OW + b) * sw;
+            const long long pix = pix0 + (long long)a * p.OW + b;
             f32x4 val;
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = wino_act(Y[k][a][b][e] + bias[e], p.act, p.act_p0, p.act_p1);
-            if (accumulate) val += *reinterpret_cast<const f32x4*>(o);
-            *reinterpret_cast<f32x4*>(o) = val;
+            if (fast4) {
+              float* o = obase + pix * sw;
+              if (accumulate) val += *reinterpret_cast<const f32x4*>(o);
+              *reinterpret_cast<f32x4*>(o) = val;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int col = n_first + e;
+                if (col < p.Ntot) {
+                  int sg = 0;
+                  if (p.n_out > 1 && col >= p.out[1].n_begin) sg = 1;
+                  if (p.n_out > 2 && col >= p.out[2].n_begin) sg = 2;
+                  const KResult& Q = p.out[sg];
+                  float* o = Q.p + pix * Q.sw + (col - Q.n_begin);
+                  *o = Q.accumulate ? *o + val[e] : val[e];
+                }
+              }
+            }
           }
       }
     }

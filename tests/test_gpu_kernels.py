@@ -65,6 +65,8 @@ CONV_CASES = [
     ("3x3_wino_cat64_aff", (64, 128),   (False, False),    64, 3, 1, 1, False, 0, 2, 20, 30, ACT_LEAKY, True),
     ("3x3_wino_cat64",    (128, 64),    (False, False),    128, 3, 1, 1, False, 0, 3, 18, 22, ACT_NONE, False),
     ("3x3_wino_64_64",    (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 24, 44, ACT_NONE, False),
+    ("3x3_wino_cat_193",  (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 24, 44, ACT_LEAKY, False),
+    ("3x3_wino_cat_97",   (32, 64, 1),  (False, False, True), 32, 3, 1, 1, False, 0, 2, 24, 44, ACT_LEAKY, False),
     ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
     ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
     ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
