@@ -153,6 +153,47 @@ def test_plan_describes_conv_transpose_and_its_input_gradient(lib, k, s, p, op, 
     np.testing.assert_allclose(sim, x.grad.permute(0, 2, 3, 1).numpy(), atol=1e-10)
 
 
+def _desc3x3(N, H, W, cins, cout, kind=None, strides_ok=True, ups=None):
+    from supervised_dispnet_amd._lib import CONV_FWD, ConvDesc
+    d = ConvDesc()
+    d.kind = CONV_FWD if kind is None else kind
+    d.N, d.IH, d.IW, d.OH, d.OW, d.R, d.S, d.stride, d.pad = N, H, W, H, W, 3, 3, 1, 1
+    d.n_in = len(cins)
+    for i, c in enumerate(cins):
+        up = 1 if (ups and ups[i]) else 0
+        h, w = H >> up, W >> up
+        d.in_[i].data = 4096 * (i + 1)          # fake, 16-byte aligned: host planning only looks at presence / alignment
+        d.in_[i].C, d.in_[i].up_shift = c, up
+        d.in_[i].stride_c, d.in_[i].stride_w, d.in_[i].stride_h, d.in_[i].stride_n = 1, c, w * c, h * w * c
+    d.n_out = 1
+    d.out[0].data, d.out[0].C = 1 << 20, cout
+    d.out[0].stride_w, d.out[0].stride_h, d.out[0].stride_n = cout, W * cout, H * W * cout
+    return d
+
+
+def test_weight_layout_follows_the_geometry(lib):
+    """dn_conv_weight_layout (host only): Winograd for the 3x3/s1/p1 layers with 16-aligned channels, even extents and enough
+    tiles -- including a decoder concat with the 1-channel upsampled disparity piece --, the implicit GEMM otherwise; the packed
+    size is 16 positions x (K padded per operand to 16, + one chunk of prefetch slack) x (Cout padded to 64)."""
+    L = lambda d: lib.dn_conv_weight_layout(C.byref(d))
+    assert L(_desc3x3(32, 64, 208, (128,), 128)) == 1
+    assert L(_desc3x3(32, 32, 104, (64, 128, 1), 64, ups=(0, 0, 1))) == 1
+    assert L(_desc3x3(32, 128, 416, (3,), 64)) == 0            # first layer: 3 channels
+    assert L(_desc3x3(32, 128, 416, (16, 1), 16, ups=(0, 1))) == 0   # 16 output channels: a 64-wide tile would be 3/4 padding
+    assert L(_desc3x3(2, 4, 6, (256,), 256)) == 0              # 12 tiles: stays on the direct kernel
+    assert L(_desc3x3(2, 15, 20, (256,), 256)) == 0            # odd extent
+    d = _desc3x3(32, 32, 104, (64, 128, 1), 64, ups=(0, 0, 1))
+    assert lib.dn_conv_packed_weight_elems(C.byref(d)) == 16 * (64 + 128 + 16 + 16) * 64
+    d5 = _desc3x3(32, 32, 104, (64,), 64)
+    d5.R = d5.S = 5
+    d5.pad = 2
+    assert L(d5) == 0
+    # the weight gradient: Winograd for 64-aligned layers, the thin kernel for the full-resolution 16 / 3-channel layers; both
+    # report a workspace
+    for dd in (_desc3x3(32, 64, 208, (128,), 128), _desc3x3(32, 128, 416, (16, 1), 16, ups=(0, 1)), _desc3x3(32, 128, 416, (3,), 64)):
+        assert lib.dn_conv_wgrad_workspace_bytes(C.byref(dd)) > 0
+
+
 def test_bad_descriptors_are_rejected_not_crashing(lib):
     from supervised_dispnet_amd._lib import CONV_FWD, ConvDesc
     d = ConvDesc()

@@ -8,18 +8,19 @@ dev = torch.device("cuda:0")
 buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 os.environ["DN_WINO_DBG"] = sys.argv[1] if len(sys.argv) > 1 else "4"
 os.environ["DN_WINO_DBGPTR"] = hex(buf.data_ptr())
-for cin, cout, H, W in [(256, 256, 32, 104)]:
+for cin, cout, H, W in [(64, 64, 128, 416), (128, 128, 64, 208), (256, 256, 32, 104), (512, 512, 16, 52)]:
     mod = nn.Conv2d(cin, cout, 3, 1, 1).to(dev)
     layer = engine.ConvLayer(mod)
     x = engine.Act(torch.randn(32, H, W, cin, device=dev), 32, H, W, cin)
     for _ in range(3):
         engine.conv_forward(layer, [engine.Piece(x)])
     torch.cuda.synchronize()
-    nblk = ((32 * H * W // 4 + 63) // 64) * (cout // 64)
+    bt = 64 if os.environ.get('DN_WINO_MTW') == '2' else 32
+    nblk = ((32 * H * W // 4 + bt - 1) // bt) * (cout // 64)
     t = buf[: ((nblk + 7) // 8 * 8) * 4].view(-1, 4).cpu()
     t = t[t[:, 3] > 0]
     pro = (t[:, 1] - t[:, 0]).float().mean().item(); loop = (t[:, 2] - t[:, 1]).float().mean().item(); epi = (t[:, 3] - t[:, 2]).float().mean().item()
     nch = cin // 16
-    print("cin%d cout%d %dx%d: blocks %d prologue %.0f loop %.0f (%.0f per chunk, ideal %d) epilogue %.0f  [clock64 ticks]" % (cin, cout, H, W, len(t), pro, loop, loop / nch, 8192, epi))
+    print("cin%d cout%d %dx%d: blocks %d prologue %.0f loop %.0f (%.0f per chunk; MFMA time of the two co-resident blocks 8192) epilogue %.0f  [clock64 ticks]" % (cin, cout, H, W, len(t), pro, loop, loop / nch, epi))
     span = (t[:, 3].max() - t[:, 0].min()).item()
     print("   kernel span %d ticks" % span)
