@@ -800,6 +800,89 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
   conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
 }
 
+// ------------------------------------------------------------------------------------------------ first layer (stem)
+// conv3x3 of a <= 4-channel image (the NCHW user tensor through its strides) to 64 channels, torchvision vgg16_bn features[0]:
+// K = 27 is one MFMA chunk, so on the tiled kernel a block's whole "main loop" is a single barrier-bound iteration and the launch
+// is all fixed cost (0.41 ms for 5.9 GFLOP).  Here a wave gathers its 32 pixels' taps straight into A fragments (14 dword loads,
+// coalesced along x), keeps the 28 x 64 weights in B-fragment registers for the whole kernel, and blocks walk the 128-pixel
+// tiles grid-stride; the epilogue (bias, activation, BatchNorm partial statistics per 128-pixel tile) is the shared one.
+__global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
+  __shared__ __align__(16) float As[4 * 64 + 64];
+  __shared__ int rowpix[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const KOperand& S = p.in[0];
+  const int C = S.C, K = 9 * C, kh = lane >> 5;
+  constexpr int NS = 18;                           // k-steps of 2: up to 4 channels x 9 taps = 36
+  const int nsteps = (K + 1) / 2;
+  const int Kp = p.ph[0].nchunks * kChunk;
+  // per-lane k-step constants: this lane's k = 2s + kh -> (tap, channel); weights from the packed rows (k = tap*C + c)
+  int kdy[NS], kdx[NS], kco[NS];
+  float wreg[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int k = 2 * s + kh;
+    const bool live = s < nsteps && k < K;
+    const int tap = live ? k / C : 0, c = live ? k - tap * C : 0;
+    kdy[s] = live ? (int)p.tdy[tap] : 127;         // 127: dead step (fails the bounds test)
+    kdx[s] = (int)p.tdx[tap];
+    kco[s] = c * (int)S.sc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wreg[s][j] = live ? p.w[(long long)((lane & 31) + 32 * j) * Kp + k] : 0.f;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+  const int ntiles = (p.M + 127) / 128;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    if (tid < 128) rowpix[tid] = (m0 + tid) < p.M ? m0 + tid : -1;
+    const int m = m0 + 32 * wave + (lane & 31);
+    const bool live = m < p.M;
+    unsigned gx, gy;
+    const unsigned t = fastdiv_dev(live ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+    const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
+    const int base = n * (int)S.sn + (int)gy * (int)S.sh + (int)gx * (int)S.sw;
+    float a[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int iy = (int)gy + kdy[s], ix = (int)gx + kdx[s];
+      const bool ok = live && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      int off = (base + kdy[s] * (int)S.sh + kdx[s] * (int)S.sw + kco[s]) * 4;
+      off = ok ? off : -1;
+      a[s] = s < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0)) : 0.f;
+    }
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s < nsteps) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[s][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[s][1], acc[0][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    conv_epilogue<128, 64, 32, 64>(p, acc, rowpix, As, m0, 0);
+    __syncthreads();
+  }
+}
+
+static bool stem_eligible(const dn_conv_desc* d, const IgemmParams& p) {
+  if (getenv("DN_NO_STEM")) return false;
+  if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
+  if (p.n_in != 1 || p.n_out != 1 || p.Ntot != 64 || p.nphases != 1) return false;
+  const KOperand& o = p.in[0];
+  return o.C <= 4 && o.up == 0 && o.scale == nullptr && o.small && p.out[0].linear;
+}
+
+static int launch_stem(const IgemmParams& p, hipStream_t stream) {
+  int blocks = (p.M + 127) / 128;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  set_last_kernel("dn::stem_conv_kernel");
+  return check_launch("stem_conv_kernel");
+}
+
 // ----------------------------------------------------------------------------------------------- weight gradient
 // ws[split][n][k] = sum over the split's pixels of G[pixel][n] * A[pixel][k].  Tile: BNW (n) x 128 (k), 32 pixels per step.
 // ALLVEC (every gathered operand and G float4-addressable with int32 offsets): straight-line staging, see igemm_conv_kernel.
@@ -1398,6 +1481,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     if (head_dgrad_eligible(d, p)) return launch_head_dgrad(p, s);
   }
   if (wino_eligible(d, p)) return launch_wino_conv(p, s);
+  if (stem_eligible(d, p)) return launch_stem(p, s);
   // Few row tiles (the 4x13 / 8x26 decoder levels at b32: 13-52 tiles of 128 rows) leave most of the 256 CUs without a block;
   // 64-row tiles double the block count at the same per-wave MFMA density along N.  Not with batch statistics: the
   // bn_partial layout is per 128-row tile.

@@ -31,28 +31,31 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const IgemmParams p, int 
   for (int i = threadIdx.x; i < ntaps * C; i += 256) wsm[i] = p.w[i];
   __syncthreads();
   const int cg = threadIdx.x & ((1 << LG) - 1);
-  const long long pix = (long long)blockIdx.x * (256 >> LG) + (threadIdx.x >> LG);
-  const bool live = pix < p.M;
-  unsigned gx, gy;
-  const unsigned t = fastdiv_dev(live ? (unsigned)pix : 0u, (unsigned)p.GW, p.mGW, &gx);
-  const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
-  const int by = (int)gy * p.sy, bx = (int)gx * p.sx;
-  float acc = 0.f;
-  for (int j = 0; j < ntaps; ++j) {
-    const int iy = by + p.tdy[j], ix = bx + p.tdx[j];
-    if (live && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(S.p + (long long)n * S.sn + (long long)iy * S.sh + (long long)ix * S.sw + cg * 4);
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + cg * 4);
-      acc += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+  // grid-stride over the pixel groups: the weight preload + barrier above is paid once per block, not once per 64 pixels
+  for (long long base = (long long)blockIdx.x * (256 >> LG); base < p.M; base += (long long)gridDim.x * (256 >> LG)) {
+    const long long pix = base + (threadIdx.x >> LG);
+    const bool live = pix < p.M;
+    unsigned gx, gy;
+    const unsigned t = fastdiv_dev(live ? (unsigned)pix : 0u, (unsigned)p.GW, p.mGW, &gx);
+    const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
+    const int by = (int)gy * p.sy, bx = (int)gx * p.sx;
+    float acc = 0.f;
+    for (int j = 0; j < ntaps; ++j) {
+      const int iy = by + p.tdy[j], ix = bx + p.tdx[j];
+      if (live && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(S.p + (long long)n * S.sn + (long long)iy * S.sh + (long long)ix * S.sw + cg * 4);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + cg * 4);
+        acc += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+      }
     }
-  }
-  for (int d = 1; d < (1 << LG); d <<= 1) acc += __shfl_xor(acc, d);
-  if (live && cg == 0) {
-    const KResult& R = p.out[0];
-    float v = head_act(acc + (p.bias ? p.bias[0] : 0.f), p.act, p.act_p0, p.act_p1);
-    float* o = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
-    if (R.accumulate) v += *o;
-    *o = v;
+    for (int d = 1; d < (1 << LG); d <<= 1) acc += __shfl_xor(acc, d);
+    if (live && cg == 0) {
+      const KResult& R = p.out[0];
+      float v = head_act(acc + (p.bias ? p.bias[0] : 0.f), p.act, p.act_p0, p.act_p1);
+      float* o = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
+      if (R.accumulate) v += *o;
+      *o = v;
+    }
   }
 }
 
@@ -69,24 +72,24 @@ __global__ void __launch_bounds__(256) head_dgrad_kernel(const IgemmParams p, in
   __syncthreads();
   const KOperand& G = p.in[0];
   const int cg = threadIdx.x & ((1 << LG) - 1);
-  const long long pix = (long long)blockIdx.x * (256 >> LG) + (threadIdx.x >> LG);
-  if (pix >= p.M) return;
-  unsigned gx, gy;
-  const unsigned t = fastdiv_dev((unsigned)pix, (unsigned)p.GW, p.mGW, &gx);
-  const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < ntaps; ++j) {
-    const int iy = (int)gy + p.tdy[j], ix = (int)gx + p.tdx[j];
-    if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
-      const float g = G.p[(long long)n * G.sn + (long long)iy * G.sh + (long long)ix * G.sw];
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + cg * 4);
-      acc += g * w;
+  for (long long pix = (long long)blockIdx.x * (256 >> LG) + (threadIdx.x >> LG); pix < p.M; pix += (long long)gridDim.x * (256 >> LG)) {
+    unsigned gx, gy;
+    const unsigned t = fastdiv_dev((unsigned)pix, (unsigned)p.GW, p.mGW, &gx);
+    const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < ntaps; ++j) {
+      const int iy = (int)gy + p.tdy[j], ix = (int)gx + p.tdx[j];
+      if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+        const float g = G.p[(long long)n * G.sn + (long long)iy * G.sh + (long long)ix * G.sw];
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + cg * 4);
+        acc += g * w;
+      }
     }
+    const KResult& R = p.out[0];
+    f32x4* o = reinterpret_cast<f32x4*>(R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw + cg * 4);
+    if (R.accumulate) acc += *o;
+    *o = acc;
   }
-  const KResult& R = p.out[0];
-  f32x4* o = reinterpret_cast<f32x4*>(R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw + cg * 4);
-  if (R.accumulate) acc += *o;
-  *o = acc;
 }
 
 // -------------------------------------------------------------------------------------------------- weight gradient
@@ -181,7 +184,9 @@ bool head_fwd_eligible(const dn_conv_desc* d, const IgemmParams& p) {
 int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
   const int LG = log2_exact(p.in[0].C / 4);
   const int px = 256 >> LG;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((p.M + px - 1) / px), dim3(256), p.ph[0].ntaps * p.in[0].C * sizeof(float), stream, p, LG);
+  int hblocks = (p.M + px - 1) / px;
+  if (hblocks > 2048) hblocks = 2048;          // 8 blocks per CU, grid-stride
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(hblocks), dim3(256), p.ph[0].ntaps * p.in[0].C * sizeof(float), stream, p, LG);
   set_last_kernel("dn::head_fwd_kernel");
   return check_launch("head_fwd_kernel");
 }
@@ -196,7 +201,9 @@ bool head_dgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
 int launch_head_dgrad(const IgemmParams& p, hipStream_t stream) {
   const int LG = log2_exact(p.Ntot / 4);
   const int px = 256 >> LG;
-  hipLaunchKernelGGL(head_dgrad_kernel, dim3((p.M + px - 1) / px), dim3(256), p.ph[0].ntaps * p.Ntot * sizeof(float), stream, p, LG,
+  int hblocks = (p.M + px - 1) / px;
+  if (hblocks > 2048) hblocks = 2048;
+  hipLaunchKernelGGL(head_dgrad_kernel, dim3(hblocks), dim3(256), p.ph[0].ntaps * p.Ntot * sizeof(float), stream, p, LG,
                      p.ph[0].nchunks * kChunk);
   set_last_kernel("dn::head_dgrad_kernel");
   return check_launch("head_dgrad_kernel");

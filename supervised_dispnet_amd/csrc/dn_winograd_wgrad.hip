@@ -424,13 +424,11 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   auto kernel = p.any_affine ? wino_wgrad_kernel<true, 0> : wino_wgrad_kernel<false, 0>;
   switch (dbg) {
-    case 1: kernel = wino_wgrad_kernel<true, 1>; break;
-    case 3: kernel = wino_wgrad_kernel<true, 3>; break;
-    case 7: kernel = wino_wgrad_kernel<true, 7>; break;
-    case 15: kernel = wino_wgrad_kernel<true, 15>; break;
-    case 31: kernel = wino_wgrad_kernel<true, 31>; break;
-    case 63: kernel = wino_wgrad_kernel<true, 63>; break;
-    case 127: kernel = wino_wgrad_kernel<true, 127>; break;
+    case 2: kernel = wino_wgrad_kernel<true, 2>; break;
+    case 6: kernel = wino_wgrad_kernel<true, 6>; break;
+    case 22: kernel = wino_wgrad_kernel<true, 22>; break;
+    case 54: kernel = wino_wgrad_kernel<true, 54>; break;
+    case 118: kernel = wino_wgrad_kernel<true, 118>; break;
     default: break;
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLds);
