@@ -184,6 +184,9 @@ def test_weight_layout_follows_the_geometry(lib):
     assert L(_desc3x3(2, 15, 20, (256,), 256)) == 0            # odd extent
     d = _desc3x3(32, 32, 104, (64, 128, 1), 64, ups=(0, 0, 1))
     assert lib.dn_conv_packed_weight_elems(C.byref(d)) == 16 * (64 + 128 + 16 + 16) * 64
+    from supervised_dispnet_amd._lib import CONV_DGRAD
+    dh = _desc3x3(32, 32, 104, (1,), 64, kind=CONV_DGRAD)       # input gradient of a disparity head: its own kernel, igemm layout
+    assert L(dh) == 0
     d5 = _desc3x3(32, 32, 104, (64,), 64)
     d5.R = d5.S = 5
     d5.pad = 2

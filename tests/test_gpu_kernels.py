@@ -67,6 +67,8 @@ CONV_CASES = [
     ("3x3_wino_64_64",    (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 24, 44, ACT_NONE, False),
     ("3x3_wino_cat_193",  (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 24, 44, ACT_LEAKY, False),
     ("3x3_wino_cat_97",   (32, 64, 1),  (False, False, True), 32, 3, 1, 1, False, 0, 2, 24, 44, ACT_LEAKY, False),
+    ("3x3_wino_iconv2",   (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 32, 104, ACT_LEAKY, False),
+    ("3x3_wino_iconv1",   (32, 64, 1),  (False, False, True), 32, 3, 1, 1, False, 0, 2, 64, 208, ACT_LEAKY, False),
     ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
     ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
     ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
