@@ -199,25 +199,31 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(const IgemmParams p, co
   for (int e = tid; e < NTC * NKT * 256; e += 256) out[e] = red[e];
 }
 
-// dw[co][(ch_off + c)][tap] = sum over blocks of partial[(i*NKT + j)*256 + (co & 15)*16 + col]
-__global__ void thin_wgrad_reduce_kernel(const IgemmParams p, const ThinTab tab, const float* __restrict__ ws, float* __restrict__ dw, int nblocks,
-                                         int NTC, int NKT) {
+// dw[co][(ch_off + c)][tap] = sum over blocks of partial[(i*NKT + j)*256 + (co & 15)*16 + col]: 32 consecutive elements per block,
+// the partials dealt over 8 thread groups and folded through LDS in a fixed order (deterministic)
+__global__ void __launch_bounds__(256) thin_wgrad_reduce_kernel(const IgemmParams p, const ThinTab tab, const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int nblocks, int NTC, int NKT) {
+  __shared__ float part[8][32];
   const int total = NTC * NKT * 256;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int tile = e >> 8, within = e & 255;
-    const int i = tile / NKT, j = tile - i * NKT;
-    const int co = 16 * i + (within >> 4), col = within & 15;
-    const int s = tab.op[j];
-    if (s < 0) continue;
-    const KOperand& S = p.in[s];
-    const bool chan_mode = tab.tap[j] >= 0;
-    const int le = tab.e0[j] + col;
-    const int c = chan_mode ? le : le / 9, tap = chan_mode ? tab.tap[j] : le - 9 * (le / 9);
-    if (c >= S.C || co >= p.Ntot) continue;
-    float sum = 0.f;
-    for (int z = 0; z < nblocks; ++z) sum += ws[(size_t)z * total + e];
-    dw[((long long)co * p.D1 + S.ch_off + c) * 9 + tap] = sum;
-  }
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), zs = threadIdx.x >> 5;
+  float sum = 0.f;
+  if (e < total)
+    for (int z = zs; z < nblocks; z += 8) sum += ws[(size_t)z * total + e];
+  part[zs][threadIdx.x & 31] = sum;
+  __syncthreads();
+  if (zs != 0 || e >= total) return;
+  sum = ((part[0][e & 31] + part[1][e & 31]) + (part[2][e & 31] + part[3][e & 31])) + ((part[4][e & 31] + part[5][e & 31]) + (part[6][e & 31] + part[7][e & 31]));
+  const int tile = e >> 8, within = e & 255;
+  const int i = tile / NKT, j = tile - i * NKT;
+  const int co = 16 * i + (within >> 4), col = within & 15;
+  const int s = tab.op[j];
+  if (s < 0) return;
+  const KOperand& S = p.in[s];
+  const bool chan_mode = tab.tap[j] >= 0;
+  const int le = tab.e0[j] + col;
+  const int c = chan_mode ? le : le / 9, tap = chan_mode ? tab.tap[j] : le - 9 * (le / 9);
+  if (c >= S.C || co >= p.Ntot) return;
+  dw[((long long)co * p.D1 + S.ch_off + c) * 9 + tap] = sum;
 }
 
 int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
@@ -236,7 +242,7 @@ int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   int rc = check_launch("thin_wgrad_kernel");
   if (rc != DN_OK) return rc;
   const int total = ntc * nkt * 256;
-  hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p, tab, p.ws, dw, blocks, ntc, nkt);
+  hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, p, tab, p.ws, dw, blocks, ntc, nkt);
   return check_launch("thin_wgrad_reduce_kernel");
 }
 
