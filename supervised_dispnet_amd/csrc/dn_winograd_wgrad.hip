@@ -378,32 +378,53 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
         }
 }
 
-// dU = sum over splits (with the sign of A's last row restored), dW = G^T dU G, written in the framework layout [co][ci][3][3]
-__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits) {
-  const long long slab = (long long)Cout * Ktot;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < slab; idx += (long long)gridDim.x * blockDim.x) {
-    float u[4][4];
+// dU = sum over splits (with the sign of A's last row restored), dW = G^T dU G, written in the framework layout [co][ci][3][3].
+// One thread per 4 consecutive ci: float4 loads of the partials (the 16 positions x splits reads are independent streams).
+__global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits, int dw_vec) {
+  const long long slab = (long long)Cout * Ktot, quads = slab >> 2;
+  for (long long qd = blockIdx.x * (long long)blockDim.x + threadIdx.x; qd < quads; qd += (long long)gridDim.x * blockDim.x) {
+    const long long idx = qd << 2;
+    f32x4 u[4][4];
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) {
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += ws[((long long)z * 16 + pos) * slab + idx];
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(ws + ((long long)z * 16 + pos) * slab + idx);
       const int i = pos >> 2, j = pos & 3;
       u[i][j] = ((i == 3) != (j == 3)) ? -s : s;
     }
     // t[r][j] = sum_i G[i][r] u[i][j],  G = (1 0 0 / .5 .5 .5 / .5 -.5 .5 / 0 0 1)
-    float t[3][4];
+    f32x4 t[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
       t[1][j] = 0.5f * (u[1][j] - u[2][j]);
       t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
     }
-    float* o = dw + idx * 9;
+    float o[4][9];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      o[r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
-      o[r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
-      o[r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+      const f32x4 o0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+      const f32x4 o1 = 0.5f * (t[r][1] - t[r][2]);
+      const f32x4 o2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e][r * 3 + 0] = o0[e];
+        o[e][r * 3 + 1] = o1[e];
+        o[e][r * 3 + 2] = o2[e];
+      }
+    }
+    // the 4 x 9 results are 36 consecutive floats of dw (idx*9 is a multiple of 4 floats: float4 stores)
+    float* dst = dw + idx * 9;
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+      f32x4 w4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w4[e] = o[(v * 4 + e) / 9][(v * 4 + e) % 9];
+      if (dw_vec) *reinterpret_cast<f32x4*>(dst + 4 * v) = w4;
+      else {                               // a gradient slice of the optimizer arena need not be 16-byte aligned
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * v + e] = w4[e];
+      }
     }
   }
 }
@@ -455,9 +476,10 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
     src = folded;
     nsrc = groups;
   }
-  int blocks = (int)((slab + 255) / 256);
+  int blocks = (int)(((slab >> 2) + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc);
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc,
+                     (reinterpret_cast<uintptr_t>(dw) & 15) == 0 ? 1 : 0);
   return check_launch("wino_wgrad_reduce_kernel");
 }
 
