@@ -27,10 +27,13 @@ N, H, W = 32, 128, 416
 
 FULL_LAYERS = [
     # name            cin  cout  h    w    what it exercises
-    ("conv1_2",        64,  64, 128, 416),   # <128,64> fast path, largest tensors (436 MB)
-    ("conv2_2",       128, 128,  64, 208),   # <128,128> fast path
-    ("conv5_3",       512, 512,   8,  26),   # long K, fewer blocks than CUs
-    ("iconv0_like",    16,  16, 128, 416),   # per-thread-tap (C = 16) path, 32-wide tiles
+    ("conv1_2",        64,  64, 128, 416),   # Winograd fwd / dgrad / wgrad, shortest K (4 chunks), largest tensors (436 MB)
+    ("conv2_2",       128, 128,  64, 208),   # Winograd, 2 x 2 (co, ci) blocks x 64 tile splits in the weight gradient
+    ("conv3_3",       256, 256,  32, 104),   # Winograd, 6.5 rounds of blocks
+    ("conv4_3",       512, 512,  16,  52),   # Winograd, weights larger than one XCD's L2
+    ("conv5_3",       512, 512,   8,  26),   # Winograd, long K, fewer blocks than slots
+    ("first_layer",     3,  64, 128, 416),   # stem forward kernel + thin weight gradient (3-channel operand)
+    ("iconv0_like",    16,  16, 128, 416),   # 32-wide implicit-GEMM tiles forward / dgrad, thin weight gradient
     ("disp_head",      16,   1, 128, 416),   # direct head kernels
 ]
 
