@@ -17,7 +17,9 @@
  *   - re-entrant: no mutable global state (safe from PyTorch's autograd worker threads).
  *   - activations are NHWC fp32 (channels fastest).  Operands carry explicit element strides so NCHW user
  *     tensors (the 3-channel image) can be consumed without a transpose pass.
- *   - arithmetic is fp32 throughout: conv contractions run on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
+ *   - arithmetic is fp32 throughout: conv contractions run on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact fp32
+ *     FMA chains).  The 3x3 / stride 1 / pad 1 layers with aligned channels use Winograd F(2x2,3x3): fp32 transforms (adds,
+ *     halves) around the same fp32 MFMAs, error at the level of the direct contraction (tests/test_gpu_kernels.py).
  */
 #ifndef DISPNET_HIP_H_
 #define DISPNET_HIP_H_
