@@ -40,6 +40,9 @@ class GradReducer(object):
 
     def _launch(self, bi):
         b = self.buckets[bi]
+        if self.arena.flat_g.is_cuda:
+            from . import engine                 # gradients of one bucket come from two HIP streams (engine.WGRAD_STREAM)
+            engine.fence_streams()
         if self.world > 1:
             self._handles.append(dist.all_reduce(self.arena.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))

@@ -15,6 +15,7 @@ Design notes
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -32,6 +33,60 @@ PARAM_EPOCH = 0
 # Optional per-launch instrumentation (bench.py): a list receiving (kernel_name, algorithmic_flops, start_event, end_event)
 # for every implicit-GEMM launch, bracketed with HIP events on the launch stream.  None = off (zero overhead).
 PROFILE = None
+
+
+# Weight gradients on a side HIP stream (DN_WGRAD_STREAM=auto|1|0; auto = on in a single-process run, off under
+# torch.distributed with more than one rank until the RCCL interplay has been measured on a multi-GPU node -- the 2-rank gloo
+# exercise on ONE GPU host-synchronises inside every bucket launch and collapses): a layer's weight gradient
+# and its input gradient only share read-only operands, so the two launches run side by side and fill each other's last,
+# partially occupied round of blocks (a Winograd weight-gradient block needs a whole CU's LDS, so it takes the CUs the input
+# gradient's tail leaves idle).  Measured +2.3 % images/sec (r01_h A/B on one box, identical losses).  The fences:
+#   side waits for main before every weight gradient (dy, the operands, this layer's bias / BatchNorm gradients);
+#   main waits for side at the end of the backward pass (optimizer, next forward) and before a data-parallel bucket is
+#   all-reduced (fence_streams); tensors the side stream reads are record_stream()ed against the caching allocator.
+_WGRAD_STREAM_MODE = os.environ.get("DN_WGRAD_STREAM", "auto")
+WGRAD_STREAM = _WGRAD_STREAM_MODE != "0"
+_SIDE = {}
+
+
+def wgrad_stream_enabled():
+    if _WGRAD_STREAM_MODE == "0":
+        return False
+    if _WGRAD_STREAM_MODE == "1":
+        return True
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+def side_stream():
+    dev = torch.cuda.current_device()
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = {"side": torch.cuda.Stream(device=dev), "main": None}
+    return st
+
+
+def join_side_stream():
+    """Make the current stream wait for everything enqueued on the side stream (end of a backward pass)."""
+    if WGRAD_STREAM and torch.cuda.is_available():
+        st = _SIDE.get(torch.cuda.current_device())
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st["side"])
+
+
+def fence_streams():
+    """Make the CURRENT stream wait for both the main and the side stream (called right before a gradient bucket is handed to
+    RCCL: the bucket holds gradients produced on either stream, whichever stream the last of them came from)."""
+    if not (WGRAD_STREAM and torch.cuda.is_available()):
+        return
+    st = _SIDE.get(torch.cuda.current_device())
+    if st is None:
+        return
+    cur = torch.cuda.current_stream()
+    if cur != st["side"]:
+        cur.wait_stream(st["side"])
+    if st["main"] is not None and cur != st["main"]:
+        cur.wait_stream(st["main"])
 
 
 def _pick_bn(ntot):
@@ -260,8 +315,10 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
     return y, partial, rows
 
 
-def conv_wgrad(layer, pieces, dy, out_hw, out=None):
-    """Weight gradient in the framework layout (same shape as module.weight); written into `out` when given."""
+def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None):
+    """Weight gradient in the framework layout (same shape as module.weight); written into `out` when given.  With `sink` the
+    gradient is also handed to it here (inside the side-stream context when DN_WGRAD_STREAM=1, so that a data-parallel bucket
+    launched by this gradient is fenced against the stream that computes it)."""
     a0 = pieces[0].act
     IH = a0.H * (2 if pieces[0].up else 1)
     IW = a0.W * (2 if pieces[0].up else 1)
@@ -277,13 +334,35 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None):
     nbytes = lib.dn_conv_wgrad_workspace_bytes(C.byref(d))
     if nbytes == 0:
         raise _lib.DispnetHipError("dn_conv_wgrad_workspace_bytes: " + _lib.last_error())
-    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
-    dw = out if out is not None else torch.empty_like(layer.m.weight, memory_format=torch.contiguous_format)
-    with _Timed("igemm_wgrad_kernel<%d>" % _pick_bn(layer.Cin if layer.transposed else layer.Cout),
-                2 * layer.macs(a0.N, IH, IW, OH, OW),
-                "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_wgrad" if layer.transposed else "conv_wgrad", layer.R, layer.stride,
-                                                         layer.Cin, layer.Cout, a0.N, IH, IW)):
-        _lib.call("dn_conv2d_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
+
+    def launch():
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+        dw = out if out is not None else torch.empty_like(layer.m.weight, memory_format=torch.contiguous_format)
+        with _Timed("igemm_wgrad_kernel<%d>" % _pick_bn(layer.Cin if layer.transposed else layer.Cout),
+                    2 * layer.macs(a0.N, IH, IW, OH, OW),
+                    "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_wgrad" if layer.transposed else "conv_wgrad", layer.R, layer.stride,
+                                                             layer.Cin, layer.Cout, a0.N, IH, IW)):
+            _lib.call("dn_conv2d_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
+        if sink is not None:
+            sink.put(layer.m.weight, dw)
+        return dw
+
+    if not (dy.is_cuda and wgrad_stream_enabled()):
+        return launch()
+    st = side_stream()
+    main, side = torch.cuda.current_stream(), st["side"]
+    st["main"] = main
+    side.wait_stream(main)                       # dy, the operands and the bias / BatchNorm gradients of this layer are ready
+    with torch.cuda.stream(side):
+        dw = launch()
+    dy.record_stream(side)                       # the caching allocator must not hand these to the main stream while side reads them
+    for p in pieces:
+        p.act.t.record_stream(side)
+        if p.act.scale is not None:
+            p.act.scale.record_stream(side)
+            p.act.shift.record_stream(side)
+    if out is None:
+        dw.record_stream(main)
     return dw
 
 
@@ -469,7 +548,7 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
         # exact arithmetic (BN removes the mean); the reference's value is rounding noise.  We store exact zeros.
         if layer.m.bias is not None:
             sink.put_zero(layer.m.bias)
-        sink.put(layer.m.weight, conv_wgrad(layer, [x_piece], g, (OH, OW), out=sink.dest(layer.m.weight)))
+        conv_wgrad(layer, [x_piece], g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink)
         conv_dgrad(layer, g, xa.N, OH, OW, [x_piece], (xa.H, xa.W))
         y.grad = None
 
@@ -528,7 +607,7 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
         db = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout, out=sink.dest(layer.m.bias) if layer.m.bias is not None else None)
         if layer.m.bias is not None:
             sink.put(layer.m.bias, db)
-        sink.put(layer.m.weight, conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight)))
+        conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink)
         conv_dgrad(layer, g, a0.N, OH, OW, pieces, in_hw)
         y.grad = None
 
