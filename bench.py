@@ -12,7 +12,8 @@ Besides the contract fields the line carries
   roofline     -- for the dominant kernel (by time): algorithmic FLOP/s = sum over its launches of 2*MACs of the DIRECT
                   convolution divided by the sum of its launch durations, measured with HIP events on
                   the launch stream during extra instrumented steps that follow the timed region (so the events do not
-                  perturb `value`); peak = 157.3 TFLOP/s dense fp32 MFMA.  The Winograd F(2x2,3x3) kernels execute 2.25x
+                  perturb `value`; they run single-stream, the timed steps put the weight gradients on a side stream);
+                  peak = 157.3 TFLOP/s dense fp32 MFMA.  The Winograd F(2x2,3x3) kernels execute 2.25x
                   fewer multiply-accumulates than they are credited with, so their `frac` may exceed 1; `executed_frac` =
                   frac / 2.25 is the share of the matrix peak their MFMAs actually occupy.
   cpu_baseline -- the CPU oracle (oracle/, a PyTorch-CPU restatement pinned to the reference's golden vectors; kind "port")

@@ -50,7 +50,7 @@ _SIDE = {}
 
 
 def wgrad_stream_enabled():
-    if _WGRAD_STREAM_MODE == "0":
+    if _WGRAD_STREAM_MODE == "0" or PROFILE is not None:      # per-launch event timing wants one kernel at a time
         return False
     if _WGRAD_STREAM_MODE == "1":
         return True
