@@ -1,7 +1,7 @@
 """ctypes binding of libdispnet_hip.so (the C ABI declared in include/dispnet_hip.h).
 
 The product path has NO fallback: if the shared library is missing or a call fails this module raises.
-Nothing here imports torch; callers pass raw device pointers (tensor.data_ptr()) and the raw hipStream_t.
+No torch types cross this binding; callers pass raw device pointers (tensor.data_ptr()) and the raw hipStream_t.
 """
 import ctypes as C
 import os
@@ -138,6 +138,13 @@ def load():
         raise DispnetHipError(
             "libdispnet_hip.so not found at %s -- build it with `python supervised_dispnet_amd/csrc/build.py` "
             "(or __graft_entry__.build()).  The HIP extension is mandatory; there is no CPU/PyTorch fallback." % LIB_PATH)
+    # libdispnet_hip.so links libamdhip64; PyTorch-ROCm ships its own copy.  If this library were loaded first, the process
+    # would hold two HIP runtimes and every launch from here would fail with "no ROCm-capable device is detected" once torch has
+    # claimed the GPU -- so let torch (when installed) load its runtime first; nothing else of torch is used in this module.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
