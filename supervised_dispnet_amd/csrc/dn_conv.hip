@@ -144,14 +144,14 @@ __device__ __forceinline__ AGroup gather4(const KOperand& S, int kl, int ntaps, 
 
 // ---- shared epilogue: bias, activation, channel-split store; optional batch-statistic partials
 // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool STORE = true>
 __device__ __forceinline__ void conv_epilogue(const IgemmParams& p, f32x16 (&acc)[WM / 32][WN / 32], const int* rowpix, float* As,
                                               int m0, int n0) {
   constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
+  for (int j = 0; j < (STORE ? NI : 0); ++j) {
     const int n = n0 + wn * WN + j * 32 + (lane & 31);
     const bool nvalid = n < p.Ntot;
     int seg = 0;
@@ -808,6 +808,7 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
 // tiles grid-stride; the epilogue (bias, activation, BatchNorm partial statistics per 128-pixel tile) is the shared one.
 __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
   __shared__ __align__(16) float As[4 * 64 + 64];
+  __shared__ __align__(16) float Ts[128 * 68];      // the 128 x 64 result tile (row padded to 68): stored as whole 256-byte pixels
   __shared__ int rowpix[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const KOperand& S = p.in[0];
@@ -862,7 +863,31 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
       }
     }
     __syncthreads();
-    conv_epilogue<128, 64, 32, 64>(p, acc, rowpix, As, m0, 0);
+    // bias + activation into the LDS tile (C/D layout: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)), then
+    // float4 stores of whole pixels: a wave writes 1 KiB contiguous per instruction instead of 2 x 128 bytes (this kernel is bound
+    // by the number of vector-memory instructions, not by bytes)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = 32 * j + (lane & 31);
+      const float bias = p.bias != nullptr ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        Ts[row * 68 + col] = apply_act(acc[0][j][reg] + bias, p.act, p.act_p0, p.act_p1);
+      }
+    }
+    conv_epilogue<128, 64, 32, 64, false>(p, acc, rowpix, As, m0, 0);      // batch-statistic partials only
+    __syncthreads();
+    {
+      const KResult& R = p.out[0];
+      const int c4 = tid & 15;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (tid >> 4) + 16 * i;
+        if (m0 + row < p.M)
+          *reinterpret_cast<f32x4*>(R.p + (long long)(m0 + row) * R.sw + 4 * c4) = *reinterpret_cast<const f32x4*>(Ts + row * 68 + 4 * c4);
+      }
+    }
     __syncthreads();
   }
 }
@@ -872,7 +897,9 @@ static bool stem_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
   if (p.n_in != 1 || p.n_out != 1 || p.Ntot != 64 || p.nphases != 1) return false;
   const KOperand& o = p.in[0];
-  return o.C <= 4 && o.up == 0 && o.scale == nullptr && o.small && p.out[0].linear;
+  const KResult& r = p.out[0];
+  return o.C <= 4 && o.up == 0 && o.scale == nullptr && o.small && r.linear && !r.accumulate && (r.sw & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(r.p) & 15) == 0;
 }
 
 static int launch_stem(const IgemmParams& p, hipStream_t stream) {
