@@ -150,8 +150,42 @@ __device__ __forceinline__ void conv_epilogue(const IgemmParams& p, f32x16 (&acc
   constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  // Fast store path (one dense float4-addressable result, no accumulation): bias + activation into an LDS tile [BM][BN + 4], then
+  // every thread stores float4s of consecutive channels -- a wave writes whole pixels (BN*4 contiguous bytes each) instead of
+  // 32 x 4 bytes of two pixels per instruction.  The thin decoder layers are bound by their vector-memory instruction count.
+  bool tile_store = false;
+  if constexpr (STORE) {
+    const KResult& R0 = p.out[0];
+    tile_store = p.n_out == 1 && R0.linear && !R0.accumulate && (R0.sw & 3) == 0 && (p.Ntot & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(R0.p) & 15) == 0 && p.tile_store != 0;
+    if (tile_store) {
+      constexpr int TLD = BN + 4;
+      float* Ts = As;                                  // the staging buffers are free after the main loop's last barrier
 #pragma unroll
-  for (int j = 0; j < (STORE ? NI : 0); ++j) {
+      for (int j = 0; j < NI; ++j) {
+        const int col = wn * WN + j * 32 + (lane & 31);
+        const int n = n0 + col;
+        const float bias = (p.bias != nullptr && n < p.Ntot) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            Ts[row * TLD + col] = apply_act(acc[i][j][reg] + bias, p.act, p.act_p0, p.act_p1);
+          }
+      }
+      __syncthreads();
+      constexpr int C4 = BN / 4;
+      for (int it = tid; it < BM * C4; it += 256) {
+        const int row = it / C4, c4 = it - row * C4;
+        const int pix = rowpix[row];
+        if (pix >= 0 && n0 + 4 * c4 < p.Ntot)
+          *reinterpret_cast<f32x4*>(R0.p + (long long)pix * R0.sw + n0 + 4 * c4) = *reinterpret_cast<const f32x4*>(Ts + row * TLD + 4 * c4);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < ((STORE && !tile_store) ? NI : 0); ++j) {
     const int n = n0 + wn * WN + j * 32 + (lane & 31);
     const bool nvalid = n < p.Ntot;
     int seg = 0;

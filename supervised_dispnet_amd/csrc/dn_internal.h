@@ -88,6 +88,7 @@ struct IgemmParams {
   int wg_uniform;                // every operand: C % 32 == 0, float4-addressable, no upsample (weight-gradient fast path)
   int any_affine;                // some operand carries a pending BN-apply + ReLU
   int reflect;                   // gather with ReflectionPad2d index mapping instead of zero fill
+  int tile_store;                // epilogue may stage the result tile in LDS and store whole pixels (off: DN_NO_TILE_STORE)
   // Winograd F(2x2,3x3) launches only (dn_winograd.hip)
   int T, TH, TW;                 // 2x2 output tiles: total, per image column / row
   unsigned mTW, mTH;             // fastdiv magics

@@ -1,6 +1,7 @@
 // Host-side planning for the implicit-GEMM convolution family: turns a dn_conv_desc into the tap / phase tables
 // the kernels consume.  Pure host logic (also exported through dn_debug_conv_plan for CPU-side tests).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "dn_internal.h"
@@ -268,6 +269,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     if (!o.small || (!o.vec && o.scale != nullptr) || o.C >= 32768) p->wg_uniform = 0;
   }
   (void)n_uniform;
+  p->tile_store = getenv("DN_NO_TILE_STORE") ? 0 : 1;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;
