@@ -133,5 +133,7 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream);
 bool thin_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
 size_t thin_wgrad_workspace_bytes(const IgemmParams& p);
 int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream);
+bool thin_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
+int launch_thin_conv(const IgemmParams& p, hipStream_t stream);
 
 }  // namespace dn

@@ -246,4 +246,251 @@ int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   return check_launch("thin_wgrad_reduce_kernel");
 }
 
+
+// =====================================================================================================================
+// Thin convolutions: at most 32 output channels and a short contraction (iconv0 17 -> 16 and its input gradient, the last two
+// conv-transposes 32 -> 16 / 64 -> 32 and the 32 -> 16 one's input gradient; models/Disp_vgg_BN.py:101-105).  The tiled kernel
+// pads 16 output channels to a 32-wide MFMA tile and every operand's taps*channels to a multiple of 32, and with K of 128-256
+// a block's main loop is 4-8 barrier-separated iterations between a prologue and an epilogue.  Here: v_mfma_f32_16x16x4_f32,
+// A fragments gathered straight from global memory (one float4 = 4 channels x 4 MFMA steps per pixel and tap; the 1-channel
+// upsampled-disparity piece as dword gathers), the whole weight matrix of the phase resident in LDS in B-fragment order
+// ([k-step][4][16 or 32]: a fragment read is 4 x 16 consecutive floats), waves persistent over groups of 64 pixels, results
+// through a per-wave LDS tile so that they leave as whole pixels.  Driven by the same plan (taps, phases, strides) as the tiled
+// kernel and reading the same packed weights, so all four conv kinds are served.
+// =====================================================================================================================
+__device__ __forceinline__ float thin_act(float v, int act, float p0, float p1) {
+  switch (act) {
+    case DN_ACT_RELU: return v > 0.f ? v : 0.f;
+    case DN_ACT_LEAKY: return v > 0.f ? v : v * p0;
+    case DN_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.f);
+    case DN_ACT_SIGMOID_AFFINE: return p0 / (1.f + expf(-v)) + p1;
+    default: return v;
+  }
+}
+
+static int thin_ksteps(const IgemmParams& p, int ntaps) {       // 4-wide MFMA k-steps of one phase
+  int k4 = 0;
+  for (int s = 0; s < p.n_in; ++s) k4 += (p.in[s].C % 16 == 0) ? ntaps * (p.in[s].C / 16) * 4 : (ntaps + 3) / 4;
+  return k4;
+}
+
+static size_t thin_conv_lds(const IgemmParams& p, int NT) {
+  int k4 = 0;
+  for (int z = 0; z < p.nphases; ++z) {
+    const int k = thin_ksteps(p, p.ph[z].ntaps);
+    if (k > k4) k4 = k;
+  }
+  const int NP = 16 * NT;
+  return (size_t)k4 * 4 * NP * sizeof(float) + 4 * 16 * (NP + 4) * sizeof(float) + 4 * 64 * sizeof(int) + 16 * sizeof(int);
+}
+
+bool thin_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) {
+  if (getenv("DN_NO_THIN") || getenv("DN_NO_THIN_CONV")) return false;
+  // measured: with 32 output channels / 256-long contractions the tiled kernel wins (0.096 vs 0.132 ms, 0.094 vs 0.164); the
+  // 16-channel layers are where padding to a 32-wide tile hurts (0.31 -> 0.15 ms, 0.23 -> 0.16)
+  if (p.reflect || p.bn_partial != nullptr || p.Ntot > 16) return false;
+  for (int z = 0; z < p.nphases; ++z)
+    if (p.ph[z].ntaps > 16 || p.ph[z].ntaps < 1) return false;
+  int kmax = 0;
+  for (int s = 0; s < p.n_in; ++s) {
+    const KOperand& o = p.in[s];
+    const bool vec16 = o.vec && o.small && o.up == 0 && o.C % 16 == 0;
+    const bool scalar1 = o.C == 1 && o.small;
+    if (o.scale != nullptr || !(vec16 || scalar1)) return false;
+    kmax += o.C;
+  }
+  for (int z = 0; z < p.nphases; ++z)
+    if (thin_ksteps(p, p.ph[z].ntaps) * 4 > 320) return false;           // long contractions belong to the tiled kernel
+  // one dense float4-addressable result (the whole-pixel store path); a channel-split input gradient stays on the tiled kernel
+  const KResult& r = p.out[0];
+  if (p.n_out != 1 || (p.Ntot & 3) || (r.sw & 3) || (r.sh & 3) || (r.sn & 3) || r.accumulate || (reinterpret_cast<uintptr_t>(r.p) & 15)) return false;
+  return thin_conv_lds(p, p.Ntot <= 16 ? 1 : 2) <= 64 * 1024;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) thin_conv_kernel(const IgemmParams p, int k4max) {
+  constexpr int NP = 16 * NT, TLD = NP + 4;
+  extern __shared__ __align__(16) float smem[];
+  float* wl = smem;                                         // [k4][4][NP]
+  float* tiles = smem + (size_t)k4max * 4 * NP;             // [4 waves][16][TLD]
+  int* outpix = reinterpret_cast<int*>(tiles + 4 * 16 * TLD);   // [4 waves][64]
+  int* tapl = outpix + 4 * 64;                              // [16]  dy | dx << 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, kk = lane >> 4;
+  const KPhase ph = p.ph[blockIdx.y];
+  const int ntaps = ph.ntaps, Kp = ph.nchunks * kChunk;
+
+  if (tid < 16) tapl[tid] = tid < ntaps ? (((int)p.tdy[ph.tap0 + tid] & 0xffff) | ((int)p.tdx[ph.tap0 + tid] << 16)) : 0;
+  // weights of this phase -> B-fragment order.  k-step order: operand by operand; a 16-aligned operand contributes, per tap and
+  // 16-channel block, four steps (step s holds channels 4*kk + s of the block); a 1-channel operand one step per four taps.
+  {
+    int k4 = 0, kbase = 0;
+    for (int s = 0; s < p.n_in; ++s) {
+      const int C = p.in[s].C;
+      const int span = ((ntaps * C + kChunk - 1) / kChunk) * kChunk;
+      const int steps = (C % 16 == 0) ? ntaps * (C / 16) * 4 : (ntaps + 3) / 4;
+      for (int e = tid; e < steps * 4 * NP; e += 256) {
+        const int n = e % NP, kq = (e / NP) & 3, st = e / (4 * NP);
+        int kpk = -1;
+        if (C % 16 == 0) {
+          const int s4 = st & 3, blk = st >> 2;             // blk = tap * (C/16) + c16
+          const int tap = blk / (C / 16), c16 = blk - tap * (C / 16);
+          kpk = kbase + tap * C + c16 * 16 + 4 * kq + s4;
+        } else {
+          const int tap = st * 4 + kq;
+          if (tap < ntaps) kpk = kbase + tap * C;
+        }
+        wl[(size_t)(k4 + st) * 4 * NP + kq * NP + n] = (kpk >= 0 && n < p.Ntot) ? p.w[ph.w_off + (long long)n * Kp + kpk] : 0.f;
+      }
+      k4 += steps;
+      kbase += span;
+    }
+  }
+  __syncthreads();
+
+  float* tile = tiles + wave * 16 * TLD;
+  int* opix = outpix + wave * 64;
+  const int ngroups = (p.M + 63) / 64;
+  const int iters = (ngroups + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
+  const KResult& R0 = p.out[0];
+  for (int it = 0; it < iters; ++it) {
+    const int group = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+    const int m0 = group * 64;
+    // output pixel of row `lane` of this group (element offset of channel 0 in result 0's pixel grid, or -1)
+    {
+      const int m = m0 + lane;
+      int pix = -1;
+      if (m < p.M) {
+        unsigned gx, gy;
+        const unsigned t = fastdiv_dev((unsigned)m, (unsigned)p.GW, p.mGW, &gx);
+        const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
+        const int oy = (int)gy * p.osy + ph.ooy, ox = (int)gx * p.osx + ph.oox;
+        if (oy < p.OH && ox < p.OW) pix = (n * p.OH + oy) * p.OW + ox;
+      }
+      opix[lane] = pix;
+    }
+    // the four pixels this lane gathers for (one per 16-row MFMA tile)
+    int pn[4], pby[4], pbx[4];
+    bool plive[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + 16 * mt + col;
+      plive[mt] = m < p.M;
+      unsigned gx, gy;
+      const unsigned t = fastdiv_dev(plive[mt] ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+      pn[mt] = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
+      pby[mt] = (int)gy * p.sy;
+      pbx[mt] = (int)gx * p.sx;
+    }
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int k4 = 0;
+    for (int s = 0; s < p.n_in; ++s) {
+      const KOperand& S = p.in[s];
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+      if (S.C % 16 == 0) {
+        const int nblk = S.C / 16;
+        int base[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) base[mt] = (pn[mt] * (int)S.sn + pby[mt] * (int)S.sh + pbx[mt] * (int)S.sw + 4 * kk) * 4;
+        for (int j = 0; j < ntaps; ++j) {
+          const int tp = tapl[j];
+          const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+          const int toff = (dy * (int)S.sh + dx * (int)S.sw) * 4;
+          bool ok[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            ok[mt] = plive[mt] && (unsigned)(pby[mt] + dy) < (unsigned)p.IH && (unsigned)(pbx[mt] + dx) < (unsigned)p.IW;
+          for (int cb = 0; cb < nblk; ++cb) {
+            f32x4 a4[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              const int off = ok[mt] ? base[mt] + toff + cb * 64 : -1;
+              typedef int i32x4 __attribute__((ext_vector_type(4)));
+              a4[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              float b[NT];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) b[nt] = wl[(size_t)(k4 + s4) * 4 * NP + kk * NP + 16 * nt + col];
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][s4], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+            k4 += 4;
+          }
+        }
+      } else {            // 1-channel piece: lane kk takes tap 4q + kk
+        for (int q4 = 0; q4 < (ntaps + 3) / 4; ++q4) {
+          const int tap = q4 * 4 + kk;
+          const int tp = tapl[tap < 16 ? tap : 15];
+          const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+          float a[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int iy = pby[mt] + dy, ix = pbx[mt] + dx;
+            const bool ok = plive[mt] && tap < ntaps && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            const int off = ok ? (pn[mt] * (int)S.sn + (iy >> S.up) * (int)S.sh + (ix >> S.up) * (int)S.sw) * 4 : -1;
+            a[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+          }
+          float b[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b[nt] = wl[(size_t)k4 * 4 * NP + kk * NP + 16 * nt + col];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          k4 += 1;
+        }
+      }
+    }
+
+    // ---- epilogue: bias + activation into this wave's 16-row tile (C/D layout: col = lane & 15, rows 4*kk + r), one MFMA row
+    //      tile at a time, then float4 stores of whole pixels
+    __syncthreads();                                   // opix written by all lanes of this wave (and tile free)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * nt + col;
+        const float bias = (p.bias != nullptr && n < p.Ntot) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(4 * kk + r) * TLD + n] = thin_act(acc[mt][nt][r] + bias, p.act, p.act_p0, p.act_p1);
+      }
+      __syncthreads();
+      constexpr int C4 = NP / 4;
+      for (int e = lane; e < 16 * C4; e += 64) {
+        const int row = e / C4, c4 = e - row * C4;
+        const int pix = opix[16 * mt + row];
+        if (pix >= 0 && 4 * c4 < p.Ntot)
+          *reinterpret_cast<f32x4*>(R0.p + (long long)pix * R0.sw + 4 * c4) = *reinterpret_cast<const f32x4*>(tile + row * TLD + 4 * c4);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int launch_thin_conv(const IgemmParams& p, hipStream_t stream) {
+  const int NT = p.Ntot <= 16 ? 1 : 2;
+  int k4 = 0;
+  for (int z = 0; z < p.nphases; ++z) {
+    const int k = thin_ksteps(p, p.ph[z].ntaps);
+    if (k > k4) k4 = k;
+  }
+  const size_t lds = thin_conv_lds(p, NT);
+  const int ngroups = (p.M + 63) / 64;
+  int blocks = (ngroups + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  if (NT == 1) hipLaunchKernelGGL((thin_conv_kernel<1>), dim3(blocks, p.nphases), dim3(256), lds, stream, p, k4);
+  else hipLaunchKernelGGL((thin_conv_kernel<2>), dim3(blocks, p.nphases), dim3(256), lds, stream, p, k4);
+  set_last_kernel("dn::thin_conv_kernel<%d>", NT);
+  return check_launch("thin_conv_kernel");
+}
+
 }  // namespace dn

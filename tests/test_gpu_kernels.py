@@ -226,6 +226,48 @@ def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
     close("wino_vs_direct:dw", res["wino"][4], res["direct"][4], rtol=1e-4, atol_rel=1e-5)
 
 
+@pytest.mark.parametrize("kind", ["iconv0", "upconv0", "iconv0_dgrad"])
+def test_thin_conv_matches_tiled_kernel(monkeypatch, kind):
+    """dn::thin_conv_kernel (16x16x4 MFMAs fed from global memory) against the tiled implicit GEMM (DN_NO_THIN_CONV=1) on the
+    layers it serves, at the metric's resolution: same fp32 products, different summation order -> agreement to round-off
+    everywhere, including the borders and the 1-channel upsampled piece."""
+    torch.manual_seed(5)
+    N, H, W = 4, 128, 416
+    res = {}
+    for tag, env in (("thin", None), ("tiled", "1")):
+        if env is None:
+            monkeypatch.delenv("DN_NO_THIN_CONV", raising=False)
+        else:
+            monkeypatch.setenv("DN_NO_THIN_CONV", env)
+        torch.manual_seed(6)
+        if kind == "upconv0":
+            mod = nn.ConvTranspose2d(32, 16, 4, 2, 1).to(DEV)
+            layer = engine.ConvLayer(mod, transposed=True)
+            x = engine.Act(torch.randn(N, H // 2, W // 2, 32, device=DEV), N, H // 2, W // 2, 32)
+            y, _, _ = engine.conv_forward(layer, [engine.Piece(x)], ACT_LEAKY, 0.1, 0.0)
+            outs = [y]
+        else:
+            mod = nn.Conv2d(17, 16, 3, 1, 1).to(DEV)
+            layer = engine.ConvLayer(mod)
+            a = engine.Act(torch.randn(N, H, W, 16, device=DEV), N, H, W, 16)
+            d = engine.Act(torch.rand(N, H // 2, W // 2, 1, device=DEV) * 10 + 0.01, N, H // 2, W // 2, 1)
+            pieces = [engine.Piece(a), engine.Piece(d, up=True)]
+            if kind == "iconv0":
+                y, _, _ = engine.conv_forward(layer, pieces, ACT_LEAKY, 0.1, 0.0)
+                outs = [y]
+            else:
+                dy = torch.randn(N, H, W, 16, device=DEV)
+                engine.conv_dgrad(layer, dy, N, H, W, pieces, (H, W))
+                outs = [a.grad, d.grad]
+        name = _lib.load().dn_last_kernel().decode()
+        torch.cuda.synchronize()
+        res[tag] = (outs, name)
+    assert "thin_conv_kernel" in res["thin"][1] or kind == "iconv0_dgrad"
+    assert "thin" not in res["tiled"][1]
+    for i, (got, want) in enumerate(zip(res["thin"][0], res["tiled"][0])):
+        close("%s[%d]" % (kind, i), got, want, rtol=2e-5, atol_rel=2e-6)
+
+
 def test_winograd_error_vs_fp64(monkeypatch):
     """Rounding of F(2x2,3x3) against the direct fp32 FMA chain, both measured against an fp64 convolution of the same
     fp32 inputs: Winograd's transforms add a few ulps of the INPUT magnitude; stated bound: max error <= 4x the direct
