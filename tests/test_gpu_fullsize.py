@@ -126,3 +126,33 @@ def test_full_size_network_properties():
     opt.step()
     moved = (opt.arena.flat_p - before).abs()
     assert torch.isfinite(opt.arena.flat_p).all() and float(moved.max()) <= 1.001e-4 and float(moved.max()) > 5e-5   # |Adam step 1| = lr (up to fp32 rounding of p - step)
+
+
+def test_two_stream_backward_is_bitwise_the_single_stream_one(monkeypatch):
+    """engine.WGRAD_STREAM: the weight gradients run on a side HIP stream next to the input gradients.  Same kernels, same
+    arguments, only the schedule differs -> the whole gradient arena must be bit-identical to the single-stream run (a missing
+    fence or a buffer recycled under a running kernel would show up here), at the metric's size, over a few steps."""
+    import supervised_dispnet_amd.loss_functions as LF
+    import supervised_dispnet_amd.models as models
+    from supervised_dispnet_amd.functional import reciprocal
+    from supervised_dispnet_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    img = ((torch.rand(N, 3, H, W, generator=g) - 0.5) / 0.5).to(DEV)
+    gt = ((torch.rand(N, H, W, generator=g) * 79.0 + 1.0) * (torch.rand(N, H, W, generator=g) < 0.05).float()).to(DEV)
+    grads, params = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(engine, "_WGRAD_STREAM_MODE", mode)
+        monkeypatch.setattr(engine, "WGRAD_STREAM", mode != "0")
+        torch.manual_seed(0)
+        net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+        net.init_weights(use_pretrained_weights=False)
+        net.to(DEV).train()
+        opt = FusedAdam(net._hot_parameters(), lr=1e-4, betas=(0.9, 0.999), production_order=net._grad_production_order())
+        for _ in range(3):
+            loss = LF.l1_loss(gt, [reciprocal(d) for d in net(img)], "kitti")
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        grads[mode], params[mode] = opt.arena.flat_g.clone(), opt.arena.flat_p.clone()
+    assert torch.equal(grads["0"], grads["1"]) and torch.equal(params["0"], params["1"])
