@@ -7,19 +7,20 @@
 //                                                    U = G g G^T   (3x3 filter g, once per optimizer step: wino_pack_kernel)
 //
 // = 16 independent GEMMs  M_p[tile][cout] = sum_c V_p[tile][c] * U_p[c][cout],  p = 4i + j the position in the 4x4 transform
-// domain.  One block: 64 tiles (= 256 output pixels) x 64 output channels x all 16 positions, 4 waves, ONE wave per SIMD with
-// the whole 512-register file: wave w owns the four positions of transform row i = w, i.e. 4 x (64x64) accumulators = 256
-// registers.
-//   A side : each thread gathers one 4x4 patch of 4 channels straight from the NHWC operands (virtual concat, pending
-//            BatchNorm-apply + ReLU of the producer, zero halo), transforms it in registers and writes the 16 transformed
-//            float4 into LDS ([position][tile][8 k] rows of 32 B: the per-lane ds_read_b128 fragment reads are contiguous);
-//            16-channel chunks, double-buffered, one barrier per chunk.
+// domain.  One block: 32 tiles (= 128 output pixels) x 64 output channels x all 16 positions, 4 waves, TWO blocks per CU:
+// wave w owns the four positions of transform row i = w, i.e. 4 x (32x64) accumulators = 128 registers next to at most 128
+// others (the 64-tile / 256-accumulator / one-block-per-CU variant is kept for comparison, DN_WINO_MTW=2).
+//   A side : each thread gathers one 4x4 patch of 2 (4) channels straight from the NHWC operands (virtual concat, pending
+//            BatchNorm-apply + ReLU of the producer, zero halo by the buffer bounds check), transforms it in registers and
+//            writes the 16 transformed values into LDS planes [position][k half][tile][4], padded so that both the stores and
+//            the per-lane ds_read_b128 fragment reads are bank-conflict free; 16-channel chunks, double-buffered, one barrier
+//            per chunk.  A 1-channel piece of a concat (the upsampled disparity) is a 16-wide chunk with one live channel.
 //   B side : the transformed weights never touch LDS.  They are packed in MFMA fragment order ([k/8][position][cout/32]
 //            [lane][4]), so a wave's B fragment is one fully coalesced 1 KiB global load per (position, 32 couts, 8 k), issued
-//            one 8-k step ahead of its use; each element is read by exactly one wave of the block.
+//            three steps ahead of its use into a 4-deep register ring; each element is read by exactly one wave of the block.
 //   Output : the transform along j is done in registers, the transform along i crosses the four waves through LDS; then the
 //            usual epilogue (batch-statistic partials of the pre-bias result per 32 tiles = 128 pixels, bias, activation,
-//            channel-split / accumulating stores, float4 along the channels).
+//            channel-split / accumulating stores, float4 along the channels; element-wise for non-float4 results).
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
