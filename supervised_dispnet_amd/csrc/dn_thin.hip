@@ -144,8 +144,16 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(const IgemmParams p, co
     const int r = r_begin + rr;
     const int n = r / OH, y = r - n * OH;
     const int m = r * OW + x0 + pp;
+    if constexpr (NTC == 4) {
+      // 64 output channels: row tile i holds channels 4*col + i, so the four A values of a lane are ONE float4 of dy
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcG, (m * Cout + 4 * col) * 4, 0, 0));
 #pragma unroll
-    for (int i = 0; i < NTC; ++i) a[which][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcG, (m * Cout + 16 * i + col) * 4, 0, 0));
+      for (int i = 0; i < NTC; ++i) a[which][i] = a4[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NTC; ++i) a[which][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcG, (m * Cout + 16 * i + col) * 4, 0, 0));
+    }
 #pragma unroll
     for (int j = 0; j < NKT; ++j) {
       const int s = tab.op[j];
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256) thin_wgrad_reduce_kernel(const IgemmParam
   sum = ((part[0][e & 31] + part[1][e & 31]) + (part[2][e & 31] + part[3][e & 31])) + ((part[4][e & 31] + part[5][e & 31]) + (part[6][e & 31] + part[7][e & 31]));
   const int tile = e >> 8, within = e & 255;
   const int i = tile / NKT, j = tile - i * NKT;
-  const int co = 16 * i + (within >> 4), col = within & 15;
+  const int co = NTC == 4 ? 4 * (within >> 4) + i : 16 * i + (within >> 4), col = within & 15;    // (64-channel layers interleave the row tiles)
   const int s = tab.op[j];
   if (s < 0) return;
   const KOperand& S = p.in[s];
