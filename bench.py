@@ -5,23 +5,31 @@ KITTI-like data resident in HBM (BASELINE.json metric / configs[1]; SURVEY.md se
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One rank per GPU (RCCL over xGMI through torch.distributed "nccl"); weak scaling: every rank steps its own b32 batch and
-the only exchange is the bucketed gradient all-reduce overlapped with the encoder backward.  Rank 0 prints ONE JSON line.
+One rank per GPU (RCCL over xGMI); the only exchange is the bucketed gradient all-reduce overlapped with the encoder backward.
+Rank 0 prints ONE JSON line.
+
+  --scaling weak    (default) every rank steps its own batch of --batch images (b32): per-GPU work fixed as N grows.
+  --scaling strong  the literal metric of BASELINE.json ("b32 @1/2/4/8 GPU"): --global-batch 32 split into 32/N per rank.
+  --config          vggbn128 (the headline) | vggbn480 | res50_480 | dorn128 | photo128: BASELINE.json configs[2..4] and the
+                    480x640 secondary of SURVEY 8d produce their own lines (never the headline; `metric` says which).
 
 Besides the contract fields the line carries
-  roofline     -- for the dominant kernel (by time): algorithmic FLOP/s = sum over its launches of 2*MACs of the DIRECT
-                  convolution divided by the sum of its launch durations, measured with HIP events on
-                  the launch stream during extra instrumented steps that follow the timed region (so the events do not
-                  perturb `value`; they run single-stream, the timed steps put the weight gradients on a side stream);
-                  peak = 157.3 TFLOP/s dense fp32 MFMA.  The Winograd F(2x2,3x3) kernels execute 2.25x
-                  fewer multiply-accumulates than they are credited with, so their `frac` may exceed 1; `executed_frac` =
-                  frac / 2.25 is the share of the matrix peak their MFMAs actually occupy.
-  cpu_baseline -- the CPU oracle (oracle/, a PyTorch-CPU restatement pinned to the reference's golden vectors; kind "port")
-                  running the same training step on this box's host cores, on a bounded sample (small batch, few steps).
+  roofline      the dominant MFMA-bound kernel (by time).  `achieved` = multiply-accumulates the kernel EXECUTES x 2 divided by
+                its launch durations (HIP events on the launch stream, instrumented steps after the timed region); `frac` =
+                achieved / 157.3 TFLOP/s (dense fp32 MFMA peak) and is <= 1 by construction.  The Winograd F(2x2,3x3) kernels
+                execute 16/36 of the direct convolution's MACs: the direct-FLOP rate BASELINE.md section 2 counts is reported
+                separately as `credited_achieved` / `credited_frac`.  `frac_of_measured_peak` divides by the register-resident
+                MFMA loop measured on this box in the same process (dn_ubench_mfma_f32).
+  roofline_hbm  the slowest HBM-bound family of the step: algorithmic bytes (operands read once, results written once) over its
+                event time, against 8 TB/s and against the float4 copy rate measured on this box (dn_ubench_copy).
+  step_executed_frac  all conv-family launches' executed FLOPs over the step time, / 157.3.
+  cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU restatement pinned to the reference's golden vectors; kind "port")
+                running the same training step on this box's host cores per SURVEY 8d: batch 8, 2 warm-up + 5 timed steps.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,24 +41,61 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
-TRAIN_GFLOP_PER_IMG = 110.54         # BASELINE.md section 2 (conv/convT MACs*2, fwd + dgrad + wgrad, no dgrad for layer 0)
+PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E spec (6.29 TB/s measured float4 copy there)
+WINO_EXEC = 16.0 / 36.0              # F(2x2,3x3): 16 element-wise products per 2x2 tile instead of 36 MACs
+
+# name -> (metric text, network, H, W, default batch per GPU, dataset tag, BASELINE.md section 2 train GFLOP/img or None)
+CONFIGS = {
+    "vggbn128": ("images/sec fwd+bwd Disp_vgg_BN 128x416 b32 @1/2/4/8 GPU", "Disp_vgg_BN", 128, 416, 32, "kitti", 110.54),
+    "vggbn480": ("images/sec fwd+bwd Disp_vgg_BN 480x640 b16 (secondary, SURVEY 8d)", "Disp_vgg_BN", 480, 640, 16, "nyu", 637.7),
+    "res50_480": ("images/sec fwd+bwd Disp_res_50 480x640 b16 (BASELINE configs[3])", "Disp_res_50", 480, 640, 16, "nyu", 247.3),
+    "dorn128": ("images/sec fwd+bwd Disp_vgg_BN_DORN K=80 128x416 b32 (BASELINE configs[4], fp32)", "Disp_vgg_BN_DORN", 128, 416, 32,
+                "kitti", 111.3),
+    "photo128": ("images/sec fwd+bwd Disp_vgg_BN + PoseExpNet photometric warp loss seq-len 3 128x416 b32 (BASELINE configs[2])",
+                 "Disp_vgg_BN", 128, 416, 32, "kitti", None),
+}
 
 
-def synthetic_batch(batch, h, w, device, seed):
-    """U(0,1) image normalised (x-0.5)/0.5; 5 %-dense U(1,80) ground truth."""
+def synthetic_batch(batch, h, w, device, seed, dataset="kitti"):
+    """U(0,1) image normalised (x-0.5)/0.5; kitti: 5 %-dense U(1,80) ground truth; nyu: dense U(0.5,10)."""
     g = torch.Generator().manual_seed(seed)
     img = (torch.rand(batch, 3, h, w, generator=g) - 0.5) / 0.5
-    depth = torch.rand(batch, h, w, generator=g) * 79.0 + 1.0
-    mask = (torch.rand(batch, h, w, generator=g) < 0.05).float()
-    return img.to(device), (depth * mask).to(device)
+    if dataset == "nyu":
+        gt = torch.rand(batch, h, w, generator=g) * 9.5 + 0.5
+    else:
+        depth = torch.rand(batch, h, w, generator=g) * 79.0 + 1.0
+        gt = depth * (torch.rand(batch, h, w, generator=g) < 0.05).float()
+    return img.to(device), gt.to(device)
 
 
-def cpu_baseline(h, w, batch, steps, warmup):
-    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (bounded sample)."""
+def host_description():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return model, len(phys) or None, os.cpu_count() or 1
+
+
+def cpu_baseline(h, w, batch, steps, warmup, threads=None):
+    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (b8, 2 warm-up + 5 timed)."""
     from oracle import losses as OL, nets as ON
-    # oneDNN/OpenMP on a 256-thread host oversubscribes badly at this problem size (measured 0.04 img/s with 256
-    # threads); 32 threads is what the baseline actually uses and reports.
-    cores = min(os.cpu_count() or 1, 32)
+    model, physical, logical = host_description()
+    # oneDNN/OpenMP with every logical CPU of this 2-socket host oversubscribes badly at this problem size (measured in round 1:
+    # 0.04 img/s with 256 threads vs 7.1 with 32, batch 4), so the baseline runs on DN_CPU_THREADS (default 32) threads and the
+    # line says so next to the host's core counts.
+    cores = int(threads or os.environ.get("DN_CPU_THREADS", min(logical, 32)))
     torch.set_num_threads(cores)
     sd = ON.xavier_init_(ON.disp_vgg_bn_state_dict(), torch.Generator().manual_seed(0))
     params = []
@@ -71,8 +116,101 @@ def cpu_baseline(h, w, batch, steps, warmup):
         opt.step()
     dt = time.perf_counter() - t0
     return {"value": batch * steps / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "oracle Disp_vgg_BN+L1+Adam, %dx%d, batch %d, %d timed steps (%d warm-up), torch %d threads" % (
-                h, w, batch, steps, warmup, cores)}
+            "host_cpu": model, "host_physical_cores": physical, "host_logical_cpus": logical,
+            "sample": "oracle Disp_vgg_BN+L1+Adam, %dx%d, batch %d, %d timed steps (%d warm-up), torch %d threads on a host with %s "
+                      "physical cores / %d logical CPUs (all-logical-CPU run measured 0.04 img/s in round 1: oversubscribed)" % (
+                          h, w, batch, steps, warmup, cores, physical, logical)}
+
+
+def measured_peaks(dev):
+    """Attainable peaks on THIS box (SURVEY 8d "Peaks"): float4 streaming copy GB/s and register-resident fp32 MFMA TFLOP/s."""
+    from supervised_dispnet_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    n = 1 << 28                                           # 1 GiB in, 1 GiB out: far beyond the 256 MiB infinity cache
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    best_copy = 0.0
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call("dn_ubench_copy", src.data_ptr(), dst.data_ptr(), n, st)
+        e1.record()
+        e1.synchronize()
+        best_copy = max(best_copy, 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    blocks, iters = 256 * 8, 2000
+    out = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+    best_mfma = 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call("dn_ubench_mfma_f32", out.data_ptr(), blocks, iters, st)
+        e1.record()
+        e1.synchronize()
+        best_mfma = max(best_mfma, lib.dn_ubench_mfma_f32_flops(blocks, iters) / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return {"copy_GBps": best_copy, "mfma_f32_TFLOPs": best_mfma}
+
+
+def build_workload(cfg, batch, dev, seed, models, LF, U, reciprocal, FusedAdam):
+    """-> (step callable, optimizer, description).  Every config: forward -> loss -> zero_grad/backward -> (all-reduce) -> Adam."""
+    metric, netname, H, W, _b, ds, _gf = CONFIGS[cfg]
+    torch.manual_seed(0)                                   # identical random-init replicas on every rank
+    if netname == "Disp_vgg_BN":
+        net = models.Disp_vgg_BN(datasets=ds, with_classifier=False)
+    elif netname == "Disp_vgg_BN_DORN":
+        net = models.Disp_vgg_BN_DORN(datasets=ds, ordinal_c=80, with_classifier=False)
+    else:
+        net = models.Disp_res_50(datasets=ds)
+    _quiet_init(net)
+    net.to(dev).train()
+    params = list(net._hot_parameters())
+    order = list(net._grad_production_order())
+    pose_net = None
+    if cfg == "photo128":
+        pose_net = models.PoseExpNet(nb_ref_imgs=2, output_exp=False).to(dev)
+        pose_net.init_weights()
+        pose_net.train()
+        params += list(pose_net._hot_parameters())
+    opt = FusedAdam(params, lr=1e-4, betas=(0.9, 0.999), production_order=order)
+    img, gt = synthetic_batch(batch, H, W, dev, seed, ds)
+    state = {"reducer": None}
+
+    def finish_step(loss):
+        opt.zero_grad()
+        loss.backward()
+        red = state["reducer"]
+        opt.step(grad_scale=red.finish() if red is not None else 1.0)
+        return loss
+
+    if cfg in ("vggbn128", "vggbn480", "res50_480"):
+        desc = "%s L1-loss training step (fwd + 1/disp + masked L1 + bwd + Adam), synthetic %s %dx%d" % (netname, ds.upper(), H, W)
+
+        def step():
+            depth = [reciprocal(d) for d in net(img)]
+            return finish_step(LF.l1_loss(gt, depth, ds))               # README recipe: --loss L1 -s 0
+    elif cfg == "dorn128":
+        desc = "Disp_vgg_BN_DORN (ordinal_c 80) DORN-loss training step (fwd + SID labels + ordinal loss + bwd + Adam), fp32, synthetic KITTI %dx%d" % (H, W)
+
+        def step():
+            target = U.get_labels_sid(gt, ordinal_c=80, dataset=ds)     # train.py:431
+            _dec, ordc = net(img)
+            return finish_step(LF.DORN_loss(gt, ordc, target, ds))
+    else:
+        desc = ("Disp_vgg_BN + PoseExpNet (trained) photometric_reconstruction_loss over 2 refs x 4 scales + 0.1 * smooth_loss, "
+                "seq-len 3, synthetic KITTI %dx%d" % (H, W))
+        g = torch.Generator().manual_seed(seed + 77)
+        refs = [(img.cpu() + 0.05 * torch.randn(img.shape, generator=g)).clamp(-1, 1).to(dev) for _ in range(2)]
+        K = torch.tensor([[241.67, 0, 204.17], [0, 246.28, 59.0], [0, 0, 1]], dtype=torch.float32)
+        Kb = K.repeat(batch, 1, 1).to(dev)
+        Kib = torch.inverse(K).repeat(batch, 1, 1).to(dev)
+
+        def step():
+            mask, pose = pose_net(img, refs)
+            depth = [reciprocal(d) for d in net(img)]
+            l1 = LF.photometric_reconstruction_loss(img, refs, Kb, Kib, depth, mask, pose, "euler", "zeros")
+            return finish_step(l1 + 0.1 * LF.smooth_loss(depth))
+    return step, opt, state, desc
 
 
 def main():
@@ -80,23 +218,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--height", type=int, default=128)
-    ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--config", default="vggbn128", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--global-batch", type=int, default=32, help="--scaling strong: images per step over ALL ranks")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the config's; strong scaling: global/N)")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps (after the timed region) for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print the per-layer launch table to stderr")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU-only plumbing check of the N>1 path: build the net, the arena, the buckets, one fake all-reduce cycle, tear down")
     args = ap.parse_args()
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -115,29 +258,23 @@ def main():
         dist.barrier()
     import supervised_dispnet_amd.loss_functions as LF
     import supervised_dispnet_amd.models as models
+    import supervised_dispnet_amd.utils as U
     from supervised_dispnet_amd import engine
     from supervised_dispnet_amd.distributed import GradReducer
     from supervised_dispnet_amd.functional import reciprocal
     from supervised_dispnet_amd.optim import FusedAdam
 
-    torch.manual_seed(0)                                   # identical random-init replicas on every rank
-    net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
-    _quiet_init(net)
-    net.to(dev).train()
-    opt = FusedAdam(net._hot_parameters(), lr=1e-4, betas=(0.9, 0.999), production_order=net._grad_production_order())
+    metric, netname, H, W, cfg_batch, ds, gflop_img = CONFIGS[args.config]
+    if args.scaling == "strong":
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d does not divide over %d ranks" % (args.global_batch, world))
+        batch = args.global_batch // world
+    else:
+        batch = args.batch or cfg_batch
+    step, opt, state, desc = build_workload(args.config, batch, dev, rank, models, LF, U, reciprocal, FusedAdam)
     reducer = GradReducer(opt.arena) if world > 1 else None
+    state["reducer"] = reducer
     engine.GradSink.reducer = reducer
-    img, gt = synthetic_batch(args.batch, args.height, args.width, dev, seed=rank)
-
-    def step():
-        disparities = net(img)
-        depth = [reciprocal(d) for d in disparities]
-        loss = LF.l1_loss(gt, depth, "kitti")               # README recipe: --loss L1 -s 0 (smoothness weight 0)
-        opt.zero_grad()
-        loss.backward()
-        scale = reducer.finish() if reducer is not None else 1.0
-        opt.step(grad_scale=scale)
-        return loss
 
     def fence():
         if world > 1:
@@ -147,81 +284,140 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
 
-    # ---- instrumented steps (not part of `value`): HIP events around every implicit-GEMM launch
-    roofline = None
+    # ---- instrumented steps (not part of `value`): HIP events around every conv-family launch and every HBM-bound family
+    roofline = roofline_hbm = None
+    step_exec_flops = step_credited_flops = None
     if args.profile_steps > 0 and rank != 0:
         for _ in range(args.profile_steps):      # the steps carry collectives: every rank takes them, rank 0 records
             step()
         torch.cuda.synchronize()
     if rank == 0 and args.profile_steps > 0:
+        peaks = measured_peaks(dev)
         engine.PROFILE = []
         for _ in range(args.profile_steps):
             step()
         torch.cuda.synchronize()
-        agg = {}
+        prof, engine.PROFILE = engine.PROFILE, None
+        nps = args.profile_steps
         if args.per_layer:
             seen = {}
-            for name, flops, e0, e1, tag in engine.PROFILE:
-                r = seen.setdefault((name, tag), [0.0, 0.0, 0])
-                r[0] += flops; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += 1
-            print("%-28s %-58s %9s %9s %8s" % ("kernel", "layer", "ms/launch", "GFLOP", "TFLOP/s"), file=sys.stderr)
-            for (name, tag), (fl, sec, n) in seen.items():
-                print("%-28s %-58s %9.3f %9.2f %8.1f" % (name, tag, sec / n * 1e3, fl / n / 1e9, fl / sec / 1e12), file=sys.stderr)
-        for name, flops, e0, e1, _tag in engine.PROFILE:
-            a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += flops
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += 1
-        engine.PROFILE = None
-        dom = max(agg.items(), key=lambda kv: kv[1][1])
-        name, (fl, sec, n) = dom
+            for name, flops, e0, e1, tag, nbytes in prof:
+                r = seen.setdefault((name, tag), [0.0, 0.0, 0, 0])
+                r[0] += flops; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += 1; r[3] += nbytes
+            print("%-46s %-58s %9s %9s %8s %8s" % ("kernel", "layer / entry", "ms/launch", "GFLOP", "TFLOP/s", "GB/s"), file=sys.stderr)
+            for (name, tag), (fl, sec, n, nb) in seen.items():
+                print("%-46s %-58s %9.3f %9.2f %8.1f %8.0f" % (name, tag, sec / n * 1e3, fl / n / 1e9, fl / sec / 1e12, nb / sec / 1e9), file=sys.stderr)
+        mf, hb = {}, {}
+        for name, flops, e0, e1, _tag, nbytes in prof:
+            sec = e0.elapsed_time(e1) * 1e-3
+            if nbytes:
+                a = hb.setdefault(name, [0, 0.0, 0])
+                a[0] += nbytes; a[1] += sec; a[2] += 1
+            else:
+                a = mf.setdefault(name, [0.0, 0.0, 0])
+                a[0] += flops; a[1] += sec; a[2] += 1
+        execf = lambda k, fl: fl * (WINO_EXEC if "wino_" in k else 1.0)
+        step_credited_flops = sum(v[0] for v in mf.values()) / nps
+        step_exec_flops = sum(execf(k, v[0]) for k, v in mf.items()) / nps
+        name, (fl, sec, n) = max(mf.items(), key=lambda kv: kv[1][1])
         wino = "wino_" in name
-        roofline = {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(name),
-                    "algorithm": "winograd F(2x2,3x3): 16/36 of the direct multiply-accumulates" if wino else "direct implicit GEMM",
-                    "executed_frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS / (2.25 if wino else 1.0),
-                    "launches_per_step": n // args.profile_steps, "avg_launch_ms": sec / n * 1e3,
-                    "avg_launch_gflop": fl / n / 1e9,
-                    "by_kernel": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / args.profile_steps * 1e3,
-                                      "launches_per_step": v[2] // args.profile_steps} for k, v in sorted(agg.items())}}
-    elif world > 1:
-        pass
+        ach = execf(name, fl) / sec / 1e12
+        roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(name),
+                    "frac_of_measured_peak": ach / peaks["mfma_f32_TFLOPs"], "measured_peak": peaks["mfma_f32_TFLOPs"],
+                    "algorithm": "winograd F(2x2,3x3): executes 16/36 of the direct multiply-accumulates" if wino else "direct implicit GEMM",
+                    "credited_achieved": fl / sec / 1e12, "credited_frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "launches_per_step": n // nps, "avg_launch_ms": sec / n * 1e3, "avg_launch_gflop_executed": execf(name, fl) / n / 1e9,
+                    "avg_launch_gflop_credited": fl / n / 1e9,
+                    "by_kernel": {k: {"tflops_executed": execf(k, v[0]) / v[1] / 1e12, "tflops_credited": v[0] / v[1] / 1e12,
+                                      "ms_per_step": v[1] / nps * 1e3, "launches_per_step": v[2] // nps} for k, v in sorted(mf.items())}}
+        if hb:
+            name, (nb, sec, n) = max(hb.items(), key=lambda kv: kv[1][1])
+            gbps = nb / sec / 1e9
+            roofline_hbm = {"bound": "hbm", "kernel": name, "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                            "frac": gbps / PEAK_HBM_GBPS, "traffic": pmc_traffic(name), "frac_of_measured_peak": gbps / peaks["copy_GBps"],
+                            "measured_peak": peaks["copy_GBps"], "launches_per_step": n // nps, "avg_launch_ms": sec / n * 1e3,
+                            "avg_launch_algorithmic_bytes": nb / n,
+                            "by_kernel": {k: {"GBps": v[0] / v[1] / 1e9, "ms_per_step": v[1] / nps * 1e3, "launches_per_step": v[2] // nps}
+                                          for k, v in sorted(hb.items())}}
 
     if world > 1:
         dist.barrier()
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(args.height, args.width, args.cpu_batch, args.cpu_steps, 1)
-        total_images = args.batch * world * args.steps
-        ips = total_images / dt
-        step_flops = TRAIN_GFLOP_PER_IMG * 1e9 * args.batch if (args.height, args.width) == (128, 416) else None
+        if not args.no_cpu_baseline and world == 1 and args.config == "vggbn128":
+            cpu = cpu_baseline(H, W, args.cpu_batch, args.cpu_steps, args.cpu_warmup)
+        total_images = batch * world * args.steps
+        sec_step = dt / args.steps
         line = {
-            "metric": "images/sec fwd+bwd Disp_vgg_BN 128x416 b32 @1/2/4/8 GPU",
-            "value": ips, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Disp_vgg_BN L1-loss training step (fwd + 1/disp + masked L1 + bwd + Adam), synthetic KITTI "
-                                   "%dx%d, batch %d per GPU" % (args.height, args.width, args.batch),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss},
-            "step_tflops_per_gpu": (step_flops / (dt / args.steps) / 1e12) if step_flops else None,
-            "step_frac_of_fp32_mfma_peak": (step_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_flops else None,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "metric": metric, "value": total_images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec_step * 1e3, "ms_per_step_median": statistics.median(per_step_ms), "ms_per_step_min": min(per_step_ms),
+            "ms_per_step_max": max(per_step_ms), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
+                       "parallelism": "dp%d" % world, "final_loss": final_loss},
+            "step_tflops_credited_per_gpu": (step_credited_flops / sec_step / 1e12) if step_credited_flops else None,
+            "step_credited_frac": (step_credited_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_credited_flops else None,
+            "step_executed_frac": (step_exec_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_exec_flops else None,
+            "baseline_md_gflop_per_img": gflop_img,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def dry_run(args, world, rank):
+    """The N>1 plumbing without a GPU (CI, gloo): parameter arena in gradient-production order, bucketing, one all-reduce cycle
+    driven through the same GradSink hooks the engine calls, the shard slice of the strong-scaling batch, tear-down."""
+    import torch.distributed as dist
+    import supervised_dispnet_amd.models as models
+    from supervised_dispnet_amd import engine
+    from supervised_dispnet_amd.distributed import GradReducer, shard_slice
+    from supervised_dispnet_amd.optim import ParamArena
+    if world > 1:
+        dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+    _quiet_init(net)
+    arena = ParamArena(list(net._hot_parameters()), net._grad_production_order())
+    reducer = GradReducer(arena)
+    engine.GradSink.reducer = reducer
+    sink = engine.GradSink()
+    for p in arena.params:                                   # what the engine does as gradients land, decoder first
+        p._dn_grad_view.fill_(float(rank + 1))
+        sink.put(p, p._dn_grad_view)
+    scale = reducer.finish()
+    want = sum(range(1, world + 1))
+    ok = abs(scale - 1.0 / world) < 1e-12
+    for p in arena.params:
+        ok = ok and bool(torch.all(p._dn_grad_view == want))
+    sl = shard_slice(args.global_batch, rank, world)
+    engine.GradSink.reducer = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "ok": ok, "world": world, "buckets": len(reducer.buckets),
+                          "bucket_mb": [round((b["hi"] - b["lo"]) * 4 / 2 ** 20, 1) for b in reducer.buckets],
+                          "arena_params": len(arena.params), "shard": [sl.start, sl.stop]}))
+    if not ok:
+        raise SystemExit(1)
 
 
 def pmc_traffic(kernel):

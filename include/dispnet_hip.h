@@ -234,6 +234,13 @@ enum dn_masked_loss_kind { DN_LOSS_L1 = 0, DN_LOSS_L2 = 1, DN_LOSS_BERHU = 2, DN
 size_t dn_masked_loss_workspace_bytes(int32_t G, int64_t pixels);
 int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, float weight,
                        int32_t accumulate, float* stats, void* workspace, size_t workspace_bytes, float* loss, dn_stream_t stream);
+/* dn_masked_loss_fwd in pieces, for one-process-per-GPU runs of the whole-batch losses (the reference's DataParallel sees the
+ * gathered batch on GPU0, loss_functions.py:232-237): pass 0 -> stats[g][0..3] = (sum f, n, sum d, max r) of THIS rank's pixels;
+ * the caller all-reduces them (columns 0..2 add, column 3 takes the max); kind berHu then runs pass 1 -> stats[g][0], [2], [4]
+ * (sums that depend on the global max; they add across ranks); dn_masked_loss_finalize turns the stats into the loss. */
+int dn_masked_loss_stats(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, int32_t pass,
+                         float* stats, void* workspace, size_t workspace_bytes, dn_stream_t stream);
+int dn_masked_loss_finalize(float* stats, int32_t G, int32_t kind, float weight, int32_t accumulate, float* loss, dn_stream_t stream);
 /* dpred = dloss * weight/G * dL_g/dpred  (0 outside the mask / clamp range).  berHu includes the gradient through its
  * max-residual threshold, like torch autograd.  dloss: device scalar. */
 int dn_masked_loss_bwd(const float* gt, const float* pred, const float* stats, const float* dloss, int32_t G, int64_t pixels,
@@ -341,6 +348,15 @@ int dn_channel_scale(const float* x, const float* mask, int32_t N, int64_t HW, i
 int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                  double eps, double weight_decay, int32_t step, double grad_scale, dn_stream_t stream);
 int dn_fill(float* p, float value, int64_t n, dn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Attainable-peak probes (SURVEY.md section 8d "Peaks"; used by bench.py only): a float4 streaming copy of n floats
+ * (n % 4 == 0, 16-byte aligned; moves 8*n bytes) and a register-resident v_mfma_f32_32x32x2_f32 loop
+ * (out: blocks*256 floats; dn_ubench_mfma_f32_flops = the FLOPs one launch executes).
+ * ------------------------------------------------------------------------------------------------------------ */
+int dn_ubench_copy(const float* src, float* dst, int64_t n, dn_stream_t stream);
+int64_t dn_ubench_mfma_f32_flops(int32_t blocks, int32_t iters);
+int dn_ubench_mfma_f32(float* out, int32_t blocks, int32_t iters, dn_stream_t stream);
 
 #ifdef __cplusplus
 }

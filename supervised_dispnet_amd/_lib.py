@@ -83,6 +83,8 @@ SIGNATURES = {
     "dn_reciprocal_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "dn_masked_loss_workspace_bytes": (_sz, [_i32, _i64]),
     "dn_masked_loss_fwd": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _f, _i32, _vp, _vp, _sz, _vp, _vp]),
+    "dn_masked_loss_stats": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dn_masked_loss_finalize": (C.c_int, [_vp, _i32, _i32, _f, _i32, _vp, _vp]),
     "dn_masked_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _f, _i32, _f, _vp, _vp]),
     "dn_pyramid_down2": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dn_upsample_int_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -118,6 +120,9 @@ SIGNATURES = {
     "dn_channel_scale": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i32, _d, _vp]),
     "dn_fill": (C.c_int, [_vp, _f, _i64, _vp]),
+    "dn_ubench_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "dn_ubench_mfma_f32_flops": (_i64, [_i32, _i32]),
+    "dn_ubench_mfma_f32": (C.c_int, [_vp, _i32, _i32, _vp]),
     # diagnostic hook (host only)
     "dn_debug_conv_plan": (C.c_int, [_P(ConvDesc), C.c_int, _P(_i32), C.c_int]),
 }

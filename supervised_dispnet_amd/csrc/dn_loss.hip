@@ -525,6 +525,35 @@ int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t G, int64_t pi
   return check_launch("masked_loss_fwd");
 }
 
+// The same forward in pieces, for data-parallel runs of the whole-batch (Multiscale_*) losses: pass 0 fills stats[g][0..3]
+// (sum f, n, sum d, max r) from this rank's pixels; the ranks exchange them (sums add, the maximum takes the max); for berHu pass
+// 1 then fills stats[g][0], [2], [4] with the sums that depend on the global maximum (exchanged again, they add); finalize turns
+// the global stats into the loss.  dn_masked_loss_bwd with those stats yields d(global loss)/d(local prediction).
+int dn_masked_loss_stats(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, int32_t pass,
+                         float* stats, void* workspace, size_t workspace_bytes, dn_stream_t stream) {
+  DN_REQUIRE(gt && pred && stats && workspace && G > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_stats: bad argument");
+  DN_REQUIRE(kind >= DN_LOSS_L1 && kind <= DN_LOSS_SCALE_INV && (pass == 0 || (pass == 1 && kind == DN_LOSS_BERHU)), DN_ERR_BAD_ARG,
+             "dn_masked_loss_stats: bad kind %d / pass %d", kind, pass);
+  DN_REQUIRE(workspace_bytes >= dn_masked_loss_workspace_bytes(G, pixels), DN_ERR_WORKSPACE, "dn_masked_loss_stats: workspace too small");
+  hipStream_t s = as_stream(stream);
+  const int nsp = loss_splits(pixels);
+  float* partial = reinterpret_cast<float*>(workspace);
+  if (pass == 0) {
+    hipLaunchKernelGGL(masked_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, kind, partial);
+    hipLaunchKernelGGL(masked_reduceA_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+  } else {
+    hipLaunchKernelGGL(berhu_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, stats, partial);
+    hipLaunchKernelGGL(masked_reduceB_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+  }
+  return check_launch("masked_loss_stats");
+}
+
+int dn_masked_loss_finalize(float* stats, int32_t G, int32_t kind, float weight, int32_t accumulate, float* loss, dn_stream_t stream) {
+  DN_REQUIRE(stats && loss && G > 0 && kind >= DN_LOSS_L1 && kind <= DN_LOSS_SCALE_INV, DN_ERR_BAD_ARG, "dn_masked_loss_finalize: bad argument");
+  hipLaunchKernelGGL(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), stats, G, kind, weight, accumulate, loss);
+  return check_launch("masked_loss_finalize_kernel");
+}
+
 int dn_masked_loss_bwd(const float* gt, const float* pred, const float* stats, const float* dloss, int32_t G, int64_t pixels,
                        float max_depth, int32_t kind, float weight, float* dpred, dn_stream_t stream) {
   DN_REQUIRE(gt && pred && stats && dloss && dpred && G > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_bwd: bad argument");

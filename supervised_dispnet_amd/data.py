@@ -149,7 +149,10 @@ class SyntheticDepthSet(data.Dataset):
 
 class RankSampler(data.Sampler):
     """Every rank draws the SAME shuffled global order and keeps its contiguous slice of each global batch -- the split
-    nn.DataParallel.scatter makes of the reference's batch (train.py:316), one process per GPU instead of one per node."""
+    nn.DataParallel.scatter makes of the reference's batch (train.py:316), one process per GPU instead of one per node.
+    With drop_last=False (validation) the last, partial global batch is split into ceil(m / world)-sized contiguous slices
+    (again what scatter does); a rank whose slice is empty simply has one batch fewer -- the validation loops carry no
+    collective per batch, the (sum, count) all-reduce at their end handles unequal counts."""
 
     def __init__(self, n, global_batch, rank, world, shuffle, seed=0, drop_last=True):
         if global_batch % world != 0:
@@ -161,14 +164,25 @@ class RankSampler(data.Sampler):
     def set_epoch(self, epoch):
         self.epoch = epoch
 
+    def _slice(self, m):
+        """[lo, hi) of this rank inside a global batch of m <= gb samples."""
+        per = self.gb // self.world if m == self.gb else (m + self.world - 1) // self.world
+        return min(self.rank * per, m), min((self.rank + 1) * per, m)
+
     def __iter__(self):
         order = list(range(self.n))
         if self.shuffle:
             random.Random(self.seed + self.epoch).shuffle(order)
-        per = self.gb // self.world
         for b in range(self.nbatches):
             chunk = order[b * self.gb:(b + 1) * self.gb]
-            yield chunk[self.rank * per:(self.rank + 1) * per]
+            lo, hi = self._slice(len(chunk))
+            if hi > lo:
+                yield chunk[lo:hi]
 
     def __len__(self):
-        return self.nbatches
+        full = self.n // self.gb
+        tail = self.n - full * self.gb
+        if self.nbatches == full or tail == 0:
+            return self.nbatches
+        lo, hi = self._slice(tail)
+        return full + (1 if hi > lo else 0)

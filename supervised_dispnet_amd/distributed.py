@@ -77,6 +77,33 @@ def shard_slice(global_batch, rank, world):
     return slice(rank * per, (rank + 1) * per)
 
 
+def data_parallel_world(process_group=None):
+    """World size of the data-parallel job (1 when torch.distributed is not initialised)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(process_group)
+    return 1
+
+
+def exchange_loss_stats(stats, sum_cols, max_cols=(), process_group=None):
+    """In-place exchange of per-group loss statistics [G, S] between the ranks: columns `sum_cols` are summed, columns
+    `max_cols` take the maximum, the others are left alone.  This is the (sum, count) exchange of SURVEY.md 8e that makes the
+    Multiscale_* / DORN whole-batch normalisation (loss_functions.py:232-237, 72-73) identical to the reference's, which sees the
+    gathered batch on GPU0: a handful of floats per step."""
+    if data_parallel_world(process_group) <= 1:
+        return stats
+    if sum_cols:
+        idx = list(sum_cols)
+        part = stats[:, idx].contiguous()
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=process_group)
+        stats[:, idx] = part
+    if max_cols:
+        idx = list(max_cols)
+        part = stats[:, idx].contiguous()
+        dist.all_reduce(part, op=dist.ReduceOp.MAX, group=process_group)
+        stats[:, idx] = part
+    return stats
+
+
 def global_masked_mean(local_sum, local_count, process_group=None):
     """sum / count over ALL ranks.  The Multiscale_* losses and DORN_loss normalise by the valid-pixel count of the whole
     batch (loss_functions.py:232-237, 72-73), which the reference's DataParallel sees gathered on GPU0; under one process
@@ -85,3 +112,23 @@ def global_masked_mean(local_sum, local_count, process_group=None):
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:
         dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=process_group)
     return pair[0] / pair[1]
+
+
+def average_plain_grads(params, process_group=None):
+    """Data-parallel exchange for the torch.optim optimizers (--sgd / --diff-lr, train.py:306-314): the `.grad` tensors are
+    summed over the ranks in ONE flattened all-reduce and divided by the world size, which is what nn.DataParallel's gradient
+    reduce gives the reference for every optimizer.  Parameters without a gradient on this step contribute zeros (every rank
+    walks the same list, so the collective shapes agree)."""
+    world = data_parallel_world(process_group)
+    if world <= 1:
+        return
+    params = list(params)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+    flat.div_(world)
+    off = 0
+    for p in params:
+        n = p.numel()
+        if p.grad is not None:
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n

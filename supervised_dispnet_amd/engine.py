@@ -110,8 +110,22 @@ class _Timed(object):
         if PROFILE is not None:
             self.e1.record()
             launched = _lib.load().dn_last_kernel().decode(errors="replace")     # what the library actually ran (rocprofv3 name)
-            PROFILE.append((launched or self.name, self.flops, self.e0, self.e1, self.tag))
+            PROFILE.append((launched or self.name, self.flops, self.e0, self.e1, self.tag, 0))
         return False
+
+
+def hbm_call(kernel, nbytes, entry, *args):
+    """_lib.call(entry, *args) for an HBM-bound family; when PROFILE is on the launch is bracketed with HIP events and recorded
+    with its ALGORITHMIC byte count (each operand read once, each result written once) under the name rocprofv3 prints for
+    its dominant kernel -- bench.py's `roofline_hbm` entry."""
+    if PROFILE is None:
+        return _lib.call(entry, *args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(entry, *args)
+    e1.record()
+    PROFILE.append((kernel, 0, e0, e1, entry, int(nbytes)))
 
 
 def bump_param_epoch():
@@ -444,7 +458,8 @@ def act_bwd(g, y_post, act, p0, p1, rows, Cn, out=None):
     """g <- g * act'(y_post) in place; returns the bias gradient (column sums of the result), written into `out` if given."""
     nblk = _lib.load().dn_reduce_blocks(rows, Cn)
     partial = torch.empty((nblk, Cn), dtype=torch.float32, device=g.device)
-    _lib.call("dn_act_bwd_reduce", g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn, partial.data_ptr(), _stream())
+    hbm_call("dn::colreduce_kernel<dn::ActBwdOp, %d>" % (4 if Cn % 4 == 0 else 1), rows * Cn * 12, "dn_act_bwd_reduce", g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn,
+             partial.data_ptr(), _stream())
     return colsum(partial, nblk, Cn, out=out)
 
 
@@ -528,8 +543,9 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
                 nblk = _lib.load().dn_reduce_blocks(y.rows, Cn)
                 y.partial = torch.empty((nblk, Cn, 2), dtype=torch.float32, device=dev)
                 y.partial_rows = nblk
-                _lib.call("dn_bn_relu_bwd_reduce", g.data_ptr(), y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(),
-                          y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn, y.partial.data_ptr(), _stream())
+                hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 12, "dn_bn_relu_bwd_reduce", g.data_ptr(),
+                         y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
+                         y.partial.data_ptr(), _stream())
             # written straight into the optimizer arena's gradient slices when there is one (no copy launches)
             dgamma = sink.dest(bn.weight)
             dbeta = sink.dest(bn.bias)
@@ -537,9 +553,9 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
                 dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
             if dbeta is None:
                 dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
-            _lib.call("dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(),
-                      bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn,
-                      dgamma.data_ptr(), dbeta.data_ptr(), _stream())
+            hbm_call("dn::bn_bwd_apply_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
+                     y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride,
+                     y.partial_offset, y.rows, Cn, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
             sink.put(bn.weight, dgamma)
             sink.put(bn.bias, dbeta)
         else:
@@ -561,8 +577,8 @@ def block_pool(tape, y):
     dev = y.t.device
     p_t = torch.empty((y.N, y.H // 2, y.W // 2, y.C), dtype=torch.float32, device=dev)
     idx = torch.empty((y.N, y.H // 2, y.W // 2, y.C), dtype=torch.uint8, device=dev)
-    _lib.call("dn_bn_relu_pool_fwd", y.t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.N, y.H, y.W, y.C,
-              p_t.data_ptr(), idx.data_ptr(), _stream())
+    hbm_call("dn::bn_relu_pool_fwd_kernel", y.rows * y.C * 4 * 1.25 + y.rows * y.C // 4, "dn_bn_relu_pool_fwd", y.t.data_ptr(),
+             y.scale.data_ptr(), y.shift.data_ptr(), y.N, y.H, y.W, y.C, p_t.data_ptr(), idx.data_ptr(), _stream())
     p = Act(p_t, y.N, y.H // 2, y.W // 2, y.C)
 
     def backward():
@@ -573,8 +589,9 @@ def block_pool(tape, y):
         y.partial_rows = nblk
         y.grad = y.new_like()
         y.grad_is_dz = True
-        _lib.call("dn_bn_relu_pool_bwd", p.grad.data_ptr(), idx.data_ptr(), y.t.data_ptr(), y.mean.data_ptr(),
-                  y.invstd.data_ptr(), y.N, y.H, y.W, y.C, y.grad.data_ptr(), y.partial.data_ptr(), _stream())
+        hbm_call("dn::colreduce_kernel<dn::PoolBwdOp, 4>", y.rows * y.C * 4 * 2.25 + y.rows * y.C // 4, "dn_bn_relu_pool_bwd",
+                 p.grad.data_ptr(), idx.data_ptr(), y.t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.N, y.H, y.W, y.C,
+                 y.grad.data_ptr(), y.partial.data_ptr(), _stream())
         p.grad = None
 
     tape.push(backward)

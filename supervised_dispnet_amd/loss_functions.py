@@ -27,14 +27,22 @@ def _f32c(t, what):
 class _MaskedLoss(torch.autograd.Function):
     """Sum of terms of the masked-loss family (C entry points dn_masked_loss_fwd/_bwd) as ONE autograd node.
     Term i: `groups[i]` runs of equal length over (gts[i], preds[i]), each with its own mask mean; contributes
-    weights[i] * mean over its groups.  The kernels accumulate into one device scalar -- no host arithmetic."""
+    weights[i] * mean over its groups.  The kernels accumulate into one device scalar -- no host arithmetic.
+
+    `sync` (a world size > 1): the terms are WHOLE-BATCH means (Multiscale_*: loss_functions.py:232-237 normalises by the valid
+    count of the gathered batch) computed one process per GPU: every rank reduces its own pixels to (sum, count, max) statistics,
+    the statistics are all-reduced (distributed.exchange_loss_stats) and the division happens afterwards, so the value is the
+    reference's whole-batch number on every rank.  The backward then yields world * d(global loss)/d(local prediction): the
+    data-parallel optimizer averages the ranks' parameter gradients (1/world folded into Adam), which restores the sum."""
 
     @staticmethod
-    def forward(ctx, max_depth, kind, groups, weights, gts, *preds):
+    def forward(ctx, max_depth, kind, groups, weights, sync, gts, *preds):
         lib = _lib.load()
         dev = preds[0].device
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        saved, cfg = [], []
+        saved, cfg, work = [], [], []
+        all_stats = torch.zeros((sum(groups[:len(preds)]), _lib.LOSS_STATS), dtype=torch.float32, device=dev)
+        row = 0
         for i, (gt, pred) in enumerate(zip(gts, preds)):
             require_cuda(pred, "predicted depth")
             require_cuda(gt, "ground-truth depth")
@@ -45,27 +53,43 @@ class _MaskedLoss(torch.autograd.Function):
             pixels = pc.numel() // g
             nbytes = lib.dn_masked_loss_workspace_bytes(g, pixels)
             ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
-            stats = torch.empty((g, _lib.LOSS_STATS), dtype=torch.float32, device=dev)
-            _lib.call("dn_masked_loss_fwd", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, weights[i], 0 if i == 0 else 1,
-                      stats.data_ptr(), ws.data_ptr(), nbytes, loss.data_ptr(), _stream())
+            stats = all_stats[row:row + g]
+            row += g
+            if sync > 1:
+                _lib.call("dn_masked_loss_stats", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, 0, stats.data_ptr(),
+                          ws.data_ptr(), nbytes, _stream())
+                work.append((gtc, pc, g, pixels, stats, ws, nbytes))
+            else:
+                _lib.call("dn_masked_loss_fwd", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, weights[i], 0 if i == 0 else 1,
+                          stats.data_ptr(), ws.data_ptr(), nbytes, loss.data_ptr(), _stream())
             saved += [gtc, pc, stats]
             cfg.append((g, pixels, weights[i], pred.shape))
+        if sync > 1:
+            from .distributed import exchange_loss_stats
+            exchange_loss_stats(all_stats, sum_cols=(0, 1, 2), max_cols=(3,))
+            if kind == _lib.LOSS_BERHU:
+                for gtc, pc, g, pixels, stats, ws, nbytes in work:
+                    _lib.call("dn_masked_loss_stats", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, 1, stats.data_ptr(),
+                              ws.data_ptr(), nbytes, _stream())
+                exchange_loss_stats(all_stats, sum_cols=(0, 2, 4), max_cols=())
+            for i, (gtc, pc, g, pixels, stats, ws, nbytes) in enumerate(work):
+                _lib.call("dn_masked_loss_finalize", stats.data_ptr(), g, kind, weights[i], 0 if i == 0 else 1, loss.data_ptr(), _stream())
         ctx.save_for_backward(*saved)
-        ctx.cfg = (max_depth, kind, cfg)
+        ctx.cfg = (max_depth, kind, cfg, float(max(sync, 1)))
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        max_depth, kind, cfg = ctx.cfg
+        max_depth, kind, cfg, up = ctx.cfg
         dl = dloss.contiguous().float()
         grads = []
         for i, (g, pixels, weight, shape) in enumerate(cfg):
             gtc, pc, stats = ctx.saved_tensors[3 * i:3 * i + 3]
             dpred = torch.empty(shape, dtype=torch.float32, device=pc.device)
             _lib.call("dn_masked_loss_bwd", gtc.data_ptr(), pc.data_ptr(), stats.data_ptr(), dl.data_ptr(), g, pixels, max_depth, kind,
-                      weight, dpred.data_ptr(), _stream())
+                      weight * up, dpred.data_ptr(), _stream())
             grads.append(dpred)
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 def _scale0(depth):
@@ -78,7 +102,8 @@ def _scale0(depth):
 
 def _per_sample(gt_depth, depth, datasets, kind):
     d0 = _scale0(depth)
-    return _MaskedLoss.apply(_max_depth(datasets), kind, [d0.shape[0]], [1.0], [gt_depth], d0)
+    # per-sample means divided by the batch size: exactly shardable over ranks, no exchange needed
+    return _MaskedLoss.apply(_max_depth(datasets), kind, [d0.shape[0]], [1.0], 0, [gt_depth], d0)
 
 
 def l1_loss(gt_depth, depth, datasets):
@@ -139,7 +164,8 @@ def generate_bilinear_pyramid(image):
 def _multiscale(gt_list, preds, kind):
     """One mask over the WHOLE batch per scale, weight 1/2^i, max depth hard-coded 80 (reference :229-238)."""
     n = min(len(gt_list), len(preds))
-    return _MaskedLoss.apply(80.0, kind, [1] * n, [1.0 / (2 ** i) for i in range(n)], list(gt_list[:n]), *preds[:n])
+    from .distributed import data_parallel_world
+    return _MaskedLoss.apply(80.0, kind, [1] * n, [1.0 / (2 ** i) for i in range(n)], data_parallel_world(), list(gt_list[:n]), *preds[:n])
 
 
 def Multiscale_L1_loss(gt_depth, depth, pool_type="bilinear"):

@@ -48,12 +48,14 @@ class HipNetFunction(torch.autograd.Function):
     require one (feature maps handed to a decoder)."""
 
     @staticmethod
-    def forward(ctx, net, n_in, *rest):
+    def forward(ctx, net, n_in, grad_mode, *rest):
         inputs, params = rest[:n_in], rest[n_in:]
-        recording = any(ctx.needs_input_grad[2:])
+        # needs_input_grad ignores torch.no_grad() (and grad mode is always off INSIDE forward): run_net passes the caller's mode,
+        # so validation / test_disp forwards do not record the tape nor keep the activations alive
+        recording = grad_mode and any(ctx.needs_input_grad[3:])
         tape = engine.Tape(recording)
         sink = engine.GradSink()
-        in_acts = [engine.Act.from_nchw(x, needs_grad=ctx.needs_input_grad[2 + i]) for i, x in enumerate(inputs)]
+        in_acts = [engine.Act.from_nchw(x, needs_grad=recording and ctx.needs_input_grad[3 + i]) for i, x in enumerate(inputs)]
         outs = net._hip_forward(tape, sink, *in_acts)         # list[Act]
         ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
         results = tuple(a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2) for a in outs)
@@ -69,7 +71,7 @@ class HipNetFunction(torch.autograd.Function):
         ig = tuple((a.grad.permute(0, 3, 1, 2) if (a.needs_grad and a.grad is not None) else None) for a in ctx.in_acts)
         pg = tuple(ctx.sink.get(p) for p in ctx.params)
         ctx.tape = ctx.outs = ctx.in_acts = None
-        return (None, None) + ig + pg
+        return (None, None, None) + ig + pg
 
 
 def run_net(net, *inputs):
@@ -80,4 +82,4 @@ def run_net(net, *inputs):
     params = [p for p in net._hot_parameters()]
     for p in params:
         engine.require_cuda(p, "model parameters")
-    return HipNetFunction.apply(net, len(inputs), *inputs, *params)
+    return HipNetFunction.apply(net, len(inputs), torch.is_grad_enabled(), *inputs, *params)

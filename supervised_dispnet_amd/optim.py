@@ -70,7 +70,7 @@ class FusedAdam(object):
         a.gather_stray_grads()
         self.step_count += 1
         g = self.param_groups[0]
-        _lib.call("dn_adam_step", a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+        engine.hbm_call("dn::adam_kernel", a.numel * 28, "dn_adam_step", a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                   self.exp_avg_sq.data_ptr(), a.numel, float(g["lr"]), self.betas[0], self.betas[1], self.eps,
                   self.weight_decay, self.step_count, float(grad_scale), engine._stream())
         engine.bump_param_epoch()

@@ -1,4 +1,6 @@
 """Mirror of the hot-path pieces of the reference's utils.py: the SID discretisation used by the DORN head / loss."""
+import os
+
 import torch
 
 from . import _lib
@@ -33,3 +35,19 @@ def get_depth_sid(labels, ordinal_c=71.0, dataset='kitti'):
     out = torch.empty(l.shape, dtype=torch.float32, device=l.device)
     _lib.call("dn_sid_depth", l.data_ptr(), l.numel(), float(ordinal_c), _beta(dataset), out.data_ptr(), _stream())
     return out
+
+
+def load_model(pretrained_model, weights_folder):
+    """Monodepth2 weight loader of the reference (train.py:726-751, test_disp.py:85-86): for n in ("encoder", "depth") read
+    <weights_folder>/<n>.pth, keep the keys the module has, load.  Fails loudly when the folder or a file is missing."""
+    folder = os.path.expanduser(weights_folder) if weights_folder else weights_folder
+    if not folder or not os.path.isdir(folder):
+        raise FileNotFoundError("Cannot find folder {}".format(folder))
+    print("loading model from folder {}".format(folder))
+    for n in ("encoder", "depth"):
+        print("Loading {} weights...".format(n))
+        path = os.path.join(folder, "{}.pth".format(n))
+        model_dict = pretrained_model[n].state_dict()
+        pretrained_dict = torch.load(path, map_location="cpu")
+        model_dict.update({k: v for k, v in pretrained_dict.items() if k in model_dict})
+        pretrained_model[n].load_state_dict(model_dict)

@@ -48,7 +48,7 @@ def build_parser():
     return p
 
 
-def create_disp_net(args, models, networks, device):
+def create_disp_net(args, models, networks, device, U=None):
     if args.monodepth2 or args.stereo or args.mono:
         if args.network == "disp_vgg_BN":
             enc = networks.vggEncoder(num_layers=16, pretrained=False).to(device)
@@ -56,7 +56,10 @@ def create_disp_net(args, models, networks, device):
             enc = networks.ResnetEncoder(num_layers=18, pretrained=False).to(device)
         else:
             raise ValueError("undefined network")
-        return models.monodepth2(encoder=enc, decoder=networks.DepthDecoder(enc.num_ch_enc).to(device))
+        dec = networks.DepthDecoder(enc.num_ch_enc).to(device)
+        if args.mono or args.stereo:            # test_disp.py:85-86: the monodepth2 weights come from a folder (encoder.pth, depth.pth)
+            U.load_model({"encoder": enc, "depth": dec}, args.pretrained_dispnet)
+        return models.monodepth2(encoder=enc, decoder=dec)
     table = {"dispnet": "DispNetS", "disp_res": "Disp_res", "disp_res_50": "Disp_res_50", "disp_res_18": "Disp_res_18",
              "disp_vgg": "Disp_vgg_feature", "disp_vgg_BN": "Disp_vgg_BN", "FCRN": "FCRN", "res50_aspp": "res50_aspp",
              "ASPP": "deeplab_depth", "disp_res_101": "Disp_res_101", "DORN": "DORN"}
@@ -120,7 +123,7 @@ def main(argv=None):
         raise ValueError("gt-type '{}' is outside this path (KITTI and NYU are supported)".format(args.gt_type))
     if args.pretrained_posenet is not None:
         raise ValueError("PoseNet-scaled evaluation is outside this path; omit --pretrained-posenet")
-    disp_net = create_disp_net(args, models, networks, device)
+    disp_net = create_disp_net(args, models, networks, device, U)
     if not (args.mono or args.stereo):
         disp_net.load_state_dict(torch.load(args.pretrained_dispnet, map_location=device)["state_dict"])
     disp_net.eval()

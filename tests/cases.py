@@ -1,0 +1,21 @@
+"""Closed-form inputs of the config-size parity cases shared by the CPU oracle tests and the GPU tests (the golden generator
+tests/golden/make_goldens.py builds the same tensors from the same detgen tags)."""
+import torch
+
+from oracle import detgen
+
+
+def config3_inputs(b=2, h=128, w=416):
+    """BASELINE configs[2] (photometric warp loss, seq-len 3): target frame, two reference frames, KITTI intrinsics at 416x128."""
+    tgt = detgen.image_batch(b, h, w, "cfg3:tgt")
+    refs = [(tgt + 0.1 * detgen.uniform((b, 3, h, w), "cfg3:ref%d" % i, -1, 1)).clamp(-1, 1) for i in range(2)]
+    k = torch.tensor([[241.67, 0, 204.17], [0, 246.28, 59.0], [0, 0, 1]], dtype=torch.float32).repeat(b, 1, 1)
+    return tgt, refs, k, torch.inverse(k)
+
+
+def dorn80_inputs(b=2, h=128, w=416):
+    """BASELINE configs[4] (ordinal_c = 80): image, 5 %-dense ground truth, injected Dropout2d keep/scale pattern [b,16]."""
+    x = detgen.image_batch(b, h, w, "dorn80:x")
+    gt = detgen.sparse_depth(b, h, w, "dorn80:gt", density=0.05)
+    mask = detgen.bernoulli((b, 16), "dorn80:drop", 0.5).float() * 2.0
+    return x, gt, mask

@@ -554,6 +554,78 @@ def gold_posenet(ref_pose):
     save("posenet", **arrays)
 
 
+def gold_config3(ref_vgg, ref_pose, ref_loss, ref_warp):
+    """BASELINE config 3 at its own resolution (2 x 128 x 416, seq-len 3): train.py:426-488 -- PoseExpNet -> Disp_vgg_BN ->
+    1/disp -> photometric_reconstruction_loss + 0.1 * smooth_loss -> backward through BOTH nets (grid_sample at the container's
+    default align_corners=False, which is what the imported reference yields today)."""
+    b, h, w = 2, 128, 416
+    ref_warp.pixel_coords = None
+    tgt = detgen.image_batch(b, h, w, "cfg3:tgt")
+    refs = [(tgt + 0.1 * detgen.uniform((b, 3, h, w), "cfg3:ref%d" % i, -1, 1)).clamp(-1, 1) for i in range(2)]
+    k = torch.tensor([[241.67, 0, 204.17], [0, 246.28, 59.0], [0, 0, 1]], dtype=torch.float32).repeat(b, 1, 1)
+    kinv = torch.inverse(k)
+    disp_net = ref_vgg.Disp_vgg_BN(datasets="kitti")
+    detgen.fill_state_dict(disp_net.state_dict(), "vggbn")
+    pose_net = ref_pose.PoseExpNet(nb_ref_imgs=2, output_exp=False)
+    detgen.fill_state_dict(pose_net.state_dict(), "posenet")
+    disp_net.train(); pose_net.train()
+    mask, pose = pose_net(tgt, refs)
+    disps = disp_net(tgt)
+    depth = [1 / d for d in disps]
+    l1 = ref_loss.photometric_reconstruction_loss(tgt, refs, k, kinv, depth, mask, pose, "euler", "zeros")
+    l3 = ref_loss.smooth_loss(depth)
+    (1.0 * l1 + 0.1 * l3).backward()
+    arrays = {"photo": np.float64(l1.item()), "smooth": np.float64(l3.item()), "pose": _np(pose), "kinv": _np(kinv)}
+    for i, o in enumerate(disps):
+        for kk, v in detgen.summarize(o).items():
+            arrays["disp%d_%s" % (i, kk)] = v
+    _grad_summaries(disp_net, arrays, ["features.features.0.weight", "features.features.40.weight", "upconv4.0.weight", "iconv2.0.weight",
+                                       "iconv0.0.weight", "iconv0.0.bias", "disp0.0.weight", "disp3.0.weight"], prefix="disp:grad:")
+    _grad_summaries(pose_net, arrays, ["conv1.0.weight", "conv7.0.weight", "pose_pred.weight", "pose_pred.bias"], prefix="pose:grad:")
+    g = dict(pose_net.named_parameters())["pose_pred.bias"].grad
+    arrays["full:pose:grad:pose_pred.bias"] = _np(g)
+    g = dict(disp_net.named_parameters())["disp0.0.weight"].grad
+    arrays["full:disp:grad:disp0.0.weight"] = _np(g)
+    save("config3_cfg", **arrays)
+
+
+class _FixedChannelMask(nn.Module):
+    """Stand-in for nn.Dropout2d(0.5) with a given keep/scale pattern (RNG streams cannot be matched across implementations)."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        return x * self.mask if self.training else x
+
+
+def gold_dorn80(ref_dorn, ref_utils, ref_loss):
+    """BASELINE config 5 at its own size: Disp_vgg_BN_DORN with ordinal_c = 80 (train.py:35 default) on 2 x 128 x 416, training
+    mode with an injected Dropout2d pattern, DORN_loss + backward (fp32; the reference has no mixed precision)."""
+    b, h, w, K = 2, 128, 416, 80
+    net = ref_dorn.Disp_vgg_BN_DORN(datasets="kitti", ordinal_c=K)
+    detgen.fill_state_dict(net.state_dict(), "vggdorn80")
+    mask = detgen.bernoulli((b, 16), "dorn80:drop", 0.5).float() * 2.0
+    net.dropout = _FixedChannelMask(mask.view(b, 16, 1, 1))
+    net.train()
+    x = detgen.image_batch(b, h, w, "dorn80:x")
+    gt = detgen.sparse_depth(b, h, w, "dorn80:gt", density=0.05)
+    tgt = ref_utils.get_labels_sid(gt, ordinal_c=K, dataset="kitti")
+    dec, ordc = net(x)
+    loss = ref_loss.DORN_loss(gt, ordc, tgt, "kitti")
+    loss.backward()
+    arrays = {"loss": np.float64(loss.item()), "labels_sum": np.int64(int(tgt.long().sum())), "decode_sum": np.int64(int(dec.sum())),
+              "decode_samples": _np(dec).reshape(-1)[::997].astype(np.int64)}
+    for kk, v in detgen.summarize(ordc).items():
+        arrays["ord_%s" % kk] = v
+    params = dict(net.named_parameters())
+    arrays["full:grad:conv_ord.weight"] = _np(params["conv_ord.weight"].grad)
+    arrays["full:grad:conv_ord.bias"] = _np(params["conv_ord.bias"].grad)
+    _grad_summaries(net, arrays, ["iconv0.0.weight", "upconv0.0.weight", "features.features.40.weight", "features.features.0.weight"])
+    save("dorn80_cfg", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -585,6 +657,8 @@ def main():
         "res50": lambda: gold_res50(ref_res50, ref_loss),
         "mono2": lambda: gold_mono2(ref_networks, ref_mono2),
         "posenet": lambda: gold_posenet(ref_pose),
+        "config3": lambda: gold_config3(ref_vgg, ref_pose, ref_loss, ref_warp),
+        "dorn80": lambda: gold_dorn80(ref_dorn, ref_utils, ref_loss),
     }
     for name, fn in sections.items():
         if not want or name in want:

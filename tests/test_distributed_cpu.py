@@ -129,3 +129,110 @@ def test_single_process_reducer_is_a_no_op():
     assert shard_slice(32, 0, 1) == slice(0, 32)
     with pytest.raises(ValueError):
         shard_slice(30, 0, 4)
+
+
+def _worker_stats_and_plain(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from supervised_dispnet_amd.distributed import average_plain_grads, data_parallel_world, exchange_loss_stats
+        assert data_parallel_world() == world
+        # per-group statistics [G, 8]: columns 0..2 are sums, column 3 is a maximum, the rest must be left alone
+        st = torch.arange(16, dtype=torch.float32).view(2, 8) * (rank + 1)
+        keep = st.clone()
+        exchange_loss_stats(st, sum_cols=(0, 1, 2), max_cols=(3,))
+        tot = sum(r + 1 for r in range(world))
+        base = torch.arange(16, dtype=torch.float32).view(2, 8)
+        assert torch.equal(st[:, :3], base[:, :3] * tot)
+        assert torch.equal(st[:, 3], base[:, 3] * world)              # max over ranks of base * (rank + 1)
+        assert torch.equal(st[:, 4:], keep[:, 4:])
+        # whole-batch masked mean = sum of sums / sum of counts: identical to the single-process value on the gathered batch
+        g = torch.Generator().manual_seed(5)
+        gt = torch.rand(4, 6, 8, generator=g) * 100.0 - 10.0          # some values outside (0, 80)
+        pred = torch.rand(4, 6, 8, generator=g) * 80.0
+        valid = (gt > 0) & (gt < 80)
+        want = (gt[valid] - pred[valid]).abs().mean()
+        sl = slice(rank * 2, rank * 2 + 2)
+        v = valid[sl]
+        loc = torch.zeros(1, 8)
+        loc[0, 0] = (gt[sl][v] - pred[sl][v]).abs().sum()
+        loc[0, 1] = v.sum()
+        exchange_loss_stats(loc, sum_cols=(0, 1, 2), max_cols=(3,))
+        assert torch.allclose(loc[0, 0] / loc[0, 1], want, rtol=1e-6)
+        # --sgd / --diff-lr path: .grad tensors are averaged over the ranks; a parameter without gradient stays without
+        ps = _make_params()
+        for i, p in enumerate(ps):
+            if i != 2:
+                p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+        average_plain_grads(ps)
+        for i, p in enumerate(ps):
+            if i == 2:
+                assert p.grad is None
+            else:
+                assert torch.allclose(p.grad, torch.full_like(p, (i + 1) * tot / world))
+        out.put((rank, "ok"))
+    except Exception as e:
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_loss_stats_exchange_and_plain_grad_average_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stats_and_plain, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+@pytest.mark.parametrize("n,gb,world", [(1000, 32, 8), (37, 8, 4), (64, 32, 8), (5, 8, 2), (33, 32, 8)])
+def test_rank_sampler_covers_every_sample_once_and_never_yields_an_empty_batch(n, gb, world):
+    """drop_last=False (the validation loader, train.py): the partial tail batch must not hand an empty index list to any rank
+    (default_collate([]) raises) and the union over ranks must be every sample exactly once."""
+    import torch.utils.data as tud
+    from supervised_dispnet_amd.data import RankSampler
+
+    class Range(tud.Dataset):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return torch.tensor(i)
+
+    seen = []
+    for rank in range(world):
+        s = RankSampler(n, gb, rank, world, shuffle=False, drop_last=False)
+        batches = list(tud.DataLoader(Range(), batch_sampler=s))
+        assert len(batches) == len(s)
+        assert all(b.numel() > 0 for b in batches)
+        seen += [int(v) for b in batches for v in b]
+    assert sorted(seen) == list(range(n))
+    # training sampler (drop_last=True): equal slices on every rank, tail dropped
+    lens = set()
+    for rank in range(world):
+        s = RankSampler(n, gb, rank, world, shuffle=True, seed=3, drop_last=True)
+        bs = list(s)
+        assert len(bs) == len(s) == n // gb and all(len(b) == gb // world for b in bs)
+        lens.add(len(bs))
+    assert len(lens) == 1
+
+
+def test_bench_dry_run_two_ranks_constructs_buckets_and_tears_down():
+    """bench.py --gpus 2 --dry-run under gloo on CPU tensors: arena in gradient-production order, bucketing, one all-reduce
+    cycle through the GradSink hooks the engine uses, strong-scaling shard, process-group tear-down."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--scaling", "strong"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["ok"] and d["world"] == 2 and d["buckets"] >= 3 and d["shard"] == [0, 16] and d["arena_params"] == 80

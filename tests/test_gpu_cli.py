@@ -50,3 +50,50 @@ def test_train_then_evaluate_synthetic(tmp_path):
     with torch.no_grad():
         errs, pred = test_disp.evaluate_sample(args, net, sample, dev, 1e-3, 80, KE, U)
     assert pred.shape == (64, 96) and len(errs) == 7 and all(np.isfinite(errs)) and 0 <= errs[4] <= errs[5] <= errs[6] <= 1
+
+
+def _run_train(tmp_path, extra, epochs=2, n=8, b=4):
+    import train
+    train.main(["SYN", "--synthetic", str(n), "-b", str(b), "--epochs", str(epochs), "--img-height", "64", "--img-width", "96",
+                "--lr", "1e-3", "--save-root", str(tmp_path), "--print-freq", "100"] + extra)
+    runs = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs]
+    full = [r for r in runs if r.endswith("progress_log_full.csv")][0]
+    rows = [l.split("\t") for l in open(full).read().strip().splitlines()]
+    assert len(rows) == 1 + epochs * (n // b)
+    vals = np.array([[float(v) for v in r] for r in rows[1:]])
+    assert np.isfinite(vals).all()
+    ckpt = [r for r in runs if r.endswith("dispnet_checkpoint.pth.tar")]
+    assert len(ckpt) == 1
+    return vals, torch.load(ckpt[0], map_location="cpu"), runs
+
+
+def test_train_cli_multi_l1_default_loss(tmp_path):
+    """--loss Multi_L1 is the reference's DEFAULT (train.py:34): whole-batch mask per scale, weights 1/2^i, bilinear GT pyramid."""
+    vals, sd, _ = _run_train(tmp_path, ["--network", "disp_vgg_BN", "--with-gt"], epochs=3)       # no --loss: the default
+    assert vals[:, 0].min() > 0 and np.mean(vals[-2:, 0]) < np.mean(vals[:2, 0])
+    assert np.allclose(vals[:, 0], vals[:, 1])                                                   # -p 1 -m 0 -s 0: total = loss_1
+
+
+def test_train_cli_dorn_loss(tmp_path):
+    """--network disp_vgg_BN_DORN --loss DORN (train.py:431-433,466-468): SID labels, ordinal head, ordinal loss, and the
+    validation's get_depth_sid decode (train.py:669-671)."""
+    vals, sd, _ = _run_train(tmp_path, ["--network", "disp_vgg_BN_DORN", "--loss", "DORN", "--ordinal-c", "16", "--with-gt"], epochs=3)
+    assert "conv_ord.weight" in sd["state_dict"] and tuple(sd["state_dict"]["conv_ord.weight"].shape) == (32, 16, 1, 1)
+    assert "disp0.0.weight" not in sd["state_dict"]
+    assert vals[:, 0].min() > 0 and np.mean(vals[-2:, 0]) < np.mean(vals[:2, 0])
+
+
+def test_train_cli_unsupervised_with_pose_training(tmp_path):
+    """--unsupervised --train-pose: the 5-tuple loader the reference's branch needs (train.py:418-430), PoseExpNet -> photometric
+    warp loss + explainability + smoothness (train.py:473-488), both nets in the optimizer, validate_without_gt."""
+    vals, sd, runs = _run_train(tmp_path, ["--network", "disp_vgg_BN", "--unsupervised", "--train-pose", "-m", "0.2", "-s", "0.1",
+                                           "--sequence-length", "3"], epochs=2)
+    total, photo, expl, smooth = vals.T
+    assert (photo > 0).all() and (expl > 0).all() and (smooth > 0).all()
+    assert np.allclose(total, photo + 0.2 * expl + 0.1 * smooth, rtol=1e-5)
+    pose_ckpt = [r for r in runs if r.endswith("exp_pose_checkpoint.pth.tar")]
+    assert len(pose_ckpt) == 1
+    psd = torch.load(pose_ckpt[0], map_location="cpu")["state_dict"]
+    assert "pose_pred.weight" in psd and "predict_mask1.weight" in psd                           # -m > 0 builds the mask decoder
+    summary = [r for r in runs if r.endswith("progress_log_summary.csv")][0]
+    assert len(open(summary).read().strip().splitlines()) == 3

@@ -359,3 +359,52 @@ def test_pose_exp_net(golden):
         _close(pe, g[tag + ":eval_pose"], rtol=1e-4, atol=1e-7)
         if exp:
             np.testing.assert_allclose(detgen.summarize(m1)["samples"], g[tag + ":eval_mask1_samples"], rtol=1e-4, atol=1e-6)
+
+
+def test_config3_pipeline_at_config_size(golden):
+    """BASELINE configs[2] at 2 x 128 x 416: PoseExpNet -> Disp_vgg_BN -> 1/disp -> photometric + 0.1 * smooth, both nets'
+    gradients (reference train.py:426-488, loss_functions.py:317-386)."""
+    import supervised_dispnet_amd.models as models
+    from oracle import nets_res
+    from cases import config3_inputs
+    g = golden("config3_cfg")
+    tgt, refs, k, kinv = config3_inputs()
+    _close(kinv, g["kinv"], rtol=1e-6, atol=1e-9)
+    dsd = _params(detgen.fill_state_dict(nets.disp_vgg_bn_state_dict(), "vggbn"))
+    psd = _params(_fresh_sd(models.PoseExpNet(2, False), "posenet"))
+    mask, pose = nets_res.pose_exp_net(psd, tgt, refs, False, training=True)
+    _close(pose, g["pose"], rtol=1e-4, atol=1e-7)
+    disps = nets.disp_vgg_bn(dsd, tgt, training=True)
+    depth = [1 / d for d in disps]
+    l1 = losses.photometric_reconstruction_loss(tgt, refs, k, kinv, depth, mask, pose, "euler", "zeros")
+    l3 = losses.smooth_loss(depth)
+    (l1 + 0.1 * l3).backward()
+    np.testing.assert_allclose(l1.item(), g["photo"], rtol=1e-5)
+    np.testing.assert_allclose(l3.item(), g["smooth"], rtol=1e-5)
+    for i, d in enumerate(disps):
+        _check_summary(d, g, "disp%d_" % i)
+    _grad_check(dsd, g, prefix="disp:grad:")
+    _grad_check(psd, g, prefix="pose:grad:")
+    _close(psd["pose_pred.bias"].grad, g["full:pose:grad:pose_pred.bias"], rtol=2e-4, atol=1e-7)
+
+
+def test_dorn_ordinal_c_80_at_config_size(golden):
+    """BASELINE configs[4] at 2 x 128 x 416 with ordinal_c = 80 (train.py:35): trunk -> Dropout2d (injected pattern) -> 1x1 conv
+    to 160 logits -> OrdinalRegressionLayer -> DORN_loss, and the gradients of the head."""
+    from cases import dorn80_inputs
+    g = golden("dorn80_cfg")
+    x, gt, mask = dorn80_inputs()
+    sd = _params(detgen.fill_state_dict(nets.disp_vgg_bn_state_dict(dorn_ordinal_c=80), "vggdorn80"))
+    tgt = image_ops.get_labels_sid(gt, ordinal_c=80, dataset="kitti")
+    assert int(tgt.long().sum()) == int(g["labels_sum"])
+    dec, ordc = nets.disp_vgg_bn_dorn(sd, x, training=True, dropout_mask=mask.view(-1, 16, 1, 1))
+    loss = losses.DORN_loss(gt, ordc, tgt, "kitti")
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    _check_summary(ordc, g, "ord_")
+    assert int(dec.sum()) == int(g["decode_sum"])
+    np.testing.assert_array_equal(dec.reshape(-1)[::997].numpy(), g["decode_samples"])
+    scale = float(np.abs(g["full:grad:conv_ord.weight"]).max())
+    np.testing.assert_allclose(sd["conv_ord.weight"].grad.numpy(), g["full:grad:conv_ord.weight"], rtol=2e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(sd["conv_ord.bias"].grad.numpy(), g["full:grad:conv_ord.bias"], rtol=2e-4, atol=2e-5 * float(np.abs(g["full:grad:conv_ord.bias"]).max()))
+    _grad_check(sd, g)

@@ -116,7 +116,7 @@ def save_checkpoint(save_path, dispnet_state, exp_pose_state, is_best, epoch, fi
                             os.path.join(save_path, "{}_model_best.pth.tar".format(prefix)))
 
 
-def create_disp_net(args, models, networks, device):
+def create_disp_net(args, models, networks, device, U=None):
     if args.monodepth2:
         if args.network == "disp_vgg_BN":
             enc = networks.vggEncoder(num_layers=16, pretrained=False).to(device)
@@ -125,6 +125,8 @@ def create_disp_net(args, models, networks, device):
         else:
             raise ValueError("undefined network")
         dec = networks.DepthDecoder(enc.num_ch_enc).to(device)
+        # "when monodepth2, it must load existing weight (not include adam)" -- train.py:236-237
+        U.load_model({"encoder": enc, "depth": dec}, args.pretrained_disp)
         return models.monodepth2(encoder=enc, decoder=dec)
     table = {"dispnet": "DispNetS", "disp_res": "Disp_res", "disp_res_50": "Disp_res_50", "disp_res_18": "Disp_res_18",
              "disp_vgg": "Disp_vgg_feature", "disp_vgg_BN": "Disp_vgg_BN", "FCRN": "FCRN", "res50_aspp": "res50_aspp",
@@ -253,7 +255,7 @@ def main(argv=None):
     # ---- models
     if rank == 0:
         print("=> creating model")
-    disp_net = create_disp_net(args, models, networks, device)
+    disp_net = create_disp_net(args, models, networks, device, U)
     output_exp = args.mask_loss_weight > 0
     pose_exp_net = models.PoseExpNet(nb_ref_imgs=args.sequence_length - 1, output_exp=output_exp).to(device)
     if args.pretrained_exp_pose:
@@ -271,11 +273,14 @@ def main(argv=None):
     if args.train_pose:
         hot += [p for p in pose_exp_net.parameters() if p.requires_grad]
     reducer = None
+    plain_params = None          # torch.optim path (--sgd / --diff-lr): gradients live in p.grad and are exchanged per step
     if args.diff_lr:
         groups = [{"params": disp_net.get_1x_lr_params(), "lr": args.lr}, {"params": disp_net.get_10x_lr_params(), "lr": args.lr * 10}]
         optimizer = torch.optim.SGD(groups, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     elif args.sgd:
         optimizer = torch.optim.SGD([{"params": hot, "lr": args.lr}], lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    if args.diff_lr or args.sgd:
+        plain_params = [p for g in optimizer.param_groups for p in g["params"]]
     else:
         if rank == 0:
             print("=> setting adam solver")
@@ -296,7 +301,8 @@ def main(argv=None):
         with open(os.path.join(save_path, args.log_full), "w") as f:
             csv.writer(f, delimiter="\t").writerow(["train_loss", "photo_loss", "explainability_loss", "smooth_loss"])
 
-    ctx = dict(args=args, device=device, LF=LF, U=U, reciprocal=reciprocal, rank=rank, world=world, reducer=reducer, save_path=save_path)
+    ctx = dict(args=args, device=device, LF=LF, U=U, reciprocal=reciprocal, rank=rank, world=world, reducer=reducer, save_path=save_path,
+               plain_params=plain_params)
 
     def run_validation(epoch):
         if args.with_gt:
@@ -389,6 +395,9 @@ def train(ctx, loader, disp_net, pose_exp_net, optimizer, epoch_size, n_iter):
         if reducer is not None:
             optimizer.step(grad_scale=reducer.finish())
         else:
+            if ctx["world"] > 1 and ctx["plain_params"] is not None:
+                from supervised_dispnet_amd.distributed import average_plain_grads
+                average_plain_grads(ctx["plain_params"])       # what DataParallel's reduce does for every optimizer (train.py:316)
             optimizer.step()
         lv = float(loss.item())
         losses.update(lv, args.batch_size)
