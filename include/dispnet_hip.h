@@ -347,6 +347,11 @@ int dn_channel_scale(const float* x, const float* mask, int32_t N, int64_t HW, i
  * ------------------------------------------------------------------------------------------------------------ */
 int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                  double eps, double weight_decay, int32_t step, double grad_scale, dn_stream_t stream);
+/* The same update with the step counter and the learning rate on the DEVICE (hyper = {lr, beta1, beta2}, step = int32 counter the
+ * call increments first, derived = 2 floats of scratch), so that a captured hipGraph of the training step advances the bias
+ * corrections on every replay and a scheduler changes lr by writing hyper[0]. */
+int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double eps, double weight_decay,
+                     int32_t* step, float* derived, double grad_scale, dn_stream_t stream);
 int dn_fill(float* p, float value, int64_t n, dn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -119,6 +119,7 @@ SIGNATURES = {
     "dn_sid_depth": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
     "dn_channel_scale": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i32, _d, _vp]),
+    "dn_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _d, _d, _vp, _vp, _d, _vp]),
     "dn_fill": (C.c_int, [_vp, _f, _i64, _vp]),
     "dn_ubench_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "dn_ubench_mfma_f32_flops": (_i64, [_i32, _i32]),
@@ -168,8 +169,14 @@ def check(rc, what=""):
         raise DispnetHipError("%s failed (%d): %s" % (what or "libdispnet_hip call", rc, last_error()))
 
 
+_bound = {}
+
+
 def call(name, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
-    rc = getattr(load(), name)(*args)
+    fn = _bound.get(name)
+    if fn is None:
+        fn = _bound[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
         raise DispnetHipError("%s failed (%d): %s" % (name, rc, last_error()))

@@ -686,6 +686,36 @@ __global__ void __launch_bounds__(kThreads) adam_kernel(float* __restrict__ p, c
   }
 }
 
+// Graph-replayable form: the step counter lives on the device, so a captured launch sequence advances it by itself.
+//   state[0] = step (as float bits of an int), hyper = {lr, beta1, beta2}; derived = {step_size, bc2_sqrt}
+__global__ void adam_tick_kernel(int* __restrict__ step, const float* __restrict__ hyper, float* __restrict__ derived) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int t = step[0] + 1;
+  step[0] = t;
+  const double bc1 = 1.0 - pow((double)hyper[1], (double)t);
+  const double bc2 = 1.0 - pow((double)hyper[2], (double)t);
+  derived[0] = (float)((double)hyper[0] / bc1);
+  derived[1] = (float)sqrt(bc2);
+}
+
+__global__ void __launch_bounds__(kThreads) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, long long n, const float* __restrict__ hyper, float eps,
+                                                            float weight_decay, const float* __restrict__ derived, float grad_scale) {
+  const float beta1 = hyper[1], beta2 = hyper[2], step_size = derived[0], bc2_sqrt = derived[1];
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+    float gi = g[i] * grad_scale;
+    const float pi = p[i];
+    if (weight_decay != 0.f) gi += weight_decay * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    vi = vi * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
 }  // namespace dn
 
 using namespace dn;
@@ -889,6 +919,16 @@ int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, as_stream(stream), p, g, m, v, (long long)n, (float)beta1, (float)beta2, (float)eps,
                      (float)weight_decay, step_size, bc2_sqrt, (float)grad_scale);
   return check_launch("adam_kernel");
+}
+
+int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double eps, double weight_decay,
+                     int32_t* step, float* derived, double grad_scale, dn_stream_t stream) {
+  DN_REQUIRE(p && g && m && v && n > 0 && hyper && step && derived, DN_ERR_BAD_ARG, "dn_adam_step_dev: bad argument");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, step, hyper, derived);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, s, p, g, m, v, (long long)n, hyper, (float)eps, (float)weight_decay,
+                     derived, (float)grad_scale);
+  return check_launch("adam_dev_kernel");
 }
 
 }  // extern "C"

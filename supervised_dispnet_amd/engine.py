@@ -16,6 +16,7 @@ Design notes
 import ctypes as C
 import math
 import os
+import threading
 
 import torch
 
@@ -133,8 +134,39 @@ def bump_param_epoch():
     PARAM_EPOCH += 1
 
 
+_TLS = threading.local()        # per-thread cached raw hipStream_t (forward runs on the caller's thread, backward on autograd's)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the stream the next launch goes to.  torch.cuda.current_stream() costs ~10 us of Python per call and a
+    training step makes ~300 launches, so the network-level entry points cache it for their duration (stream_scope)."""
+    h = getattr(_TLS, "handle", None)
+    return h if h is not None else torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope(object):
+    """Cache the current stream's raw handle for the launches made inside the block (re-entrant; `stream=` switches to another
+    torch stream for the block, as the side-stream weight gradients do)."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "handle", None)
+        if self.stream is not None:
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+            _TLS.handle = self.stream.cuda_stream
+        else:
+            self.ctx = None
+            _TLS.handle = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.handle = self.prev
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def _ptr(t):
@@ -367,7 +399,7 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None):
     main, side = torch.cuda.current_stream(), st["side"]
     st["main"] = main
     side.wait_stream(main)                       # dy, the operands and the bias / BatchNorm gradients of this layer are ready
-    with torch.cuda.stream(side):
+    with stream_scope(side):
         dw = launch()
     dy.record_stream(side)                       # the caching allocator must not hand these to the main stream while side reads them
     for p in pieces:

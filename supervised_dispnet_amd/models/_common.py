@@ -56,18 +56,20 @@ class HipNetFunction(torch.autograd.Function):
         tape = engine.Tape(recording)
         sink = engine.GradSink()
         in_acts = [engine.Act.from_nchw(x, needs_grad=recording and ctx.needs_input_grad[3 + i]) for i, x in enumerate(inputs)]
-        outs = net._hip_forward(tape, sink, *in_acts)         # list[Act]
+        with engine.stream_scope():
+            outs = net._hip_forward(tape, sink, *in_acts)     # list[Act]
         ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
         results = tuple(a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2) for a in outs)
         return results
 
     @staticmethod
     def backward(ctx, *grads):
-        for a, g in zip(ctx.outs, grads):
-            if g is not None:
-                engine.seed_grad(a, g)
-        ctx.tape.run_backward()
-        engine.join_side_stream()
+        with engine.stream_scope():
+            for a, g in zip(ctx.outs, grads):
+                if g is not None:
+                    engine.seed_grad(a, g)
+            ctx.tape.run_backward()
+            engine.join_side_stream()
         ig = tuple((a.grad.permute(0, 3, 1, 2) if (a.needs_grad and a.grad is not None) else None) for a in ctx.in_acts)
         pg = tuple(ctx.sink.get(p) for p in ctx.params)
         ctx.tape = ctx.outs = ctx.in_acts = None
@@ -79,7 +81,12 @@ def run_net(net, *inputs):
         engine.require_cuda(x, "input tensor")
         if x.dtype != torch.float32:
             raise TypeError("expected float32 input, got %s" % x.dtype)
-    params = [p for p in net._hot_parameters()]
-    for p in params:
-        engine.require_cuda(p, "model parameters")
+    params = getattr(net, "_dn_param_cache", None)
+    if params is None or not params[0].is_cuda:
+        # the Parameter objects are stable (.to() / load_state_dict() swap .data in place); walking named_parameters() every
+        # forward costs ~0.25 ms of a 6 ms host-side step
+        params = [p for p in net._hot_parameters()]
+        for p in params:
+            engine.require_cuda(p, "model parameters")
+        object.__setattr__(net, "_dn_param_cache", params)
     return HipNetFunction.apply(net, len(inputs), torch.is_grad_enabled(), *inputs, *params)
