@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--graph", default="0", choices=["0", "1"],
+                    help="1: replay the whole step (fwd + loss + bwd + Adam) as ONE captured hipGraph.  Off by default: measured on "
+                         "ROCm 7.2 the replay is 1-4 %% SLOWER than the eager launches at every batch size (profiles/r02_strong_1gpu.txt)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only plumbing check of the N>1 path: build the net, the arena, the buckets, one fake all-reduce cycle, tear down")
     args = ap.parse_args()
@@ -281,6 +284,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eager_step, graphed, graph_note = step, False, None
+    if args.graph == "1":
+        from supervised_dispnet_amd.graph import GraphedStep
+        for _ in range(2):
+            eager_step()                              # the arena / caches exist before the capture
+        try:
+            gs = GraphedStep(eager_step, optimizer=opt, warmup=2).capture()
+            step, graphed = gs, True
+        except Exception as e:                        # noqa: BLE001 -- the eager path is the same kernels; say why it was used
+            graph_note = "%s: %s" % (type(e).__name__, str(e)[:200])
+            opt.capturable(False)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -302,6 +317,7 @@ def main():
     # ---- instrumented steps (not part of `value`): HIP events around every conv-family launch and every HBM-bound family
     roofline = roofline_hbm = None
     step_exec_flops = step_credited_flops = None
+    step = eager_step                            # per-launch event timing needs the launches issued one by one
     if args.profile_steps > 0 and rank != 0:
         for _ in range(args.profile_steps):      # the steps carry collectives: every rank takes them, rank 0 records
             step()
@@ -370,7 +386,8 @@ def main():
             "ms_per_step_max": max(per_step_ms), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
-                       "parallelism": "dp%d" % world, "final_loss": final_loss},
+                       "parallelism": "dp%d" % world, "final_loss": final_loss,
+                       "launch": "one hipGraph replay per step" if graphed else "eager launches", "graph_fallback": graph_note},
             "step_tflops_credited_per_gpu": (step_credited_flops / sec_step / 1e12) if step_credited_flops else None,
             "step_credited_frac": (step_credited_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_credited_flops else None,
             "step_executed_frac": (step_exec_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_exec_flops else None,

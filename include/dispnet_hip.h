@@ -41,6 +41,7 @@ enum dn_status {
   DN_ERR_LAUNCH = -4
 };
 
+void dn_reload_knobs(void);          /* re-read the DN_* tuning / test switches (they are read once, at first use) */
 int dn_version(void);                 /* ABI version, bumped on any signature/struct change */
 const char* dn_last_error(void);      /* thread-local, valid until the next failing call on this thread */
 const char* dn_last_kernel(void);     /* thread-local: name (as rocprofv3 prints it) of the main kernel the last conv-family call launched */
@@ -155,7 +156,8 @@ int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count,
 int dn_bn_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, dn_stream_t stream);
 /* p = maxpool2x2(relu(y*scale+shift));  idx (uint8, one per output element): bits0-1 = argmax position in the
- * window (first max in row-major order, like ATen), bit2 = pooled value > 0. */
+ * window (first max in row-major order, like ATen), bit2 = pooled value > 0.  scale == shift == NULL: y is a plain tensor
+ * (already activated), p = maxpool2x2(y) -- the BatchNorm-free VGG encoders (reference models/Disp_vgg.py:79-100). */
 int dn_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, int32_t N, int32_t H, int32_t W,
                         int32_t C, float* pooled, uint8_t* idx, dn_stream_t stream);
 /* dz (full resolution, pre-ReLU gradient; zero where not routed) from dpooled, plus per-channel partial sums
@@ -163,6 +165,9 @@ int dn_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, 
 int dn_bn_relu_pool_bwd(const float* dpooled, const uint8_t* idx, const float* y, const float* mean,
                         const float* invstd, int32_t N, int32_t H, int32_t W, int32_t C, float* dz, float* partial,
                         dn_stream_t stream);
+/* gradient of the plain 2x2 max-pool (dn_bn_relu_pool_fwd with NULL scale): dx[window arg-max] (+)= dpooled, 0 elsewhere. */
+int dn_maxpool2_bwd(const float* dpooled, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, int32_t accumulate,
+                    dn_stream_t stream);
 /* dz = da * (y*scale+shift > 0) in place on `da`, plus the same partial sums. */
 int dn_bn_relu_bwd_reduce(float* da_dz, const float* y, const float* scale, const float* shift, const float* mean,
                           const float* invstd, int64_t rows, int32_t C, float* partial, dn_stream_t stream);
@@ -347,10 +352,10 @@ int dn_channel_scale(const float* x, const float* mask, int32_t N, int64_t HW, i
  * ------------------------------------------------------------------------------------------------------------ */
 int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                  double eps, double weight_decay, int32_t step, double grad_scale, dn_stream_t stream);
-/* The same update with the step counter and the learning rate on the DEVICE (hyper = {lr, beta1, beta2}, step = int32 counter the
- * call increments first, derived = 2 floats of scratch), so that a captured hipGraph of the training step advances the bias
- * corrections on every replay and a scheduler changes lr by writing hyper[0]. */
-int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double eps, double weight_decay,
+/* The same update with the step counter and the learning rate on the DEVICE (hyper = {lr, beta1, beta2} as doubles, step = int32
+ * counter the call increments first, derived = 4 floats of scratch), so that a captured hipGraph of the training step advances
+ * the bias corrections on every replay and a scheduler changes lr by writing hyper[0]. */
+int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* hyper, double eps, double weight_decay,
                      int32_t* step, float* derived, double grad_scale, dn_stream_t stream);
 int dn_fill(float* p, float value, int64_t n, dn_stream_t stream);
 

@@ -45,6 +45,7 @@ _i32, _i64, _f, _d, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_
 # name -> (restype, argtypes); every symbol include/dispnet_hip.h declares (checked by tests/test_abi.py)
 SIGNATURES = {
     "dn_version": (C.c_int, []),
+    "dn_reload_knobs": (None, []),
     "dn_last_error": (C.c_char_p, []),
     "dn_last_kernel": (C.c_char_p, []),
     "dn_device_arch_ok": (C.c_int, []),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "dn_bn_finalize": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "dn_bn_eval_affine": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "dn_bn_relu_pool_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_maxpool2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "dn_bn_relu_pool_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_bn_relu_bwd_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "dn_bn_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp]),

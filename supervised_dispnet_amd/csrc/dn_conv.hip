@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
 }
 
 static bool stem_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  if (getenv("DN_NO_STEM")) return false;
+  if (knobs().no_stem) return false;
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
   if (p.n_in != 1 || p.n_out != 1 || p.Ntot != 64 || p.nphases != 1) return false;
   const KOperand& o = p.in[0];
@@ -1494,7 +1494,7 @@ static int enable_big_lds(K kernel, size_t bytes) {
 template <int BM, int BN, int WM, int WN, bool ALLVEC>
 static int launch_conv_v(const IgemmParams& p, hipStream_t stream) {
   size_t lds = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (kMaxTaps + BM) * sizeof(int);
-  if (const char* e = getenv("DN_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(e);   // tuning aid: lowers blocks per CU
+  lds += (size_t)knobs().extra_lds;   // tuning aid: lowers blocks per CU
   auto kernel = igemm_conv_kernel<BM, BN, WM, WN, ALLVEC>;
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
@@ -1519,7 +1519,7 @@ static int launch_conv_u32(const IgemmParams& p, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const IgemmParams& p, hipStream_t stream) {
-  if (p.uni32 && !getenv("DN_NO_U32"))
+  if (p.uni32 && !knobs().no_u32)
     return launch_conv_u32<BM, BN, WM, WN>(p, stream);
   return p.allvec ? launch_conv_v<BM, BN, WM, WN, true>(p, stream) : launch_conv_v<BM, BN, WM, WN, false>(p, stream);
 }
@@ -1537,7 +1537,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
                "result %d must be pixel-dense (NHWC with a channel stride)", i);
   }
   hipStream_t s = as_stream(stream);
-  if (!getenv("DN_NO_DIRECT")) {
+  if (!knobs().no_direct) {
     if (head_fwd_eligible(d, p)) return launch_head_fwd(p, s);
     if (head_dgrad_eligible(d, p)) return launch_head_dgrad(p, s);
   }
@@ -1548,7 +1548,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
   // 64-row tiles double the block count at the same per-wave MFMA density along N.  Not with batch statistics: the
   // bn_partial layout is per 128-row tile.
   const long long blocks128 = (long long)((p.M + 127) / 128) * (p.Npad / p.BN) * p.nphases;
-  const bool small_m = p.uni32 && p.bn_partial == nullptr && blocks128 <= 208 && !getenv("DN_NO_BM64");
+  const bool small_m = p.uni32 && p.bn_partial == nullptr && blocks128 <= 208 && !knobs().no_bm64;
   switch (p.BN) {
     case 128: return small_m ? launch_conv_u32<64, 128, 32, 64>(p, s) : launch_conv<128, 128, 64, 64>(p, s);
     case 64: return small_m ? launch_conv_u32<64, 64, 32, 32>(p, s) : launch_conv<128, 64, 64, 32>(p, s);
@@ -1583,7 +1583,7 @@ static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
 
 template <int BNW, int WNn, int WKk>
 static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
-  if (p.wg_uniform && !getenv("DN_NO_U32"))
+  if (p.wg_uniform && !knobs().no_u32)
     return p.any_affine ? launch_wgrad_u32<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_u32<BNW, WNn, WKk, false>(p, stream);
   return p.allvec ? launch_wgrad_v<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_v<BNW, WNn, WKk, false>(p, stream);
 }
@@ -1660,7 +1660,7 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
   int rc = build_plan(fwd, true, &p);
   if (rc != DN_OK) return rc;
   DN_REQUIRE(dy != nullptr && dw != nullptr && workspace != nullptr, DN_ERR_BAD_ARG, "null pointer");
-  if (head_wgrad_eligible(fwd, p) && workspace_bytes >= head_wgrad_workspace_bytes(p) && !getenv("DN_NO_DIRECT")) {
+  if (head_wgrad_eligible(fwd, p) && workspace_bytes >= head_wgrad_workspace_bytes(p) && !knobs().no_direct) {
     DN_REQUIRE(p.in[0].p != nullptr, DN_ERR_BAD_ARG, "operand 0 has no data");
     p.g = dy;
     return launch_head_wgrad(p, dw, reinterpret_cast<float*>(workspace), as_stream(stream));

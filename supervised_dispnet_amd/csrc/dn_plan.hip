@@ -4,6 +4,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "dn_internal.h"
 
 namespace dn {
@@ -68,6 +71,43 @@ static bool offsets_fit_int32(const KOperand& k, int N, int IH, int IW) {
   const long long span = (long long)N * (k.sn < 0 ? -k.sn : k.sn) + hs * (k.sh < 0 ? -k.sh : k.sh) +
                          ws * (k.sw < 0 ? -k.sw : k.sw) + (long long)k.C * (k.sc < 0 ? -k.sc : k.sc);
   return span < (1ll << 31);
+}
+
+// ------------------------------------------------------------------------------------------------------ knobs
+static Knobs g_knobs;
+static std::atomic<int> g_knobs_state{0};      // 0 = unread, 1 = valid
+static std::mutex g_knobs_mu;
+
+static void read_knobs(Knobs* k) {
+  auto on = [](const char* n) { return getenv(n) != nullptr; };
+  auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+  k->no_winograd = on("DN_NO_WINOGRAD");
+  k->no_winograd_wgrad = on("DN_NO_WINOGRAD_WGRAD");
+  k->no_direct = on("DN_NO_DIRECT");
+  k->no_stem = on("DN_NO_STEM");
+  k->no_u32 = on("DN_NO_U32");
+  k->no_bm64 = on("DN_NO_BM64");
+  k->no_thin = on("DN_NO_THIN");
+  k->no_thin_conv = on("DN_NO_THIN_CONV");
+  k->no_tile_store = on("DN_NO_TILE_STORE");
+  k->no_splitk = on("DN_NO_SPLITK");
+  k->extra_lds = num("DN_DEBUG_EXTRA_LDS", 0);
+  k->wino_dbg = num("DN_WINO_DBG", 0);
+  k->wino_mtw = num("DN_WINO_MTW", 1);
+  k->wino_wg_dbg = num("DN_WINO_WG_DBG", 0);
+  k->wino_dbgptr = getenv("DN_WINO_DBGPTR") ? strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0) : 0ull;
+  k->wino_min_tiles = num("DN_WINO_MIN_TILES", 192);
+}
+
+const Knobs& knobs() {
+  if (g_knobs_state.load(std::memory_order_acquire) == 0) {
+    std::lock_guard<std::mutex> lock(g_knobs_mu);
+    if (g_knobs_state.load(std::memory_order_relaxed) == 0) {
+      read_knobs(&g_knobs);
+      g_knobs_state.store(1, std::memory_order_release);
+    }
+  }
+  return g_knobs;
 }
 
 int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
@@ -269,7 +309,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     if (!o.small || (!o.vec && o.scale != nullptr) || o.C >= 32768) p->wg_uniform = 0;
   }
   (void)n_uniform;
-  p->tile_store = getenv("DN_NO_TILE_STORE") ? 0 : 1;
+  p->tile_store = knobs().no_tile_store ? 0 : 1;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;
@@ -287,7 +327,13 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 3; }
+int dn_version(void) { return 4; }
+
+void dn_reload_knobs(void) {
+  std::lock_guard<std::mutex> lock(dn::g_knobs_mu);
+  dn::read_knobs(&dn::g_knobs);
+  dn::g_knobs_state.store(1, std::memory_order_release);
+}
 
 const char* dn_last_error(void) { return dn::g_err; }
 

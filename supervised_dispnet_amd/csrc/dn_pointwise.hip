@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(kThreads) bn_relu_pool_fwd_kernel(const float*
     pix /= PW;
     const int py = (int)(pix % PH), n = (int)(pix / PH);
     const int c = g * 4;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    // scale == nullptr: y is a plain (already activated) tensor -- nn.MaxPool2d(2, 2) after conv + ReLU (models/Disp_vgg.py:79-100)
+    const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sh = scale ? *reinterpret_cast<const f32x4*>(shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float* base = y + (((long long)n * H + 2 * py) * W + 2 * px) * C + c;
     f32x4 best;
     int bi[4];
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(kThreads) bn_relu_pool_fwd_kernel(const float*
       const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((long long)(q >> 1) * W + (q & 1)) * C);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float a = fmaxf(0.f, v[e] * sc[e] + sh[e]);
+        const float a = scale ? fmaxf(0.f, v[e] * sc[e] + sh[e]) : v[e];
         if (q == 0 || a > best[e]) {
           best[e] = a;
           bi[e] = q;
@@ -212,6 +214,33 @@ __global__ void __launch_bounds__(kThreads) bn_relu_pool_fwd_kernel(const float*
     code.z = (uint8_t)(bi[2] | (best[2] > 0.f ? 4 : 0));
     code.w = (uint8_t)(bi[3] | (best[3] > 0.f ? 4 : 0));
     *reinterpret_cast<uchar4*>(idx + o) = code;
+  }
+}
+
+// gradient of the plain 2x2 max-pool: every input pixel of a window gets the window's gradient if it was the arg-max, else 0
+__global__ void __launch_bounds__(kThreads) maxpool2_bwd_kernel(const float* __restrict__ dpooled, const uint8_t* __restrict__ idx, int N, int H,
+                                                                int W, int C, float* __restrict__ dx, int accumulate) {
+  const int PH = H / 2, PW = W / 2, G = C / 4;
+  const long long total = (long long)N * PH * PW * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int g = (int)(i % G);
+    long long pix = i / G;
+    const int px = (int)(pix % PW);
+    pix /= PW;
+    const int py = (int)(pix % PH), n = (int)(pix / PH);
+    const uchar4 code = *reinterpret_cast<const uchar4*>(idx + i * 4);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(dpooled + i * 4);
+    float* base = dx + (((long long)n * H + 2 * py) * W + 2 * px) * C + g * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float* dst = base + ((long long)(q >> 1) * W + (q & 1)) * C;
+      f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((code.x & 3) == q) o[0] += gv[0];
+      if ((code.y & 3) == q) o[1] += gv[1];
+      if ((code.z & 3) == q) o[2] += gv[2];
+      if ((code.w & 3) == q) o[3] += gv[3];
+      *reinterpret_cast<f32x4*>(dst) = o;
+    }
   }
 }
 
@@ -687,21 +716,23 @@ __global__ void __launch_bounds__(kThreads) adam_kernel(float* __restrict__ p, c
 }
 
 // Graph-replayable form: the step counter lives on the device, so a captured launch sequence advances it by itself.
-//   state[0] = step (as float bits of an int), hyper = {lr, beta1, beta2}; derived = {step_size, bc2_sqrt}
-__global__ void adam_tick_kernel(int* __restrict__ step, const float* __restrict__ hyper, float* __restrict__ derived) {
+//   hyper = {lr, beta1, beta2} in double (what the host form receives); derived = {step_size, bc2_sqrt, beta1, beta2} in float
+__global__ void adam_tick_kernel(int* __restrict__ step, const double* __restrict__ hyper, float* __restrict__ derived) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int t = step[0] + 1;
   step[0] = t;
-  const double bc1 = 1.0 - pow((double)hyper[1], (double)t);
-  const double bc2 = 1.0 - pow((double)hyper[2], (double)t);
-  derived[0] = (float)((double)hyper[0] / bc1);
+  const double bc1 = 1.0 - pow(hyper[1], (double)t);
+  const double bc2 = 1.0 - pow(hyper[2], (double)t);
+  derived[0] = (float)(hyper[0] / bc1);
   derived[1] = (float)sqrt(bc2);
+  derived[2] = (float)hyper[1];
+  derived[3] = (float)hyper[2];
 }
 
 __global__ void __launch_bounds__(kThreads) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                            float* __restrict__ v, long long n, const float* __restrict__ hyper, float eps,
+                                                            float* __restrict__ v, long long n, float eps,
                                                             float weight_decay, const float* __restrict__ derived, float grad_scale) {
-  const float beta1 = hyper[1], beta2 = hyper[2], step_size = derived[0], bc2_sqrt = derived[1];
+  const float beta1 = derived[2], beta2 = derived[3], step_size = derived[0], bc2_sqrt = derived[1];
   for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
     float gi = g[i] * grad_scale;
     const float pi = p[i];
@@ -744,12 +775,21 @@ int dn_bn_eval_affine(int32_t C, const float* gamma, const float* beta, const fl
 
 int dn_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, int32_t N, int32_t H, int32_t W, int32_t C, float* pooled,
                         uint8_t* idx, dn_stream_t stream) {
-  DN_REQUIRE(y && scale && shift && pooled && idx, DN_ERR_BAD_ARG, "dn_bn_relu_pool_fwd: null pointer");
+  DN_REQUIRE(y && pooled && idx && ((scale == nullptr) == (shift == nullptr)), DN_ERR_BAD_ARG, "dn_bn_relu_pool_fwd: null pointer");
   DN_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && N > 0, DN_ERR_UNSUPPORTED, "dn_bn_relu_pool_fwd: need C%%4==0 and even H,W");
   const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, as_stream(stream), y, scale, shift, N, H, W, C,
                      pooled, idx);
   return check_launch("bn_relu_pool_fwd_kernel");
+}
+
+int dn_maxpool2_bwd(const float* dpooled, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, int32_t accumulate,
+                    dn_stream_t stream) {
+  DN_REQUIRE(dpooled && idx && dx && N > 0, DN_ERR_BAD_ARG, "dn_maxpool2_bwd: bad argument");
+  DN_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool2_bwd: need C%%4==0 and even H,W");
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, as_stream(stream), dpooled, idx, N, H, W, C, dx, accumulate);
+  return check_launch("maxpool2_bwd_kernel");
 }
 
 int dn_bn_relu_pool_bwd(const float* dpooled, const uint8_t* idx, const float* y, const float* mean, const float* invstd, int32_t N,
@@ -921,12 +961,12 @@ int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
   return check_launch("adam_kernel");
 }
 
-int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double eps, double weight_decay,
+int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* hyper, double eps, double weight_decay,
                      int32_t* step, float* derived, double grad_scale, dn_stream_t stream) {
   DN_REQUIRE(p && g && m && v && n > 0 && hyper && step && derived, DN_ERR_BAD_ARG, "dn_adam_step_dev: bad argument");
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, step, hyper, derived);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, s, p, g, m, v, (long long)n, hyper, (float)eps, (float)weight_decay,
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, s, p, g, m, v, (long long)n, (float)eps, (float)weight_decay,
                      derived, (float)grad_scale);
   return check_launch("adam_dev_kernel");
 }

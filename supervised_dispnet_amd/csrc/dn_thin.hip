@@ -72,7 +72,7 @@ static bool thin_shape(const IgemmParams& p, int* ntc, int* nkt) {
 }
 
 bool thin_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  if (getenv("DN_NO_THIN")) return false;
+  if (knobs().no_thin) return false;
   if (d->kind != DN_CONV_FWD) return false;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OW & 3)) return false;
@@ -293,7 +293,7 @@ static size_t thin_conv_lds(const IgemmParams& p, int NT) {
 }
 
 bool thin_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  if (getenv("DN_NO_THIN") || getenv("DN_NO_THIN_CONV")) return false;
+  if (knobs().no_thin || knobs().no_thin_conv) return false;
   // measured: with 32 output channels / 256-long contractions the tiled kernel wins (0.096 vs 0.132 ms, 0.094 vs 0.164); the
   // 16-channel layers are where padding to a 32-wide tile hurts (0.31 -> 0.15 ms, 0.23 -> 0.16)
   if (p.reflect || p.bn_partial != nullptr || p.Ntot > 16) return false;

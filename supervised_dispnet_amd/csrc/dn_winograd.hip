@@ -58,11 +58,11 @@ __device__ __forceinline__ float wino_act(float v, int act, float p0, float p1) 
 
 // ------------------------------------------------------------------------------------------------ eligibility
 bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  if (getenv("DN_NO_WINOGRAD")) return false;
+  if (knobs().no_winograd) return false;
   if (!(d->kind == DN_CONV_FWD || d->kind == DN_CONV_DGRAD)) return false;
   // the one-channel disparity heads have their own kernels, dispatched before this one (dn_conv.hip::run_conv); the packed
   // weight layout must follow the same decision (a head's input gradient has a 1-channel operand and would qualify below)
-  if (!getenv("DN_NO_DIRECT") && (head_fwd_eligible(d, p) || head_dgrad_eligible(d, p))) return false;
+  if (!knobs().no_direct && (head_fwd_eligible(d, p) || head_dgrad_eligible(d, p))) return false;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
   if (p.nphases != 1 || p.ph[0].ntaps != 9) return false;
@@ -73,10 +73,11 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
     // when padding eats the 2.25x, e.g. the 12-tile deep layers of a 64x96 test image
     const long long T = p.M / 4, Tpad = (T + 31) / 32 * 32, Npad = (p.Ntot + WBN - 1) / WBN * WBN;
     if (T * p.Ntot * 10 < Tpad * Npad * 6) return false;
-    // Few tiles: nothing to win (a handful of blocks on 256 CUs), and F(2x2,3x3) rounds 2-3x coarser than the direct FMA chain
-    // (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64), which the BatchNorm of a tiny map (batch statistics over a few
-    // dozen values) amplifies.  Such maps keep the direct kernel.
-    if (T < 256) return false;
+    // Few tiles: F(2x2,3x3) rounds 2-3x coarser than the direct FMA chain (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64),
+    // which the BatchNorm of a tiny map (batch statistics over a few dozen values) amplifies: such maps keep the direct kernel.
+    // The floor is 192 tiles so that the 8x26 levels of a 4-image shard (208 tiles: BASELINE's b32 split over 8 GPUs) stay on
+    // this path -- 56 blocks that each do 2.25x less work beat the direct kernel's 28 (0.32 -> 0.1 ms per layer).
+    if (T < knobs().wino_min_tiles) return false;
   }
   for (int i = 0; i < p.n_in; ++i) {
     const KOperand& o = p.in[i];
@@ -635,12 +636,9 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.TW = p.OW / 2;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
-  const char* dbg_env = getenv("DN_WINO_DBG");
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  const char* mtw_env = getenv("DN_WINO_MTW");
-  const int mtw = mtw_env ? atoi(mtw_env) : 1;
+  const int dbg = knobs().wino_dbg, mtw = knobs().wino_mtw;
   if (dbg == 4) {
-    p.ws = reinterpret_cast<float*>(strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0));
+    p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
     if (mtw == 1) return p.any_affine ? launch_wino_variant<1, true, 4>(p, stream) : launch_wino_variant<1, false, 4>(p, stream);
     return p.any_affine ? launch_wino_variant<2, true, 4>(p, stream) : launch_wino_variant<2, false, 4>(p, stream);
   }

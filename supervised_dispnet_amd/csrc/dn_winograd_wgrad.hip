@@ -50,7 +50,7 @@ __device__ __forceinline__ f32x4 wg_buffer_load(__amdgpu_buffer_rsrc_t r, int vo
 }
 
 bool wino_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  if (getenv("DN_NO_WINOGRAD") || getenv("DN_NO_WINOGRAD_WGRAD")) return false;
+  if (knobs().no_winograd || knobs().no_winograd_wgrad) return false;
   if (d->kind != DN_CONV_FWD) return false;
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
@@ -441,8 +441,7 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   p.OW = p.GW;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
-  const char* dbg_env = getenv("DN_WINO_WG_DBG");
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  const int dbg = knobs().wino_wg_dbg;
   auto kernel = p.any_affine ? wino_wgrad_kernel<true, 0> : wino_wgrad_kernel<false, 0>;
   switch (dbg) {
     case 2: kernel = wino_wgrad_kernel<true, 2>; break;

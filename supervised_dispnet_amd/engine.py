@@ -35,6 +35,9 @@ PARAM_EPOCH = 0
 # for every implicit-GEMM launch, bracketed with HIP events on the launch stream.  None = off (zero overhead).
 PROFILE = None
 
+# True while graph.GraphedStep records a step into a hipGraph (nothing in the engine may synchronise or time launches then)
+CAPTURING = False
+
 
 # Weight gradients on a side HIP stream (DN_WGRAD_STREAM=auto|1|0; auto = on in a single-process run, off under
 # torch.distributed with more than one rank until the RCCL interplay has been measured on a multi-GPU node -- the 2-rank gloo
@@ -789,6 +792,34 @@ def block_maxpool3s2(tape, x):
         if first:
             x.grad = x.new_like()
         _lib.call("dn_maxpool3s2_bwd", out.grad.data_ptr(), idx.data_ptr(), x.N, x.H, x.W, x.C, x.grad.data_ptr(), 0 if first else 1, _stream())
+        out.grad = None
+
+    tape.push(backward)
+    return out
+
+
+def block_maxpool2(tape, x):
+    """nn.MaxPool2d(2, 2) on a plain (already activated) tensor -- the BatchNorm-free VGG encoders (models/Disp_vgg.py:79-100,
+    Disp_vgg_feature.py:138-142).  Odd extents drop their last row / column like ATen (floor)."""
+    if x.scale is not None:
+        raise RuntimeError("block_maxpool2 expects a plain activation (block_pool handles the pending-BatchNorm case)")
+    if (x.H | x.W) & 1:
+        raise NotImplementedError("2x2 max-pool of an odd-sized map (%dx%d)" % (x.H, x.W))
+    dev = x.t.device
+    o_t = torch.empty((x.N, x.H // 2, x.W // 2, x.C), dtype=torch.float32, device=dev)
+    idx = torch.empty((x.N, x.H // 2, x.W // 2, x.C), dtype=torch.uint8, device=dev)
+    hbm_call("dn::bn_relu_pool_fwd_kernel", x.rows * x.C * 4 * 1.25 + x.rows * x.C // 4, "dn_bn_relu_pool_fwd", x.t.data_ptr(), None, None,
+             x.N, x.H, x.W, x.C, o_t.data_ptr(), idx.data_ptr(), _stream())
+    out = Act(o_t, x.N, x.H // 2, x.W // 2, x.C)
+
+    def backward():
+        if out.grad is None or not x.needs_grad:
+            return
+        first = x.grad is None
+        if first:
+            x.grad = x.new_like()
+        hbm_call("dn::maxpool2_bwd_kernel", x.rows * x.C * 4 * 1.25 + x.rows * x.C // 4, "dn_maxpool2_bwd", out.grad.data_ptr(), idx.data_ptr(),
+                 x.N, x.H, x.W, x.C, x.grad.data_ptr(), 0 if first else 1, _stream())
         out.grad = None
 
     tape.push(backward)

@@ -109,6 +109,10 @@ def residual_block_params_backward_order(blk):
 
 
 class Disp_res_50(nn.Module):
+    # what Disp_res_18 (reference models/Disp_res_18.py:50-135: BasicBlock, expansion written out as 1) changes
+    _block, _expansion, _counts = Bottleneck, 4, (3, 4, 6, 3)
+    _pretrained_url = 'https://download.pytorch.org/models/resnet50-19c8e357.pth'
+
     def __init__(self, datasets='kitti'):
         super(Disp_res_50, self).__init__()
         if datasets == 'kitti':
@@ -124,19 +128,20 @@ class Disp_res_50(nn.Module):
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.pool1 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
-        self.layer1 = self.resblock(conv_planes[1], 3)
-        self.layer2 = self.resblock(conv_planes[2], 4, stride=2)
-        self.layer3 = self.resblock(conv_planes[3], 6, stride=2)
-        self.layer4 = self.resblock(conv_planes[4], 3, stride=2)
+        ex, cnt = self._expansion, self._counts
+        self.layer1 = self.resblock(conv_planes[1], cnt[0])
+        self.layer2 = self.resblock(conv_planes[2], cnt[1], stride=2)
+        self.layer3 = self.resblock(conv_planes[3], cnt[2], stride=2)
+        self.layer4 = self.resblock(conv_planes[4], cnt[3], stride=2)
         upconv_planes = [512, 256, 128, 64, 32, 16]
-        self.upconv5 = upconv(conv_planes[4] * 4, upconv_planes[1])
+        self.upconv5 = upconv(conv_planes[4] * ex, upconv_planes[1])
         self.upconv4 = upconv(upconv_planes[1], upconv_planes[2])
         self.upconv3 = upconv(upconv_planes[2], upconv_planes[3])
         self.upconv2 = upconv(upconv_planes[3], upconv_planes[4])
         self.upconv1 = upconv(upconv_planes[4], upconv_planes[5])
-        self.iconv5 = conv(upconv_planes[1] + conv_planes[3] * 4, upconv_planes[1])
-        self.iconv4 = conv(upconv_planes[2] + conv_planes[2] * 4, upconv_planes[2])
-        self.iconv3 = conv(1 + upconv_planes[3] + conv_planes[1] * 4, upconv_planes[3])
+        self.iconv5 = conv(upconv_planes[1] + conv_planes[3] * ex, upconv_planes[1])
+        self.iconv4 = conv(upconv_planes[2] + conv_planes[2] * ex, upconv_planes[2])
+        self.iconv3 = conv(1 + upconv_planes[3] + conv_planes[1] * ex, upconv_planes[3])
         self.iconv2 = conv(1 + upconv_planes[4] + conv_planes[0], upconv_planes[4])
         self.iconv1 = conv(1 + upconv_planes[5], upconv_planes[5])
         self.predict_disp4 = predict_disp(upconv_planes[2])
@@ -146,13 +151,13 @@ class Disp_res_50(nn.Module):
         self._rt = None
 
     def resblock(self, planes, num_blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * 4:
-            downsample = nn.Sequential(conv1x1(self.inplanes, planes * 4, stride), nn.BatchNorm2d(planes * 4))
-        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * 4
+        downsample, ex = None, self._expansion
+        if stride != 1 or self.inplanes != planes * ex:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * ex, stride), nn.BatchNorm2d(planes * ex))
+        layers = [self._block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * ex
         for _ in range(1, num_blocks):
-            layers.append(Bottleneck(self.inplanes, planes))
+            layers.append(self._block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
     def init_weights(self, use_pretrained_weights=False):
@@ -160,7 +165,7 @@ class Disp_res_50(nn.Module):
         if use_pretrained_weights:
             import torch.utils.model_zoo as model_zoo
             print("loading pretrained weights downloaded from pytorch.org")
-            self.load_res_params(model_zoo.load_url('https://download.pytorch.org/models/resnet50-19c8e357.pth'))
+            self.load_res_params(model_zoo.load_url(self._pretrained_url))
         else:
             print("do not load pretrained weights for the monocular model")
 

@@ -1,12 +1,18 @@
 """Mirror of the reference's `models` package for the hot path (reference models/__init__.py:1-15).
 
-In-scope nets are real; the reference's other exports are out of scope for this build and raise a
-clear error rather than silently running something else.
+In-scope nets are real; the reference's remaining exports (FCRN, the ASPP / DORN
+backbones: up-projection blocks and dilated convolutions outside the op vocabulary of section 8) raise a clear error rather than
+silently running something else.
 """
 from .DispNetS import DispNetS
 from .Disp_vgg_BN import Disp_vgg_BN
 from .Disp_vgg_BN_DORN import Disp_vgg_BN_DORN
 from .Disp_res_50 import Disp_res_50
+from .Disp_res_18 import Disp_res_18
+from .Disp_res import Disp_res
+from .Disp_res_101 import Disp_res_101
+from .Disp_vgg import Disp_vgg
+from .Disp_vgg_feature import Disp_vgg_feature
 from .PoseExpNet import PoseExpNet
 from .monodepth2 import monodepth2
 

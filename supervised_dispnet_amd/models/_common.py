@@ -31,6 +31,26 @@ class VGG16BNContainer(nn.Module):
                                             nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 1000))
 
 
+class VGG16Container(nn.Module):
+    """torchvision.models.vgg16() layout (cfg "D", no BatchNorm): `.features` indices 0..30, `.avgpool`, `.classifier` -- what
+    models/Disp_vgg_feature.py:85 holds as `self.features` (state_dict keys `features.features.N.*`, `features.classifier.N.*`)."""
+
+    def __init__(self, with_classifier=True):
+        super().__init__()
+        layers, c = [], 3
+        for v in VGG16_CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                c = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        if with_classifier:
+            self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(),
+                                            nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 1000))
+
+
 def xavier_init_like_reference(module):
     """init_weights() of the reference nets: xavier_uniform_ on every Conv2d / ConvTranspose2d / Linear weight, zero
     bias; the BatchNorm branch is unreachable there (models/Disp_vgg_BN.py:116-120) so BN keeps gamma=1, beta=0."""

@@ -54,6 +54,27 @@ class FusedAdam(object):
         self.exp_avg_sq = torch.zeros_like(self.arena.flat_p)
         self.param_groups = [{"params": self.arena.params, "lr": self.lr, "betas": self.betas, "eps": self.eps,
                               "weight_decay": self.weight_decay}]
+        self._dev = None          # capturable(): device-resident step counter / hyper-parameters for hipGraph replay
+
+    def capturable(self, on=True):
+        """Keep the step counter and (lr, beta1, beta2) on the DEVICE (dn_adam_step_dev) so that a captured hipGraph of the
+        training step advances the bias corrections on every replay; a scheduler changes lr through set_lr()."""
+        if on and self._dev is None:
+            dev = self.arena.flat_p.device
+            g = self.param_groups[0]
+            self._dev = {"hyper": torch.tensor([float(g["lr"]), self.betas[0], self.betas[1]], dtype=torch.float64, device=dev),
+                         "step": torch.tensor([self.step_count], dtype=torch.int32, device=dev),
+                         "derived": torch.zeros(4, dtype=torch.float32, device=dev), "lr": float(g["lr"])}
+        elif not on and self._dev is not None:
+            self.step_count = int(self._dev["step"].item())
+            self._dev = None
+        return self
+
+    def set_lr(self, lr):
+        self.param_groups[0]["lr"] = float(lr)
+        if self._dev is not None and self._dev["lr"] != float(lr):
+            self._dev["hyper"][0:1].fill_(float(lr))
+            self._dev["lr"] = float(lr)
 
     @property
     def params(self):
@@ -70,16 +91,29 @@ class FusedAdam(object):
         a.gather_stray_grads()
         self.step_count += 1
         g = self.param_groups[0]
+        if self._dev is not None:
+            d = self._dev
+            if d["lr"] != float(g["lr"]):
+                self.set_lr(g["lr"])
+            engine.hbm_call("dn::adam_dev_kernel", a.numel * 28, "dn_adam_step_dev", a.flat_p.data_ptr(), a.flat_g.data_ptr(),
+                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), a.numel, d["hyper"].data_ptr(), self.eps,
+                            self.weight_decay, d["step"].data_ptr(), d["derived"].data_ptr(), float(grad_scale), engine._stream())
+            engine.bump_param_epoch()
+            return
         engine.hbm_call("dn::adam_kernel", a.numel * 28, "dn_adam_step", a.flat_p.data_ptr(), a.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                   self.exp_avg_sq.data_ptr(), a.numel, float(g["lr"]), self.betas[0], self.betas[1], self.eps,
                   self.weight_decay, self.step_count, float(grad_scale), engine._stream())
         engine.bump_param_epoch()
 
     def state_dict(self):
+        if self._dev is not None:
+            self.step_count = int(self._dev["step"].item())
         return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
+        if self._dev is not None:
+            self._dev["step"].fill_(self.step_count)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -19,3 +19,18 @@ def dorn80_inputs(b=2, h=128, w=416):
     gt = detgen.sparse_depth(b, h, w, "dorn80:gt", density=0.05)
     mask = detgen.bernoulli((b, 16), "dorn80:drop", 0.5).float() * 2.0
     return x, gt, mask
+
+
+# the rest of the DispNet zoo.  tag (tests/golden/zoo.npz prefix), product class, constructor kwargs, dataset of the loss,
+# oracle call (oracle/nets_zoo.py)
+def zoo_cases():
+    from oracle import nets_zoo as Z
+    return [
+        ("res18", "Disp_res_18", {"datasets": "nyu"}, "nyu", lambda sd, x, tr: Z.disp_res_18(sd, x, training=tr, datasets="nyu")),
+        ("res6", "Disp_res", {"datasets": "kitti"}, "kitti", lambda sd, x, tr: Z.disp_res6(sd, x, training=tr, datasets="kitti")),
+        ("res101", "Disp_res_101", {"datasets": "kitti"}, "kitti",
+         lambda sd, x, tr: Z.disp_res6(sd, x, training=tr, datasets="kitti", layer3_blocks=23, leaky=False)),
+        ("vgg", "Disp_vgg", {"alpha": 10, "beta": 0.01}, "kitti", lambda sd, x, tr: Z.disp_vgg(sd, x, training=tr, alpha=10, beta=0.01)),
+        ("vggfeat", "Disp_vgg_feature", {"datasets": "nyu", "with_classifier": False}, "nyu",
+         lambda sd, x, tr: Z.disp_vgg(sd, x, training=tr, alpha=10, beta=0.1, layout="Disp_vgg_feature")),
+    ]

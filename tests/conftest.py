@@ -24,3 +24,13 @@ def golden():
         return np.load(GOLDEN / (name + ".npz"))
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment():
+    """The library reads its DN_* switches once; tests that monkeypatch them call dn_reload_knobs() themselves, and this puts the
+    cached copy back in step with the restored environment afterwards (autouse fixtures are torn down after monkeypatch)."""
+    yield
+    from supervised_dispnet_amd import _lib
+    if _lib._lib is not None:
+        _lib._lib.dn_reload_knobs()

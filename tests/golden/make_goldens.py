@@ -53,6 +53,24 @@ def _install_shims():
 
     tvm.vgg16_bn = lambda pretrained=False, **kw: _VGG()
 
+    class _VGGPlain(nn.Module):                 # torchvision.models.vgg16() layout (cfg "D", no BatchNorm): Disp_vgg_feature.py:85
+        def __init__(self):
+            super().__init__()
+            cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+            layers, c = [], 3
+            for v in cfg:
+                if v == "M":
+                    layers.append(nn.MaxPool2d(2, 2))
+                else:
+                    layers += [nn.Conv2d(c, v, 3, padding=1), nn.ReLU(inplace=True)]
+                    c = v
+            self.features = nn.Sequential(*layers)
+            self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+            self.classifier = nn.Sequential(nn.Linear(8, 8), nn.ReLU(True), nn.Dropout(), nn.Linear(8, 8),
+                                            nn.ReLU(True), nn.Dropout(), nn.Linear(8, 8))
+
+    tvm.vgg16 = lambda pretrained=False, **kw: _VGGPlain()
+
     # ResNet: layout only (torchvision.models.ResNet with BasicBlock / Bottleneck), used by networks/resnet_encoder.py
     def _c3(i, o, s=1):
         return nn.Conv2d(i, o, 3, s, 1, bias=False)
@@ -626,6 +644,59 @@ def gold_dorn80(ref_dorn, ref_utils, ref_loss):
     save("dorn80_cfg", **arrays)
 
 
+ZOO = (
+    # tag, reference file, class, constructor kwargs, parameters whose gradient summaries are kept, BatchNorm buffers kept
+    ("res18", "models/Disp_res_18.py", "Disp_res_18", {"datasets": "nyu"},
+     ["conv1.weight", "bn1.weight", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.bn2.weight", "layer4.1.conv2.weight",
+      "upconv5.0.weight", "iconv3.0.weight", "iconv1.0.bias", "predict_disp1.0.weight"],
+     ["bn1.running_mean", "layer4.1.bn2.running_var"]),
+    ("res6", "models/Disp_res.py", "Disp_res", {"datasets": "kitti"},
+     ["conv1.weight", "layer1.0.conv1.weight", "layer2.0.bn3.weight", "layer3.5.conv2.weight", "layer4.2.bn3.bias", "upconv6.0.weight",
+      "iconv6.0.weight", "upconv3.0.weight", "iconv3.0.weight", "iconv2.0.weight", "iconv1.0.bias", "predict_disp3.0.weight"],
+     ["bn1.running_var", "layer4.2.bn3.running_mean"]),
+    ("res101", "models/Disp_res_101.py", "Disp_res_101", {"datasets": "kitti"},
+     ["conv1.weight", "layer3.22.conv2.weight", "layer3.11.bn1.weight", "upconv6.0.weight", "iconv3.0.weight", "predict_disp1.0.weight"],
+     ["layer3.22.bn3.running_mean"]),
+    ("vgg", "models/Disp_vgg.py", "Disp_vgg", {"alpha": 10, "beta": 0.01},
+     ["conv1.0.weight", "conv1.2.bias", "conv3.4.weight", "conv5.4.weight", "upconv4.0.weight", "iconv2.0.weight", "iconv0.0.weight",
+      "disp0.0.weight", "disp3.0.bias"], []),
+    ("vggfeat", "models/Disp_vgg_feature.py", "Disp_vgg_feature", {"datasets": "nyu"},
+     ["features.features.0.weight", "features.features.14.weight", "features.features.28.bias", "upconv3.0.weight", "iconv1.0.weight",
+      "disp1.0.weight"], []),
+)
+
+
+def gold_zoo(ref_loss):
+    """Disp_res_18, Disp_res, Disp_res_101, Disp_vgg, Disp_vgg_feature -- forward (4 outputs, full, 2 x 64 x 96),
+    l1 + 0.1 smooth backward (gradient summaries), BatchNorm buffers, eval output, state_dict key list."""
+    b, h, w = 2, 64, 96
+    arrays = {}
+    for tag, rel, cls, kwargs, gkeys, bnkeys in ZOO:
+        mod = _load("ref_zoo_" + tag, rel)
+        net = getattr(mod, cls)(**kwargs)
+        detgen.fill_state_dict(net.state_dict(), "zoo:" + tag)
+        ds = kwargs.get("datasets", "kitti")
+        x = detgen.image_batch(b, h, w, "zoo:%s:x" % tag)
+        gt = detgen.sparse_depth(b, h, w, "zoo:%s:gt" % tag, density=0.6, lo=0.3, hi=11.0)
+        net.train()
+        disps = net(x)
+        depth = [1 / d for d in disps]
+        loss = ref_loss.l1_loss(gt, depth, ds) + 0.1 * ref_loss.smooth_loss(depth)
+        loss.backward()
+        arrays[tag + ":loss"] = np.float64(loss.item())
+        arrays[tag + ":keys"] = np.array(sorted(net.state_dict().keys()))
+        for i, o in enumerate(disps):
+            arrays["%s:disp%d" % (tag, i)] = _np(o)
+        _grad_summaries(net, arrays, gkeys, prefix=tag + ":grad:")
+        sd = net.state_dict()
+        for key in bnkeys:
+            arrays["%s:bn:%s" % (tag, key)] = _np(sd[key])
+        net.eval()
+        with torch.no_grad():
+            arrays[tag + ":eval"] = _np(net(x))
+    save("zoo", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -659,6 +730,7 @@ def main():
         "posenet": lambda: gold_posenet(ref_pose),
         "config3": lambda: gold_config3(ref_vgg, ref_pose, ref_loss, ref_warp),
         "dorn80": lambda: gold_dorn80(ref_dorn, ref_utils, ref_loss),
+        "zoo": lambda: gold_zoo(ref_loss),
     }
     for name, fn in sections.items():
         if not want or name in want:

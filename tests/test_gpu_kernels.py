@@ -65,6 +65,9 @@ CONV_CASES = [
     ("3x3_wino_cat64_aff", (64, 128),   (False, False),    64, 3, 1, 1, False, 0, 2, 20, 30, ACT_LEAKY, True),
     ("3x3_wino_cat64",    (128, 64),    (False, False),    128, 3, 1, 1, False, 0, 3, 18, 22, ACT_NONE, False),
     ("3x3_wino_64_64",    (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 24, 44, ACT_NONE, False),
+    ("3x3_wino_t192",     (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 16, 24, ACT_LEAKY, False),   # 192 tiles: the floor
+    ("3x3_wino_t208_512", (512,),       (False,),          512, 3, 1, 1, False, 0, 4, 8, 26, ACT_NONE, True),     # conv5_x of a 4-image shard
+    ("3x3_wino_t208_cat", (256, 512),   (False, False),    256, 3, 1, 1, False, 0, 4, 8, 26, ACT_LEAKY, False),   # iconv4 of a 4-image shard
     ("3x3_wino_cat_193",  (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 24, 44, ACT_LEAKY, False),
     ("3x3_wino_cat_97",   (32, 64, 1),  (False, False, True), 32, 3, 1, 1, False, 0, 2, 24, 44, ACT_LEAKY, False),
     ("3x3_wino_iconv2",   (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 32, 104, ACT_LEAKY, False),
@@ -208,6 +211,7 @@ def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
             monkeypatch.delenv("DN_NO_WINOGRAD", raising=False)
         else:
             monkeypatch.setenv("DN_NO_WINOGRAD", env)
+        _lib.load().dn_reload_knobs()
         engine.bump_param_epoch()
         layer = engine.ConvLayer(mod)
         xa = engine.Act(x.clone(), N, H, W, cin)
@@ -239,6 +243,7 @@ def test_thin_conv_matches_tiled_kernel(monkeypatch, kind):
             monkeypatch.delenv("DN_NO_THIN_CONV", raising=False)
         else:
             monkeypatch.setenv("DN_NO_THIN_CONV", env)
+        _lib.load().dn_reload_knobs()
         torch.manual_seed(6)
         if kind == "upconv0":
             mod = nn.ConvTranspose2d(32, 16, 4, 2, 1).to(DEV)
@@ -284,6 +289,7 @@ def test_winograd_error_vs_fp64(monkeypatch):
             monkeypatch.delenv("DN_NO_WINOGRAD", raising=False)
         else:
             monkeypatch.setenv("DN_NO_WINOGRAD", env)
+        _lib.load().dn_reload_knobs()
         layer = engine.ConvLayer(mod)
         y, _, _ = engine.conv_forward(layer, [engine.Piece(engine.Act(x, N, H, W, cin))])
         torch.cuda.synchronize()

@@ -286,7 +286,7 @@ def _fresh(net, prefix):
     return {k: v.clone() for k, v in net.state_dict().items()}
 
 
-def _check_all_grads(net, osd, skip=(), osd64=None):
+def _check_all_grads(net, osd, skip=(), osd64=None, flip_allow=5e-3, total_allow=2e-3):
     """Per-parameter gradient check.  With an fp64 run of the oracle (`osd64`) the criterion is the yardstick form: the HIP
     gradient must be about as close to the fp64 truth as PyTorch-CPU fp32 is -- relative L2 error <= 3x CPU-fp32's + 5e-3 for
     every parameter and <= 1.5x + 2e-3 for the whole gradient vector (a single parameter's ratio moves by tens of percent with
@@ -315,11 +315,11 @@ def _check_all_grads(net, osd, skip=(), osd64=None):
         tot_hip += float((p.grad.detach().double().cpu() - g64).norm() ** 2)
         tot_cpu += float((og.detach().double() - g64).norm() ** 2)
         tot_ref += float(g64.norm() ** 2)
-        assert e_hip <= 3.0 * e_cpu + 5e-3, "%s: HIP rel-L2 error vs fp64 %.3g, PyTorch-CPU fp32's own %.3g" % (name, e_hip, e_cpu)
+        assert e_hip <= 3.0 * e_cpu + flip_allow, "%s: HIP rel-L2 error vs fp64 %.3g, PyTorch-CPU fp32's own %.3g" % (name, e_hip, e_cpu)
     if osd64 is not None:
         a_hip, a_cpu = (tot_hip / tot_ref) ** 0.5, (tot_cpu / tot_ref) ** 0.5
         print("whole-gradient error vs fp64: HIP %.3g, CPU-fp32 %.3g; worst per-parameter ratio %.2f" % (a_hip, a_cpu, worst))
-        assert a_hip <= 1.5 * a_cpu + 2e-3, "whole gradient: HIP %.3g vs PyTorch-CPU fp32 %.3g" % (a_hip, a_cpu)
+        assert a_hip <= 1.5 * a_cpu + total_allow, "whole gradient: HIP %.3g vs PyTorch-CPU fp32 %.3g" % (a_hip, a_cpu)
 
 
 def test_disp_res_50_config4(golden):
@@ -356,6 +356,78 @@ def test_disp_res_50_config4(golden):
     with torch.no_grad():
         e = net(x.to(DEV))
     close("eval_disp1(golden)", e, g["eval_disp1"], rtol=2e-3, atol_rel=2e-4)
+
+
+@pytest.mark.parametrize("tag", ["res18", "res6", "res101", "vgg", "vggfeat"])
+def test_model_zoo(golden, tag):
+    """Disp_res_18 (BasicBlocks), Disp_res / Disp_res_101 (six-level decoder, crop_like incl. the H/4 crop quirk,
+    bilinear disparity upsampling, LeakyReLU / ReLU), Disp_vgg / Disp_vgg_feature (BatchNorm-free VGG16, plain 2x2 max-pool) on the
+    HIP engine: outputs and loss against the REFERENCE's own numbers, every parameter gradient against the oracle with the fp64
+    yardstick, BatchNorm buffers, eval output."""
+    from tests.cases import zoo_cases
+    g = golden("zoo")
+    _, cls, kwargs, ds, run = [c for c in zoo_cases() if c[0] == tag][0]
+    net = getattr(models, cls)(**kwargs)
+    sd0 = _fresh(net, "zoo:" + tag)
+    net.to(DEV).train()
+    b, h, w = 2, 64, 96
+    x = detgen.image_batch(b, h, w, "zoo:%s:x" % tag)
+    gt = detgen.sparse_depth(b, h, w, "zoo:%s:gt" % tag, density=0.6, lo=0.3, hi=11.0)
+    disps = net(x.to(DEV))
+    depth = [reciprocal(d) for d in disps]
+    loss = LF.l1_loss(gt.to(DEV), depth, ds) + 0.1 * LF.smooth_loss(depth)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g[tag + ":loss"]), rtol=2e-4)
+    for i, d in enumerate(disps):
+        close("%s:disp%d(golden)" % (tag, i), d, g["%s:disp%d" % (tag, i)], rtol=2e-3, atol_rel=2e-4)
+    osd = _oracle_params(sd0)
+    odepth = [1 / d for d in run(osd, x, True)]
+    (OL.l1_loss(gt, odepth, ds) + 0.1 * OL.smooth_loss(odepth)).backward()
+    osd64 = _oracle_params({k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd0.items()})
+    d64 = [1 / d for d in run(osd64, x.double(), True)]
+    (OL.l1_loss(gt.double(), d64, ds) + 0.1 * OL.smooth_loss(d64)).backward()
+    skip = ("bn1.weight", "bn1.bias") if tag.startswith("res") else ()
+    # 2 x 64 x 96 puts 2x3 .. 16x24 maps in the deep layers: ONE ReLU whose pre-activation is within fp32 rounding of zero moves a
+    # weight gradient by 1/pixels ~ 0.5 % (tests/gpu_diag_zoo.py: the same net on the direct kernels sits at 1e-5 -- different
+    # rounding, different flips), hence the wider additive terms here; the standard yardstick runs at 2 x 128 x 416 below
+    _check_all_grads(net, osd, skip=skip, osd64=osd64, flip_allow=1.2e-2, total_allow=8e-3)
+    sd1 = net.state_dict()
+    for key in [k[len(tag) + 4:] for k in g.files if k.startswith(tag + ":bn:")]:
+        close(key, sd1[key], g["%s:bn:%s" % (tag, key)], rtol=1e-3, atol_rel=1e-4)
+    net.eval()
+    with torch.no_grad():
+        e = net(x.to(DEV))
+    close("%s:eval(golden)" % tag, e, g[tag + ":eval"], rtol=2e-3, atol_rel=2e-4)
+
+
+@pytest.mark.parametrize("tag", ["res18", "res6", "vgg"])
+def test_model_zoo_gradients_vs_fp64_yardstick(tag):
+    """Every parameter gradient of the zoo nets at 2 x 128 x 416 (the KITTI training resolution): the HIP gradient is about as close
+    to the fp64 oracle as PyTorch-CPU fp32 is (per parameter <= 3x + 5e-3, whole gradient <= 1.5x + 2e-3).  Disp_res_101 and
+    Disp_vgg_feature share these schedules (23-block layer3 / other key names) and are covered at the small size above."""
+    from tests.cases import zoo_cases
+    _, cls, kwargs, ds, run = [c for c in zoo_cases() if c[0] == tag][0]
+    net = getattr(models, cls)(**kwargs)
+    sd0 = _fresh(net, "zoo:" + tag)
+    net.to(DEV).train()
+    b, h, w = 2, 128, 416
+    x = detgen.image_batch(b, h, w, "zoo:%s:x2" % tag)
+    gt = detgen.sparse_depth(b, h, w, "zoo:%s:gt2" % tag, density=0.3, lo=0.3, hi=11.0)
+    depth = [reciprocal(d) for d in net(x.to(DEV))]
+    loss = LF.l1_loss(gt.to(DEV), depth, ds) + 0.1 * LF.smooth_loss(depth)
+    loss.backward()
+    osd = _oracle_params(sd0)
+    odepth = [1 / d for d in run(osd, x, True)]
+    oloss = OL.l1_loss(gt, odepth, ds) + 0.1 * OL.smooth_loss(odepth)
+    oloss.backward()
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=2e-4)
+    for i, (d, od) in enumerate(zip(depth, odepth)):
+        close("%s:depth%d" % (tag, i), d, od, rtol=2e-3, atol_rel=2e-4)
+    osd64 = _oracle_params({k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd0.items()})
+    d64 = [1 / d for d in run(osd64, x.double(), True)]
+    (OL.l1_loss(gt.double(), d64, ds) + 0.1 * OL.smooth_loss(d64)).backward()
+    skip = ("bn1.weight", "bn1.bias") if tag.startswith("res") else ()
+    _check_all_grads(net, osd, skip=skip, osd64=osd64)
 
 
 @pytest.mark.parametrize("tag", ["vgg", "res18"])

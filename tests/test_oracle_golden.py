@@ -311,6 +311,36 @@ def test_disp_res_50(golden):
         _close(nets_res.disp_res_50(sd, x, training=False, datasets="nyu"), g["eval_disp1"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["res18", "res6", "res101", "vgg", "vggfeat"])
+def test_model_zoo(golden, tag):
+    """Disp_res_18 / Disp_res / Disp_res_101 / Disp_vgg / Disp_vgg_feature -- the oracle restatement against the
+    imported reference's own outputs, gradients, BatchNorm buffers, eval output; and the product's state_dict layout against the
+    reference's key list."""
+    import supervised_dispnet_amd.models as models
+    from tests.cases import zoo_cases
+    g = golden("zoo")
+    _, cls, kwargs, ds, run = [c for c in zoo_cases() if c[0] == tag][0]
+    net = getattr(models, cls)(**kwargs)
+    strip = lambda ks: sorted(k for k in ks if ".classifier." not in k)
+    assert strip(net.state_dict().keys()) == strip(g[tag + ":keys"].tolist())        # drop-in checkpoint layout
+    sd = _params(_fresh_sd(net, "zoo:" + tag))
+    b, h, w = 2, 64, 96
+    x = detgen.image_batch(b, h, w, "zoo:%s:x" % tag)
+    gt = detgen.sparse_depth(b, h, w, "zoo:%s:gt" % tag, density=0.6, lo=0.3, hi=11.0)
+    disps = run(sd, x, True)
+    depth = [1 / d for d in disps]
+    loss = losses.l1_loss(gt, depth, ds) + 0.1 * losses.smooth_loss(depth)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[tag + ":loss"], rtol=1e-5)
+    for i, d in enumerate(disps):
+        _close(d, g["%s:disp%d" % (tag, i)], rtol=1e-4, atol=1e-5)
+    _grad_check(sd, g, prefix=tag + ":grad:")
+    for key in [k[len(tag) + 4:] for k in g.files if k.startswith(tag + ":bn:")]:
+        _close(sd[key], g["%s:bn:%s" % (tag, key)], rtol=1e-4, atol=1e-6)
+    with torch.no_grad():
+        _close(run(sd, x, False), g[tag + ":eval"], rtol=1e-4, atol=1e-5)
+
+
 def test_monodepth2_style_nets(golden):
     import supervised_dispnet_amd.models as models
     import supervised_dispnet_amd.networks as networks

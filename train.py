@@ -275,6 +275,10 @@ def main(argv=None):
     reducer = None
     plain_params = None          # torch.optim path (--sgd / --diff-lr): gradients live in p.grad and are exchanged per step
     if args.diff_lr:
+        if not hasattr(disp_net, "get_1x_lr_params"):
+            # the reference's only network with these methods is models/DORN.py:222-236 (train.py:306-312 calls them unconditionally and
+            # dies with AttributeError for every other --network); the full DORN model is outside SURVEY.md section 8
+            raise SystemExit("--diff-lr needs a network with get_1x_lr_params() / get_10x_lr_params() (reference: models.DORN only)")
         groups = [{"params": disp_net.get_1x_lr_params(), "lr": args.lr}, {"params": disp_net.get_10x_lr_params(), "lr": args.lr * 10}]
         optimizer = torch.optim.SGD(groups, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     elif args.sgd:
