@@ -360,6 +360,18 @@ int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, co
 int dn_fill(float* p, float value, int64_t n, dn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Input pipeline on the device (reference custom_transforms.py: RandomHorizontalFlip :56-72, ArrayToTensor :40-53, Normalize :25-37;
+ * datasets/sequence_folders.py:60-77).  src = pre-decoded uint8 frames [B,H,W,C] (NHWC, as imread returns them); flip = one byte per
+ * sample (non-zero: mirror along W) or NULL; dst = fp32 [B,C,H,W] with the given plane / sample strides (in floats):
+ *     dst[n,c,y,x] = ((float)src[n,y,x',c] / 255 - mean[c]) / std[c],  x' = flip[n] ? W-1-x : x      (IEEE fp32, that order)
+ * mean / std: device pointers (general path); mean_host / std_host: the same values on the host, used by the C == 3, W % 4 == 0
+ * fast path (pass both).  dn_flip_w applies the same per-sample mirror to the fp32 ground-truth depth [B,H,W] (out of place).
+ * ------------------------------------------------------------------------------------------------------------ */
+int dn_u8_normalize_flip(const uint8_t* src, const uint8_t* flip, int32_t B, int32_t H, int32_t W, int32_t C, const float* mean, const float* stdv,
+                         const float* mean_host, const float* std_host, float* dst, int64_t dst_stride_n, int64_t dst_stride_c, dn_stream_t stream);
+int dn_flip_w(const float* src, const uint8_t* flip, int32_t B, int32_t H, int32_t W, float* dst, dn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Attainable-peak probes (SURVEY.md section 8d "Peaks"; used by bench.py only): a float4 streaming copy of n floats
  * (n % 4 == 0, 16-byte aligned; moves 8*n bytes) and a register-resident v_mfma_f32_32x32x2_f32 loop
  * (out: blocks*256 floats; dn_ubench_mfma_f32_flops = the FLOPs one launch executes).

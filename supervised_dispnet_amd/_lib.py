@@ -123,6 +123,8 @@ SIGNATURES = {
     "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i32, _d, _vp]),
     "dn_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _d, _d, _vp, _vp, _d, _vp]),
     "dn_fill": (C.c_int, [_vp, _f, _i64, _vp]),
+    "dn_u8_normalize_flip": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "dn_flip_w": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "dn_ubench_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "dn_ubench_mfma_f32_flops": (_i64, [_i32, _i32]),
     "dn_ubench_mfma_f32": (C.c_int, [_vp, _i32, _i32, _vp]),

@@ -34,3 +34,20 @@ def zoo_cases():
         ("vggfeat", "Disp_vgg_feature", {"datasets": "nyu", "with_classifier": False}, "nyu",
          lambda sd, x, tr: Z.disp_vgg(sd, x, training=tr, alpha=10, beta=0.1, layout="Disp_vgg_feature")),
     ]
+
+
+def make_scene_folders(root, scenes=("s1", "s2", "s3"), frames=5, h=16, w=32, seed=0):
+    """A tiny dataset in the reference's KITTI layout (scene/{%07d.jpg, %07d.npy, cam.txt} + train.txt / val.txt) with random content."""
+    import numpy as np
+    from PIL import Image
+    r = np.random.RandomState(seed)
+    for si, scene in enumerate(scenes):
+        d = root / scene
+        d.mkdir(parents=True)
+        np.savetxt(d / "cam.txt", np.array([[100.0 + si, 0, w / 2.0 - 1.5], [0, 101.0, h / 2.0], [0, 0, 1]]))
+        for i in range(frames):
+            Image.fromarray(r.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(d / ("%07d.jpg" % i), quality=95)
+            np.save(d / ("%07d.npy" % i), (r.rand(h, w) * 80 * (r.rand(h, w) < 0.3)).astype(np.float32))
+    (root / "train.txt").write_text("".join(s + "\n" for s in scenes))
+    (root / "val.txt").write_text(scenes[-1] + "\n")
+    return root

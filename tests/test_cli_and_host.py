@@ -155,6 +155,31 @@ def test_scene_folder_readers_and_rank_sampler(tmp_path):
     assert torch.equal(s[1][0], s[1][0]) and 0.02 < float((s[0][1] > 0).float().mean()) < 0.08
 
 
+def test_shard_writer_matches_the_scene_folder_reader(tmp_path):
+    """the pre-decoded uint8 shards hold exactly what the reference's loader decodes (imread frames, .npy depth, cam.txt)
+    and the same sample list as datasets/sequence_folders.py:32-50 crawls (before its shuffle)."""
+    from supervised_dispnet_amd import data as D
+    from supervised_dispnet_amd import shards as S
+    from tests.cases import make_scene_folders
+    root = make_scene_folders(tmp_path / "kitti")
+    meta = S.write_shards(str(root), str(tmp_path / "sh"), train=True, sequence_length=3)
+    st = S.ShardSet(str(tmp_path / "sh"))
+    assert meta["frames"] == 15 and len(st) == 9 and (st.H, st.W) == (16, 32)
+    ds = D.SequenceFolder(str(root), seed=0, train=True, sequence_length=3, transform=None, with_refs=True)
+    crawl = sorted((s["tgt"], tuple(s["ref_imgs"])) for s in ds.samples)
+    names = []
+    for scene in ("s1", "s2", "s3"):
+        names += [str(root / scene / ("%07d.jpg" % i)) for i in range(5)]
+    assert sorted((names[t], tuple(names[r] for r in refs)) for t, refs, _ in st.samples) == crawl
+    for fi in (0, 7, 14):
+        a = D.load_as_float(names[fi])
+        assert np.array_equal(st.frames[fi].astype(np.float32), a)                 # imread's integers, losslessly as uint8
+        assert np.array_equal(st.depth[fi], np.load(names[fi][:-4] + ".npy"))
+    np.testing.assert_array_equal(st.intrinsics[1], np.genfromtxt(root / "s2" / "cam.txt").astype(np.float32))
+    val = S.write_shards(str(root), str(tmp_path / "shv"), train=False, with_gt=True)
+    assert len(val["samples"]) == 5 and val["samples"][2] == [2, [], 0]
+
+
 def test_imresize_matches_scipy_misc_semantics():
     from supervised_dispnet_amd import kitti_eval as KE
     img = np.zeros((4, 4, 3), dtype=np.float32)

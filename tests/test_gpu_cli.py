@@ -97,3 +97,33 @@ def test_train_cli_unsupervised_with_pose_training(tmp_path):
     assert "pose_pred.weight" in psd and "predict_mask1.weight" in psd                           # -m > 0 builds the mask decoder
     summary = [r for r in runs if r.endswith("progress_log_summary.csv")][0]
     assert len(open(summary).read().strip().splitlines()) == 3
+
+
+@pytest.mark.parametrize("network", ["disp_res_18", "disp_vgg", "disp_res_101"])
+def test_train_cli_zoo_networks(tmp_path, network):
+    """SURVEY 8 f-4 through the command line: --network disp_res_18 / disp_vgg (= models.Disp_vgg_feature, train.py:248) /
+    disp_res_101 train, checkpoint with the reference's keys."""
+    vals, sd, _ = _run_train(tmp_path, ["--network", network, "--loss", "L1", "--with-gt"], epochs=3)
+    assert vals[:, 0].min() > 0 and np.mean(vals[-2:, 0]) < np.mean(vals[:2, 0])
+    key = {"disp_res_18": "layer4.1.conv2.weight", "disp_vgg": "features.features.28.weight", "disp_res_101": "layer3.22.conv3.weight"}[network]
+    assert key in sd["state_dict"]
+
+
+def test_train_cli_from_uint8_shards(tmp_path):
+    """SURVEY 8 f-3 through the command line: scene folders -> tools/make_shards.py -> train.py --shards (GPU-side flip / /255 / normalise);
+    validation keeps reading the scene folders."""
+    import train
+    from supervised_dispnet_amd.shards import write_shards
+    from tests.cases import make_scene_folders
+    import pathlib
+    root = make_scene_folders(pathlib.Path(tmp_path) / "kitti", frames=6, h=64, w=96)
+    write_shards(str(root), str(tmp_path / "sh"), train=True, sequence_length=3)
+    out = tmp_path / "run"
+    train.main([str(root), "--shards", str(tmp_path / "sh"), "-b", "4", "--network", "disp_vgg_BN", "--loss", "L1", "--with-gt", "--epochs", "2",
+                "--lr", "1e-3", "--save-root", str(out), "--print-freq", "100"])
+    runs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs]
+    full = [r for r in runs if r.endswith("progress_log_full.csv")][0]
+    rows = [l.split("\t") for l in open(full).read().strip().splitlines()]
+    assert len(rows) == 1 + 2 * 3                                      # 12 samples / batch 4, two epochs
+    vals = np.array([[float(v) for v in r] for r in rows[1:]])
+    assert np.isfinite(vals).all() and (vals[:, 0] > 0).all()

@@ -81,6 +81,9 @@ def build_parser():
                    help="frequence for outputting dispnet outputs and warped imgs at training")
     # extensions (not in the reference)
     p.add_argument("--synthetic", type=int, default=0, metavar="N", help="train on N synthetic samples instead of DIR")
+    p.add_argument("--shards", default=None, metavar="SHARD_DIR",
+                   help="training samples from pre-decoded uint8 shards (tools/make_shards.py DIR SHARD_DIR): flip / /255 / normalise run "
+                        "on the GPU (dn_u8_normalize_flip), bit-identical to the JPEG loader's host chain")
     p.add_argument("--img-height", type=int, default=128, help="synthetic image height")
     p.add_argument("--img-width", type=int, default=416, help="synthetic image width")
     p.add_argument("--train-pose", action="store_true", help="also optimise PoseExpNet (the reference never does, appendix C-3)")
@@ -249,6 +252,12 @@ def main(argv=None):
     workers = min(per_rank, os.cpu_count() or 1)     # the reference uses num_workers = batch_size and ignores -j (train.py:201-206)
     train_loader = torch.utils.data.DataLoader(train_set, batch_sampler=train_sampler, num_workers=workers, pin_memory=True)
     val_loader = torch.utils.data.DataLoader(val_set, batch_sampler=val_sampler, num_workers=workers, pin_memory=True)
+    if args.shards:
+        from supervised_dispnet_amd.shards import ShardLoader
+        mean, std = D.normalization(args.imagenet_normalization, args.monodepth2)
+        train_loader = ShardLoader(args.shards, per_rank, device, mean=mean, std=std, flip=True, shuffle=True, seed=args.seed, rank=rank,
+                                   world=world, with_refs=with_refs)
+        train_sampler = train_loader                 # set_epoch() reshuffles
     if args.epoch_size == 0:
         args.epoch_size = len(train_loader)
 
