@@ -341,6 +341,18 @@ int dn_ordinal_loss_fwd(const float* ord, const float* gt, const int32_t* target
 int dn_ordinal_loss_bwd(const float* ord, const float* gt, const int32_t* target, const float* stats, const float* dloss, int32_t N,
                         int64_t HW, int32_t K, float max_depth, float* dord, dn_stream_t stream);
 /* get_labels_sid / get_depth_sid (beta = 80.999 kitti, 10.999 nyu). */
+/* Fused head (models/Disp_vgg_BN_DORN.py:112-114,191-227): Dropout2d channel mask (mask[N][16] = 0 or 1/(1-p), NULL = none) ->
+ * 1x1 convolution 16 -> 2K (w = conv_ord.weight [2K][16], bias [2K]) -> clamp -> pair softmax.  The 2K-channel logits never reach
+ * HBM: forward writes ord [N][K][HW] (planar, the reference's NCHW) and decode [N][HW] int64; backward takes dord (planar) and
+ * recomputes the logits, producing dx [N][HW][16] (NHWC, accumulate != 0 adds), dw [2K][16] and dbias [2K] (fixed-order sums of
+ * per-block partials in `workspace`: dn_ord_head_bwd_blocks() * (2K*16 + 2K) floats).  Supported (dn_ord_head_supported): 16 input
+ * channels, H*W % 64 == 0, K <= 80; otherwise use dn_conv2d_fwd + dn_ordinal_fwd. */
+int32_t dn_ord_head_supported(int32_t C_in, int64_t HW, int32_t K);
+int32_t dn_ord_head_bwd_blocks(int32_t N, int64_t HW);
+int dn_ord_head_fwd(const float* x, const float* mask, const float* w, const float* bias, int32_t N, int64_t HW, int32_t K, float* ord,
+                    int64_t* decode, dn_stream_t stream);
+int dn_ord_head_bwd(const float* x, const float* mask, const float* w, const float* bias, const float* dord, int32_t N, int64_t HW, int32_t K,
+                    float* dx, int32_t accumulate, float* workspace, float* dw, float* dbias, dn_stream_t stream);
 int dn_sid_labels(const float* depth, int64_t n, float ordinal_c, float beta, int32_t* labels, dn_stream_t stream);
 int dn_sid_depth(const int64_t* labels, int64_t n, float ordinal_c, float beta, float* depth, dn_stream_t stream);
 /* Dropout2d apply (and its backward): out[n][p][c] = x[n][p][c] * mask[n][c], NHWC. */

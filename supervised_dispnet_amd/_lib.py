@@ -117,6 +117,10 @@ SIGNATURES = {
     "dn_ordinal_loss_blocks": (_i32, [_i32, _i64]),
     "dn_ordinal_loss_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp]),
     "dn_ordinal_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _vp, _vp]),
+    "dn_ord_head_supported": (_i32, [_i32, _i64, _i32]),
+    "dn_ord_head_bwd_blocks": (_i32, [_i32, _i64]),
+    "dn_ord_head_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "dn_ord_head_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "dn_sid_labels": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
     "dn_sid_depth": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
     "dn_channel_scale": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),

@@ -185,7 +185,7 @@ def require_cuda(t, what):
 class Act:
     """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
     __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
-                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu")
+                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar")
 
     def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
         self.t = t
@@ -198,6 +198,7 @@ class Act:
         self.partial_stride, self.partial_offset = 2, 0
         self.no_relu = False            # pending BatchNorm affine WITHOUT ReLU (bottleneck bn3 / downsample BN): only
                                         # block_bn_add_relu may consume it
+        self.planar = False             # .t is [N,C,H,W] (a network OUTPUT the caller's API wants planar: ord_c1, decode_c)
         self.needs_grad = needs_grad
         self.strides = strides or (H * W * C, W * C, C, 1)   # (n, h, w, c) element strides
 
@@ -669,7 +670,13 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
 
 def seed_grad(act, g):
     """Seed an activation's gradient with one supplied by autograd (owned copy: the tape works in place)."""
-    g = g.reshape(act.N, act.H, act.W, act.C) if act.C == 1 else g.permute(0, 2, 3, 1)
+    if act.planar:
+        g = g.reshape(act.N, act.C, act.H, act.W)
+        if act.grad is None:
+            act.grad = g                 # read-only use by the producing block: no owned copy of a K-channel full-resolution map
+            return
+    else:
+        g = g.reshape(act.N, act.H, act.W, act.C) if act.C == 1 else g.permute(0, 2, 3, 1)
     if act.grad is None:
         act.grad = g.clone(memory_format=torch.contiguous_format)
     else:
@@ -697,6 +704,59 @@ def block_bilinear_up2(tape, d, out_hw):
 
     tape.push(backward)
     return up
+
+
+def ord_head_fusable(x, K):
+    return (x.scale is None and x.strides == (x.H * x.W * x.C, x.W * x.C, x.C, 1)
+            and bool(_lib.load().dn_ord_head_supported(x.C, x.H * x.W, K)))
+
+
+def block_ord_head(tape, sink, x, conv, mask):
+    """Dropout2d mask -> 1x1 conv (16 -> 2K) -> clamp -> pair softmax as ONE kernel (models/Disp_vgg_BN_DORN.py:112-114,191-227):
+    returns (ord_c1 Act planar [N,K,H,W], decode_c Act planar int64 [N,1,H,W]); the 2K-channel logits never exist in HBM, and the
+    backward recomputes them to go from d(ord_c1) straight to d(x), d(conv.weight), d(conv.bias)."""
+    K = conv.out_channels // 2
+    N, H, W = x.N, x.H, x.W
+    dev = x.t.device
+    w, b = conv.weight.detach(), conv.bias.detach()
+    ord_t = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+    dec_t = torch.empty((N, 1, H, W), dtype=torch.int64, device=dev)
+    mp = mask.data_ptr() if mask is not None else None
+    px = N * H * W
+    hbm_call("dn::ord_head_fwd_kernel", px * (16 + K + 2) * 4, "dn_ord_head_fwd", x.t.data_ptr(), mp, w.data_ptr(), b.data_ptr(), N, H * W, K,
+             ord_t.data_ptr(), dec_t.data_ptr(), _stream())
+    o = Act(ord_t, N, H, W, K)
+    o.planar = True
+    d = Act(dec_t, N, H, W, 1, needs_grad=False)
+    d.planar = True
+
+    def backward():
+        if o.grad is None:
+            return
+        g = o.grad if o.grad.is_contiguous() else o.grad.contiguous()
+        nblk = _lib.load().dn_ord_head_bwd_blocks(N, H * W)
+        ws = torch.empty(nblk * (2 * K * 16 + 2 * K), dtype=torch.float32, device=dev)
+        dw = sink.dest(conv.weight)
+        if dw is None:
+            dw = torch.empty_like(conv.weight, memory_format=torch.contiguous_format)
+        db = sink.dest(conv.bias)
+        if db is None:
+            db = torch.empty_like(conv.bias)
+        first = x.grad is None
+        if x.needs_grad:
+            if first:
+                x.grad = x.new_like()
+            dx = x.grad
+        else:
+            dx, first = x.new_like(), True
+        hbm_call("dn::ord_head_bwd_kernel", px * (K + 48) * 4, "dn_ord_head_bwd", x.t.data_ptr(), mp, w.data_ptr(), b.data_ptr(), g.data_ptr(), N,
+                 H * W, K, dx.data_ptr(), 0 if first else 1, ws.data_ptr(), dw.data_ptr(), db.data_ptr(), _stream())
+        sink.put(conv.bias, db)
+        sink.put(conv.weight, dw)
+        o.grad = None
+
+    tape.push(backward)
+    return o, d
 
 
 def block_channel_scale(tape, x, mask):

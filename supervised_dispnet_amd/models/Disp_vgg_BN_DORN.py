@@ -59,11 +59,14 @@ class Disp_vgg_BN_DORN(Disp_vgg_BN):
         self.dropout = nn.Dropout2d(p=0.5)
         self.conv_ord = nn.Conv2d(16, 2 * ordinal_c, 1)
         self.orl = OrdinalRegressionLayer()
+        self.fused_head = True                              # False: conv -> logits in HBM -> OrdinalRegressionLayer (the r01 path)
         self._dropout_mask = None                           # test hook: fixed [N,16] keep/scale mask instead of RNG
 
     def forward(self, x):
-        pre = run_net(self, x)[0]                           # [N,2K,H,W] view of the NHWC logits
-        return self.orl(pre)
+        outs = run_net(self, x)
+        if len(outs) == 2:                                  # fused head: (ord_c1, decode_c) straight from the engine
+            return outs[1], outs[0]
+        return self.orl(outs[0])                            # [N,2K,H,W] view of the NHWC logits -> OrdinalRegressionLayer
 
     def _runtime(self):
         rt = super(Disp_vgg_BN_DORN, self)._runtime()
@@ -77,12 +80,17 @@ class Disp_vgg_BN_DORN(Disp_vgg_BN):
     def _hip_forward(self, tape, sink, x):
         feats = self._encoder(tape, sink, x)
         i0, _d1, _d2, _d3, _head = self._decoder_trunk(tape, sink, feats)
-        cur = i0
+        cur, mask = i0, None
         if self.training and self.dropout.p > 0:
             mask = self._dropout_mask
             if mask is None:
                 keep = 1.0 - self.dropout.p
                 mask = torch.bernoulli(torch.full((i0.N, i0.C), keep, dtype=torch.float32, device=i0.t.device)) / keep
-            cur = engine.block_channel_scale(tape, i0, mask.to(i0.t.device).contiguous().float())
+            mask = mask.to(i0.t.device).contiguous().float()
+        if self.fused_head and engine.ord_head_fusable(i0, self.conv_ord.out_channels // 2):
+            o, d = engine.block_ord_head(tape, sink, i0, self.conv_ord, mask)
+            return [o, d]
+        if mask is not None:
+            cur = engine.block_channel_scale(tape, i0, mask)
         pre = engine.block_conv_act(tape, sink, [engine.Piece(cur)], self._runtime()["conv_ord"], ACT_NONE)
         return [pre]

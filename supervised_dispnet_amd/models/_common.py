@@ -79,7 +79,10 @@ class HipNetFunction(torch.autograd.Function):
         with engine.stream_scope():
             outs = net._hip_forward(tape, sink, *in_acts)     # list[Act]
         ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
-        results = tuple(a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2) for a in outs)
+        results = tuple(a.t if a.planar else (a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2)) for a in outs)
+        for r in results:
+            if not torch.is_floating_point(r):
+                ctx.mark_non_differentiable(r)
         return results
 
     @staticmethod

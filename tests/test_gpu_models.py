@@ -347,7 +347,8 @@ def test_disp_res_50_config4(golden):
     d64 = [1 / d for d in nets_res.disp_res_50(osd64, x.double(), training=True, datasets="nyu")]
     (OL.l1_loss(gt.double(), d64, "nyu") + 0.1 * OL.smooth_loss(d64)).backward()
     assert net.bn1.weight.grad is None and net.bn1.bias.grad is None                    # bn1's output is discarded by the reference
-    _check_all_grads(net, osd, skip=("bn1.weight", "bn1.bias"), osd64=osd64)
+    # 2 x 64 x 96: layer4 normalises over 12 values per channel and one flipped ReLU moves a gradient by ~0.5 % (see test_model_zoo)
+    _check_all_grads(net, osd, skip=("bn1.weight", "bn1.bias"), osd64=osd64, flip_allow=1.2e-2, total_allow=8e-3)
     sd1 = net.state_dict()
     for key in ("bn1.running_mean", "bn1.running_var", "layer4.2.bn3.running_mean", "layer1.0.downsample.1.running_var"):
         close(key, sd1[key], g["bn:" + key], rtol=1e-3, atol_rel=1e-4)
