@@ -13,10 +13,34 @@ import torch.distributed as dist
 
 
 class GradReducer(object):
-    def __init__(self, arena, bucket_bytes=20 << 20, process_group=None):
+    """`comm`: "rccl" = this library's own communicator and HIP stream (rccl.Communicator: ncclAllReduce + event fences, the
+    default for device arenas), "torch" = torch.distributed.all_reduce(async_op=True) (gloo on CPU in the tests; also available on the
+    device for A/B), or a ready rccl.Communicator.  DN_COMM=torch|rccl overrides the default."""
+
+    def __init__(self, arena, bucket_bytes=20 << 20, process_group=None, comm=None):
         self.arena = arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        import os
+        choice = comm if comm is not None else os.environ.get("DN_COMM", "rccl" if arena.flat_g.is_cuda else "torch")
+        self.comm = None
+        if choice == "rccl":
+            if not arena.flat_g.is_cuda or process_group is not None:
+                raise ValueError("the RCCL communicator serves device arenas on the default process group")
+            from .rccl import Communicator
+            try:
+                self.comm = Communicator(device=arena.flat_g.device)
+                self.world = self.comm.world
+            except Exception as e:               # noqa: BLE001 -- same arithmetic through torch.distributed; say so
+                import sys
+                if comm == "rccl":
+                    raise
+                print("supervised_dispnet_amd: own RCCL communicator unavailable (%s); gradients go through torch.distributed" % e,
+                      file=sys.stderr)
+                self.comm = None
+        elif choice != "torch":
+            self.comm = choice
+            self.world = choice.world
         # contiguous buckets over the arena (arena order == gradient production order)
         self.buckets, start, acc = [], 0, 0
         for i, (p, o) in enumerate(zip(arena.params, arena.offsets)):
@@ -40,8 +64,13 @@ class GradReducer(object):
 
     def _launch(self, bi):
         b = self.buckets[bi]
-        if self.arena.flat_g.is_cuda:
+        if self.comm is not None:
             from . import engine                 # gradients of one bucket come from two HIP streams (engine.WGRAD_STREAM)
+            self.comm.all_reduce_sum_(self.arena.flat_g[b["lo"]:b["hi"]], engine.compute_streams())
+            self._used_comm = True
+            return
+        if self.arena.flat_g.is_cuda:
+            from . import engine
             engine.fence_streams()
         if self.world > 1:
             self._handles.append(dist.all_reduce(self.arena.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM,
@@ -64,6 +93,8 @@ class GradReducer(object):
                 self._launch(bi)
         for h in self._handles:
             h.wait()
+        if self.comm is not None:
+            self.comm.join()                     # the optimizer (current stream) waits for the last bucket; no host sync
         self.reset()
         return 1.0 / self.world
 

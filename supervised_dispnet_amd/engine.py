@@ -39,15 +39,15 @@ PROFILE = None
 CAPTURING = False
 
 
-# Weight gradients on a side HIP stream (DN_WGRAD_STREAM=auto|1|0; auto = on in a single-process run, off under
-# torch.distributed with more than one rank until the RCCL interplay has been measured on a multi-GPU node -- the 2-rank gloo
-# exercise on ONE GPU host-synchronises inside every bucket launch and collapses): a layer's weight gradient
+# Weight gradients on a side HIP stream (DN_WGRAD_STREAM=auto|1|0; auto = on): a layer's weight gradient
 # and its input gradient only share read-only operands, so the two launches run side by side and fill each other's last,
 # partially occupied round of blocks (a Winograd weight-gradient block needs a whole CU's LDS, so it takes the CUs the input
 # gradient's tail leaves idle).  Measured +2.3 % images/sec (r01_h A/B on one box, identical losses).  The fences:
 #   side waits for main before every weight gradient (dy, the operands, this layer's bias / BatchNorm gradients);
-#   main waits for side at the end of the backward pass (optimizer, next forward) and before a data-parallel bucket is
-#   all-reduced (fence_streams); tensors the side stream reads are record_stream()ed against the caching allocator.
+#   main waits for side at the end of the backward pass (optimizer, next forward);
+#   a data-parallel gradient bucket is fenced against BOTH streams before it is exchanged (compute_streams() -> the RCCL stream's
+#   hipStreamWaitEvent, or fence_streams() on the torch.distributed path); tensors the side stream reads are record_stream()ed
+#   against the caching allocator.
 _WGRAD_STREAM_MODE = os.environ.get("DN_WGRAD_STREAM", "auto")
 WGRAD_STREAM = _WGRAD_STREAM_MODE != "0"
 _SIDE = {}
@@ -56,10 +56,9 @@ _SIDE = {}
 def wgrad_stream_enabled():
     if _WGRAD_STREAM_MODE == "0" or PROFILE is not None:      # per-launch event timing wants one kernel at a time
         return False
-    if _WGRAD_STREAM_MODE == "1":
-        return True
-    import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    # "auto" == on, also under data parallelism: every gradient bucket is fenced against BOTH compute streams before it is
+    # exchanged (rccl.Communicator.all_reduce_sum_ / fence_streams), so the two-stream schedule needs no special case there
+    return True
 
 
 def side_stream():
@@ -76,6 +75,20 @@ def join_side_stream():
         st = _SIDE.get(torch.cuda.current_device())
         if st is not None:
             torch.cuda.current_stream().wait_stream(st["side"])
+
+
+def compute_streams():
+    """The HIP streams gradients may have been produced on so far in this backward pass: the current one (the autograd thread's)
+    plus the weight-gradient side stream once it exists -- what a gradient bucket must be fenced against before it is exchanged."""
+    cur = torch.cuda.current_stream()
+    out = [cur]
+    st = _SIDE.get(torch.cuda.current_device())
+    if WGRAD_STREAM and st is not None:
+        if st["side"] != cur:
+            out.append(st["side"])
+        if st["main"] is not None and st["main"] != cur and st["main"] != st["side"]:
+            out.append(st["main"])
+    return out
 
 
 def fence_streams():

@@ -71,28 +71,45 @@ def inverse_warp(img, depth, pose, intrinsics, intrinsics_inv, rotation_mode='eu
                               1 if align_corners else 0)
 
 
-@torch.no_grad()
+class _PoseVec2Mat(torch.autograd.Function):
+    """[B,6] -> [B,3,4] = [R|t] with the analytic backward the warp kernels use (dn_pose_proj_fwd / dn_pose_proj_bwd with K = I)."""
+
+    @staticmethod
+    def forward(ctx, vec, rot):
+        require_cuda(vec, "pose vector")
+        v = vec.contiguous().float()
+        B = v.shape[0]
+        eye = torch.eye(3, dtype=torch.float32, device=v.device).repeat(B, 1, 1)
+        proj = torch.empty((B, 12), dtype=torch.float32, device=v.device)
+        scratch = torch.empty((B, 9), dtype=torch.float32, device=v.device)
+        _lib.call("dn_pose_proj_fwd", v.data_ptr(), 6, eye.data_ptr(), eye.data_ptr(), B, rot, 1.0, proj.data_ptr(), scratch.data_ptr(), _stream())
+        ctx.save_for_backward(v, eye)
+        ctx.rot = rot
+        return proj.view(B, 3, 4)
+
+    @staticmethod
+    def backward(ctx, dmat):
+        v, eye = ctx.saved_tensors
+        B = v.shape[0]
+        dpp = dmat.contiguous().float().view(B, 1, 12)               # one "block" of projection-matrix gradients per sample
+        dpose = torch.empty_like(v)
+        _lib.call("dn_pose_proj_bwd", v.data_ptr(), 6, eye.data_ptr(), B, ctx.rot, 1.0, dpp.data_ptr(), 1, dpose.data_ptr(), 6, 0, _stream())
+        return dpose, None
+
+
 def pose_vec2mat(vec, rotation_mode='euler'):
-    """reference inverse_warp.py:141-157: [B,6] (tx,ty,tz,rx,ry,rz) -> [B,3,4] = [R|t].  Forward only (the differentiable
-    use is inside inverse_warp / photometric_reconstruction_loss, whose backward is analytic)."""
-    require_cuda(vec, "pose vector")
-    v = vec.contiguous().float()
-    B = v.shape[0]
-    eye = torch.eye(3, dtype=torch.float32, device=v.device).repeat(B, 1, 1)
-    proj = torch.empty((B, 12), dtype=torch.float32, device=v.device)
-    scratch = torch.empty((B, 9), dtype=torch.float32, device=v.device)
-    _lib.call("dn_pose_proj_fwd", v.data_ptr(), 6, eye.data_ptr(), eye.data_ptr(), B, _ROT[rotation_mode], 1.0, proj.data_ptr(),
-              scratch.data_ptr(), _stream())
-    return proj.view(B, 3, 4)
+    """reference inverse_warp.py:141-157: [B,6] (tx,ty,tz,rx,ry,rz) -> [B,3,4] = [R|t], differentiable w.r.t. `vec` like the
+    reference's torch expression."""
+    return _PoseVec2Mat.apply(vec, _ROT[rotation_mode])
 
 
 def euler2mat(angle):
-    """reference inverse_warp.py:77-114: [B,3] -> [B,3,3] = Rx @ Ry @ Rz (forward only)."""
+    """reference inverse_warp.py:77-114: [B,3] -> [B,3,3] = Rx @ Ry @ Rz (differentiable)."""
     vec = torch.cat([torch.zeros_like(angle), angle], dim=1)
     return pose_vec2mat(vec, 'euler')[:, :, :3].contiguous()
 
 
 def quat2mat(quat):
-    """reference inverse_warp.py:117-138 (forward only)."""
+    """reference inverse_warp.py:117-138 (differentiable)."""
     vec = torch.cat([torch.zeros_like(quat), quat], dim=1)
     return pose_vec2mat(vec, 'quat')[:, :, :3].contiguous()

@@ -169,6 +169,20 @@ def test_pose_vec2mat_matches_oracle():
         close("pose_vec2mat:" + rot, IW.pose_vec2mat(dev(pose), rot), OG.pose_vec2mat(pose, rot), rtol=1e-5, atol=1e-6)
     close("euler2mat", IW.euler2mat(dev(pose[:, 3:])), OG.euler2mat(pose[:, 3:]), rtol=1e-5, atol=1e-6)
     close("quat2mat", IW.quat2mat(dev(pose[:, 3:])), OG.quat2mat(pose[:, 3:]), rtol=1e-5, atol=1e-6)
+    # differentiable like the reference's torch expressions (inverse_warp.py:77-157)
+    for rot in ("euler", "quat"):
+        wt = torch.randn(pose.shape[0], 3, 4, generator=torch.Generator().manual_seed(3))
+        pc = pose.clone().requires_grad_(True)
+        (OG.pose_vec2mat(pc, rot) * wt).sum().backward()
+        pd = dev(pose).requires_grad_(True)
+        (IW.pose_vec2mat(pd, rot) * dev(wt)).sum().backward()
+        close("d pose_vec2mat:" + rot, pd.grad, pc.grad, rtol=1e-4, atol=1e-6)
+        ac = pose[:, 3:].clone().requires_grad_(True)
+        fn_o, fn_h = (OG.euler2mat, IW.euler2mat) if rot == "euler" else (OG.quat2mat, IW.quat2mat)
+        (fn_o(ac) * wt[:, :, :3]).sum().backward()
+        ad = dev(pose[:, 3:]).requires_grad_(True)
+        (fn_h(ad) * dev(wt[:, :, :3])).sum().backward()
+        close("d %s2mat" % rot, ad.grad, ac.grad, rtol=1e-4, atol=1e-6)
 
 
 def test_photometric_loss_golden(golden):

@@ -103,13 +103,20 @@ def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
         close("disp%d" % i, d, od, rtol=1e-3, atol_rel=1e-4)
         if full:
             close("disp%d(golden)" % i, d, g["disp%d" % i], rtol=1e-3, atol_rel=1e-4)
+        else:
+            # the configuration-size golden keeps every 97th element + checksums of each output (make_goldens.py::_vgg_case)
+            s = detgen.summarize(d.detach().cpu(), 97)
+            assert tuple(s["shape"]) == tuple(g["disp%d_shape" % i])
+            close("disp%d samples(golden)" % i, torch.as_tensor(s["samples"]), g["disp%d_samples" % i], rtol=1e-3, atol_rel=1e-4)
+            np.testing.assert_allclose(s["sum"], g["disp%d_sum" % i], rtol=1e-4)
+            np.testing.assert_allclose(s["max"], g["disp%d_max" % i], rtol=1e-3)
     for name, p in net.named_parameters():
         if _is_pre_bn_conv_bias(name):
             assert float(p.grad.abs().max()) == 0.0
             continue
         grad_close("grad:" + name, p.grad, osd[name].grad)
-    if full:
-        # fp64 yardstick: the HIP fp32 path must be about as accurate as PyTorch-CPU fp32 is
+    if True:
+        # fp64 yardstick (both sizes): the HIP fp32 path must be about as accurate as PyTorch-CPU fp32 is
         o64 = {k: (v.double() if torch.is_floating_point(v) else v.clone()) for k, v in sd0.items()}
         for k, v in o64.items():
             if torch.is_floating_point(v) and "running" not in k:
@@ -118,10 +125,15 @@ def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
         dep64 = [1 / d for d in d64]
         (OL.l1_loss(gt.double(), dep64, "kitti") + 0.1 * OL.smooth_loss(dep64)).backward()
         worst = 0.0
+        tot = {"enc": [0.0, 0.0, 0.0], "dec": [0.0, 0.0, 0.0]}                    # squared L2: HIP error, CPU-fp32 error, fp64 norm
         for name, p in net.named_parameters():
             if _is_pre_bn_conv_bias(name):
                 continue
             g64 = o64[name].grad
+            acc = tot["enc" if name.startswith("features.") else "dec"]
+            acc[0] += float((p.grad.cpu().double() - g64).norm() ** 2)
+            acc[1] += float((osd[name].grad.double() - g64).norm() ** 2)
+            acc[2] += float(g64.norm() ** 2)
             scale = float(g64.abs().max()) + 1e-30
             e_hip = float((p.grad.cpu().double() - g64).abs().median()) / scale
             e_cpu = float((osd[name].grad.double() - g64).abs().median()) / scale
@@ -132,6 +144,13 @@ def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
             if not name.startswith("features."):
                 assert e_hip <= 10 * e_cpu + 1e-6, "%s: median HIP err %.3g vs CPU-fp32 err %.3g (relative to max|grad|)" % (name, e_hip, e_cpu)
         print("worst HIP/CPU-fp32 median gradient error ratio vs fp64: %.2f" % worst)
+        # the 26 encoder tensors (88 % of the FLOPs, all on the Winograd kernels) as ONE vector, and the decoder likewise: relative
+        # L2 error against fp64 no worse than 1.5x PyTorch-CPU fp32's own + 2e-3 (a flipped ReLU mask moves single channels by
+        # percents -- see the module docstring -- but not the aggregate; at 2 x 64 x 96 one flip on a 4 x 6 map is 0.5 %: + 6e-3 there)
+        for part, (eh, ec, nr) in tot.items():
+            a_hip, a_cpu = (eh / nr) ** 0.5, (ec / nr) ** 0.5
+            print("%s gradient vs fp64: HIP %.3g, CPU-fp32 %.3g" % (part, a_hip, a_cpu))
+            assert a_hip <= 1.5 * a_cpu + (8e-3 if full else 2e-3), "%s: HIP %.3g vs PyTorch-CPU fp32 %.3g" % (part, a_hip, a_cpu)
     sd1 = net.state_dict()
     for key in ("features.features.1.running_mean", "features.features.1.running_var",
                 "features.features.41.running_mean", "features.features.41.running_var"):
