@@ -165,6 +165,193 @@ __global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const IgemmParam
   }
 }
 
+// =====================================================================================================================
+// Second generation of the three head kernels (r02) for the dense 3x3 / stride 1 / pad 1 heads with C % 16 == 0 -- all four
+// predict_disp layers of the DispNets.  What bounded the first generation was not HBM but the number of vector-memory
+// instructions (a CU retires about one per 40-60 cycles whatever its width): 9 neighbour fetches per (pixel, 4-channel group).
+//   forward   separable form  y[p] = sum_tap t_tap[p + off_tap],  t_tap[q] = <x[q], w[tap]>: a block reads an (8+2) x (64+2)
+//             input tile ONCE (64 contiguous bytes per thread), leaves the nine partial dot products in LDS and sums nine LDS
+//             words per output pixel.
+//   dgrad     one thread per pixel: 9 neighbour values of the 1-channel gradient, 16 channels x 9 taps of FMAs from LDS-broadcast
+//             weights, whole-pixel stores.
+//   wgrad     dW[tap][c] = sum_q dy[q - off_tap] x[q][c] as 16x16x4 MFMAs (rows = taps, columns = 16 channels, contraction over
+//             pixels): a wave stages 64 pixels of x (float4 loads) and the three gradient rows it needs in LDS and feeds both
+//             operands from there -- 5 global + ~36 LDS instructions per 64 pixels instead of 40 global ones.
+// =====================================================================================================================
+constexpr int kH2TY = 8, kH2TX = 64, kH2LD = kH2TX + 4;          // forward tile; LDS row of a t plane (66 used)
+
+__global__ void __launch_bounds__(256) head_fwd2_kernel(const IgemmParams p, int tilesX, int tilesY) {
+  extern __shared__ float sm[];
+  const KOperand& S = p.in[0];
+  const int C = S.C;
+  float* wsm = sm;                                   // [9][C]
+  float* t = sm + 9 * C;                             // [9][kH2TY + 2][kH2LD]
+  for (int i = threadIdx.x; i < 9 * C; i += 256) wsm[i] = p.w[i];
+  int b = blockIdx.x;
+  const int tx = b % tilesX;
+  b /= tilesX;
+  const int ty = b % tilesY, n = b / tilesY;
+  const int y0 = ty * kH2TY, x0 = tx * kH2TX;
+  __syncthreads();
+  constexpr int IN_W = kH2TX + 2, IN_N = (kH2TY + 2) * IN_W;
+  for (int idx = threadIdx.x; idx < IN_N; idx += 256) {
+    const int r = idx / IN_W, ci = idx - r * IN_W;
+    const int iy = y0 - 1 + r, ix = x0 - 1 + ci;
+    float tj[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) tj[j] = 0.f;
+    if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+      const float* xp = S.p + (long long)n * S.sn + (long long)iy * S.sh + (long long)ix * S.sw;
+      for (int c0 = 0; c0 < C; c0 += 16) {
+        f32x4 xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const f32x4*>(xp + c0 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          float a = tj[j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + c0 + 4 * q);       // same address in every lane: broadcast
+            a += xv[q][0] * w[0] + xv[q][1] * w[1] + xv[q][2] * w[2] + xv[q][3] * w[3];
+          }
+          tj[j] = a;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) t[(j * (kH2TY + 2) + r) * kH2LD + ci] = tj[j];
+  }
+  __syncthreads();
+  const KResult& R = p.out[0];
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  for (int o = threadIdx.x; o < kH2TY * kH2TX; o += 256) {
+    const int oy = o / kH2TX, ox = o - oy * kH2TX;
+    const int gy = y0 + oy, gx = x0 + ox;
+    if (gy < p.GH && gx < p.GW) {
+      float acc = bias;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc += t[(j * (kH2TY + 2) + oy + 1 + p.tdy[j]) * kH2LD + ox + 1 + p.tdx[j]];
+      float v = head_act(acc, p.act, p.act_p0, p.act_p1);
+      float* op = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
+      if (R.accumulate) v += *op;
+      *op = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) head_dgrad2_kernel(const IgemmParams p, int Kp) {
+  extern __shared__ float wsm[];                     // [9][C]   (transposed on the way in)
+  const int C = p.Ntot;
+  for (int i = threadIdx.x; i < 9 * C; i += 256) {
+    const int c = i / 9, j = i - c * 9;
+    wsm[j * C + c] = p.w[(long long)c * Kp + j];
+  }
+  __syncthreads();
+  const KOperand& G = p.in[0];
+  const KResult& R = p.out[0];
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < p.M; pix += (long long)gridDim.x * 256) {
+    unsigned gx, gy;
+    const unsigned tq = fastdiv_dev((unsigned)pix, (unsigned)p.GW, p.mGW, &gx);
+    const int n = (int)fastdiv_dev(tq, (unsigned)p.GH, p.mGH, &gy);
+    float g[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int iy = (int)gy + p.tdy[j], ix = (int)gx + p.tdx[j];
+      const bool ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      g[j] = ok ? G.p[(long long)n * G.sn + (long long)iy * G.sh + (long long)ix * G.sw] : 0.f;
+    }
+    float* op = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
+    for (int c0 = 0; c0 < C; c0 += 16) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = R.accumulate ? *reinterpret_cast<const f32x4*>(op + c0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += g[j] * *reinterpret_cast<const f32x4*>(wsm + j * C + c0 + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(op + c0 + 4 * q) = acc[q];
+    }
+  }
+}
+
+constexpr int kH2MaxCG = 8;                           // C <= 128
+constexpr int kH2DLD = 68;                            // LDS row of the staged gradient rows (66 used)
+
+template <int CG>
+__global__ void __launch_bounds__(256) head_wgrad2_kernel(const IgemmParams p, float* __restrict__ slabs) {
+  __shared__ float xs[4][64 * 16];                    // per wave: 64 pixels x 16 channels
+  __shared__ float ds[4][4 * kH2DLD];                 // per wave: gradient rows y+1, y, y-1 (columns x0-1 .. x0+64) and a zero row
+  __shared__ float red[4][9][CG * 16];
+  const KOperand& S = p.in[0];
+  const int C = S.C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 4, j = lane & 15;
+  float* xw = xs[wave];
+  float* dw_ = ds[wave];
+  for (int i = lane; i < kH2DLD; i += 64) dw_[3 * kH2DLD + i] = 0.f;
+  // A operand (rows = taps): lane (tap = j, pixel sub-index k) reads dy[y - tdy][x - tdx] = staged row (1 - tdy... see below), col 1 + x - tdx
+  const bool tap_ok = j < 9;
+  const int tdy = tap_ok ? p.tdy[j] : 0, tdx = tap_ok ? p.tdx[j] : 0;
+  // staged rows: index 0 <-> gradient row y-1, 1 <-> y, 2 <-> y+1; dy row needed = y - tdy -> index 1 - tdy; invalid taps -> zero row 3
+  const int a_off = (tap_ok ? (1 - tdy) : 3) * kH2DLD + 1 + k - (tap_ok ? tdx : 0);
+  f32x4 acc[CG];
+#pragma unroll
+  for (int q = 0; q < CG; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int segX = (p.IW + 63) / 64;
+  const long long nseg = (long long)p.N * p.IH * segX;
+  for (long long sg = (long long)blockIdx.x * 4 + wave; sg < nseg; sg += (long long)gridDim.x * 4) {
+    const int sx = (int)(sg % segX);
+    const long long ty = sg / segX;
+    const int y = (int)(ty % p.IH), n = (int)(ty / p.IH);
+    const int x0 = sx * 64;
+    // ---- the three gradient rows (1-channel map [N][GH][GW]), columns x0-1 .. x0+64
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int gy = y - 1 + r;
+      const bool rok = (unsigned)gy < (unsigned)p.GH;
+      const float* row = p.g + ((long long)n * p.GH + (rok ? gy : 0)) * p.GW;
+      const int gx = x0 - 1 + lane;
+      dw_[r * kH2DLD + lane] = (rok && (unsigned)gx < (unsigned)p.GW) ? row[gx] : 0.f;
+      if (lane < 2) {
+        const int gx2 = x0 + 63 + lane;
+        dw_[r * kH2DLD + 64 + lane] = (rok && (unsigned)gx2 < (unsigned)p.GW) ? row[gx2] : 0.f;
+      }
+    }
+    const float* xrow = S.p + (long long)n * S.sn + (long long)y * S.sh;
+#pragma unroll
+    for (int q = 0; q < CG; ++q) {
+      // ---- 64 pixels x 16 channels of x into LDS: lane = (pixel 16 i + lane / 4, channel quad lane % 4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int px = 16 * i + (lane >> 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (x0 + px < p.IW) v = *reinterpret_cast<const f32x4*>(xrow + (long long)(x0 + px) * S.sw + q * 16 + 4 * (lane & 3));
+        *reinterpret_cast<f32x4*>(xw + px * 16 + 4 * (lane & 3)) = v;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = dw_[a_off + 4 * s];
+        const float b = xw[(4 * s + k) * 16 + j];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+      }
+    }
+  }
+  // ---- fold the four waves (fixed order), one slab [9][C] per block
+#pragma unroll
+  for (int q = 0; q < CG; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tap = 4 * k + r;
+      if (tap < 9) red[wave][tap][q * 16 + j] = acc[q][r];
+    }
+  __syncthreads();
+  float* slab = slabs + (long long)blockIdx.x * 9 * C;
+  for (int i = threadIdx.x; i < 9 * C; i += 256) {
+    const int tap = i / C, c = i - tap * C;
+    slab[i] = (red[0][tap][c] + red[1][tap][c]) + (red[2][tap][c] + red[3][tap][c]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------- dispatch
 static int log2_exact(int v) {
   for (int l = 0; l <= 6; ++l)
@@ -181,7 +368,22 @@ bool head_fwd_eligible(const dn_conv_desc* d, const IgemmParams& p) {
          plain_vec_operand(p.in[0]) && p.ph[0].ntaps * p.in[0].C * sizeof(float) <= 48 * 1024;
 }
 
+// the r02 kernels: 3x3 taps within +-1, stride 1, 16-aligned channels
+static bool head2_geometry(const IgemmParams& p, int C) {
+  if (knobs().no_head2 || p.ph[0].ntaps != 9 || C % 16 != 0 || C > 16 * kH2MaxCG || p.sy != 1 || p.sx != 1) return false;
+  for (int j = 0; j < 9; ++j)
+    if (p.tdy[j] < -1 || p.tdy[j] > 1 || p.tdx[j] < -1 || p.tdx[j] > 1) return false;
+  return true;
+}
+
 int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
+  if (head2_geometry(p, p.in[0].C) && p.GH == p.IH && p.GW == p.IW) {
+    const int tilesX = (p.GW + kH2TX - 1) / kH2TX, tilesY = (p.GH + kH2TY - 1) / kH2TY;
+    const size_t lds = (size_t)(9 * p.in[0].C + 9 * (kH2TY + 2) * kH2LD) * sizeof(float);
+    hipLaunchKernelGGL(head_fwd2_kernel, dim3(p.N * tilesX * tilesY), dim3(256), lds, stream, p, tilesX, tilesY);
+    set_last_kernel("dn::head_fwd2_kernel");
+    return check_launch("head_fwd2_kernel");
+  }
   const int LG = log2_exact(p.in[0].C / 4);
   const int px = 256 >> LG;
   int hblocks = (p.M + px - 1) / px;
@@ -199,6 +401,13 @@ bool head_dgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
 }
 
 int launch_head_dgrad(const IgemmParams& p, hipStream_t stream) {
+  if (head2_geometry(p, p.Ntot)) {
+    long long hb = ((long long)p.M + 255) / 256;
+    if (hb > 4096) hb = 4096;
+    hipLaunchKernelGGL(head_dgrad2_kernel, dim3((int)hb), dim3(256), 9 * p.Ntot * sizeof(float), stream, p, p.ph[0].nchunks * kChunk);
+    set_last_kernel("dn::head_dgrad2_kernel");
+    return check_launch("head_dgrad2_kernel");
+  }
   const int LG = log2_exact(p.Ntot / 4);
   const int px = 256 >> LG;
   int hblocks = (p.M + px - 1) / px;
@@ -216,7 +425,32 @@ bool head_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p) {
 
 size_t head_wgrad_workspace_bytes(const IgemmParams& p) { return (size_t)kHeadSlabs * p.ph[0].ntaps * p.in[0].C * sizeof(float); }
 
+template <int CG>
+static void launch_head_wgrad2(const IgemmParams& p, float* workspace, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(head_wgrad2_kernel<CG>, dim3(blocks), dim3(256), 0, stream, p, workspace);
+}
+
 int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStream_t stream) {
+  const KOperand& S0 = p.in[0];
+  if (head2_geometry(p, S0.C) && p.GH == p.IH && p.GW == p.IW && S0.sw == S0.C) {
+    const long long nseg = (long long)p.N * p.IH * ((p.IW + 63) / 64);
+    int blocks = (int)((nseg + 3) / 4);
+    if (blocks > kHeadSlabs) blocks = kHeadSlabs;
+    switch (S0.C / 16) {
+      case 1: launch_head_wgrad2<1>(p, workspace, blocks, stream); break;
+      case 2: launch_head_wgrad2<2>(p, workspace, blocks, stream); break;
+      case 4: launch_head_wgrad2<4>(p, workspace, blocks, stream); break;
+      case 8: launch_head_wgrad2<8>(p, workspace, blocks, stream); break;
+      default: blocks = 0; break;
+    }
+    if (blocks > 0) {
+      set_last_kernel("dn::head_wgrad2_kernel");
+      int rc = check_launch("head_wgrad2_kernel");
+      if (rc != DN_OK) return rc;
+      hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(9 * S0.C), dim3(256), 0, stream, p, workspace, blocks, dw);
+      return check_launch("head_wgrad_reduce_kernel");
+    }
+  }
   const int LG = log2_exact(p.in[0].C / 4);
   const int px = 256 >> LG;
   const long long npix = (long long)p.N * p.IH * p.IW;

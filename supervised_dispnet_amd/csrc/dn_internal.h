@@ -17,7 +17,7 @@ static inline hipStream_t as_stream(dn_stream_t s) { return reinterpret_cast<hip
 // Tuning / test switches (DN_* environment variables), read ONCE and again only on dn_reload_knobs(): the conv entry points
 // consult a dozen of them per launch.
 struct Knobs {
-  bool no_winograd, no_winograd_wgrad, no_direct, no_stem, no_u32, no_bm64, no_thin, no_thin_conv, no_tile_store, no_splitk;
+  bool no_winograd, no_winograd_wgrad, no_direct, no_stem, no_u32, no_bm64, no_thin, no_thin_conv, no_tile_store, no_splitk, no_head2;
   int extra_lds;            // DN_DEBUG_EXTRA_LDS: bytes added to the tiled kernels' LDS request (lowers blocks per CU)
   int wino_dbg, wino_mtw, wino_wg_dbg;   // DN_WINO_DBG / DN_WINO_MTW / DN_WINO_WG_DBG: ablation variants (tools/wino_timing.py)
   unsigned long long wino_dbgptr;

@@ -91,6 +91,7 @@ static void read_knobs(Knobs* k) {
   k->no_thin_conv = on("DN_NO_THIN_CONV");
   k->no_tile_store = on("DN_NO_TILE_STORE");
   k->no_splitk = on("DN_NO_SPLITK");
+  k->no_head2 = on("DN_NO_HEAD2");
   k->extra_lds = num("DN_DEBUG_EXTRA_LDS", 0);
   k->wino_dbg = num("DN_WINO_DBG", 0);
   k->wino_mtw = num("DN_WINO_MTW", 1);
