@@ -120,6 +120,14 @@ int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d);
 /* Re-lay the framework weight tensor for desc->kind.  `w` is nn.Conv2d.weight [Cout][Cin][R][S] for DN_CONV_*,
  * nn.ConvTranspose2d.weight [Cin][Cout][R][S] for DN_CONVT_*.  Run once per optimizer step per kind. */
 int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed, dn_stream_t stream);
+/* Every weight re-lay of a training step in (at most) two launches.  The caller keeps a table of dn_pack_entry_bytes()-sized rows:
+ * dn_pack_entry_fill() writes one row on the HOST for (descriptor, framework weights, packed destination) and returns 1 for a
+ * Winograd-layout row, 0 for a direct-layout row (<0: error); the caller orders the rows direct-first, copies the table to the
+ * device once, and calls dn_pack_many(device table, #direct, #winograd, stream) after every optimizer step (same arithmetic as
+ * dn_conv_pack_weights per row; the pointers in the rows must still be valid). */
+int64_t dn_pack_entry_bytes(void);
+int dn_pack_entry_fill(const dn_conv_desc* d, const float* w, float* w_packed, void* entry_host);
+int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, dn_stream_t stream);
 /* Which packed layout dn_conv_pack_weights produces for this descriptor: 0 = implicit-GEMM [phase][Npad][K chunks], 1 = Winograd
  * F(2x2,3x3) transformed weights in MFMA fragment order (3x3 / stride 1 / pad 1 layers with 16-aligned channels and even
  * extents that fill the kernel's tiles).  The layout depends on the geometry, not only on the weights: a caller that caches
@@ -148,10 +156,11 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
 /* partial (sum, M2 about the tile mean) [rows][C][2] of the pre-bias conv result (128-row tiles, merged with the
  * parallel-variance update in fp64) -> batch mean / biased var, folded affine
  * (scale = gamma*invstd, shift = beta - mean*scale), running-stat update (momentum, unbiased var), save mean/invstd.
- * count = N*H*W.  training != 0.  */
+ * count = N*H*W.  training != 0.  num_batches_tracked (nullable): nn.BatchNorm2d's int64 step counter, incremented by one. */
 int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count, const float* conv_bias,
                    const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                   float eps, float* mean, float* invstd, float* scale, float* shift, dn_stream_t stream);
+                   float eps, float* mean, float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
+                   dn_stream_t stream);
 /* eval mode: scale/shift from running statistics. */
 int dn_bn_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, dn_stream_t stream);

@@ -51,6 +51,9 @@ SIGNATURES = {
     "dn_device_arch_ok": (C.c_int, []),
     "dn_conv_packed_weight_elems": (_i64, [_P(ConvDesc)]),
     "dn_conv_pack_weights": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
+    "dn_pack_entry_bytes": (_i64, []),
+    "dn_pack_entry_fill": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
+    "dn_pack_many": (C.c_int, [_vp, _i32, _i32, _vp]),
     "dn_conv_weight_layout": (_i32, [_P(ConvDesc)]),
     "dn_conv_bn_partial_rows": (_i32, [_P(ConvDesc)]),
     "dn_conv2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),
@@ -59,7 +62,7 @@ SIGNATURES = {
     "dn_convT2d_dgrad": (C.c_int, [_P(ConvDesc), _vp]),
     "dn_conv_wgrad_workspace_bytes": (_sz, [_P(ConvDesc)]),
     "dn_conv2d_wgrad": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp, _sz, _vp]),
-    "dn_bn_finalize": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "dn_bn_finalize": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dn_bn_eval_affine": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "dn_bn_relu_pool_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_maxpool2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

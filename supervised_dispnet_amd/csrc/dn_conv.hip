@@ -1451,7 +1451,7 @@ __device__ __forceinline__ long long packed_to_framework(const IgemmParams& p, c
   return base * rs + r * p.S + t;
 }
 
-__global__ void pack_weights_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, long long total) {
+__device__ __forceinline__ void pack_weights_body(const IgemmParams& p, const float* __restrict__ w, float* __restrict__ wp, long long total) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     int z = 0;
     while (z + 1 < p.nphases && idx >= p.ph[z + 1].w_off) ++z;
@@ -1462,6 +1462,15 @@ __global__ void pack_weights_kernel(const IgemmParams p, const float* __restrict
     const long long src = packed_to_framework(p, ph, n, k);
     wp[idx] = src >= 0 ? w[src] : 0.f;
   }
+}
+
+__global__ void pack_weights_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, long long total) {
+  pack_weights_body(p, w, wp, total);
+}
+
+__global__ void pack_weights_many_kernel(const PackEntry* __restrict__ tab) {
+  const PackEntry& e = tab[blockIdx.y];
+  pack_weights_body(e.p, e.w, e.wp, e.total);
 }
 
 __global__ void wgrad_reduce_kernel(const IgemmParams p, float* __restrict__ dw) {
@@ -1622,6 +1631,41 @@ static void choose_splits(IgemmParams* p) {
 using namespace dn;
 
 extern "C" {
+
+int64_t dn_pack_entry_bytes(void) { return (int64_t)sizeof(PackEntry); }
+
+int dn_pack_entry_fill(const dn_conv_desc* d, const float* w, float* w_packed, void* entry_host) {
+  DN_REQUIRE(d && w && w_packed && entry_host, DN_ERR_BAD_ARG, "dn_pack_entry_fill: null pointer");
+  PackEntry* e = reinterpret_cast<PackEntry*>(entry_host);
+  int rc = build_plan(d, false, &e->p);
+  if (rc != DN_OK) return rc;
+  e->w = w;
+  e->wp = w_packed;
+  if (wino_eligible(d, e->p)) {
+    e->wino = 1;
+    e->total = wino_packed_elems(e->p);
+    e->NS = ((e->p.Ntot + 63) / 64 * 64) / 32;
+  } else {
+    e->wino = 0;
+    const KPhase& last = e->p.ph[e->p.nphases - 1];
+    e->total = last.w_off + (long long)e->p.Npad * last.nchunks * kChunk;
+    e->NS = 0;
+  }
+  return e->wino;
+}
+
+int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, dn_stream_t stream) {
+  DN_REQUIRE(entries_dev && n_direct >= 0 && n_wino >= 0, DN_ERR_BAD_ARG, "dn_pack_many: bad argument");
+  const PackEntry* tab = reinterpret_cast<const PackEntry*>(entries_dev);
+  hipStream_t s = as_stream(stream);
+  if (n_direct > 0) {
+    hipLaunchKernelGGL(pack_weights_many_kernel, dim3(64, n_direct), dim3(256), 0, s, tab);
+    int rc = check_launch("pack_weights_many_kernel");
+    if (rc != DN_OK) return rc;
+  }
+  if (n_wino > 0) return launch_wino_pack_many(tab, n_direct, n_wino, s);
+  return DN_OK;
+}
 
 int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed, dn_stream_t stream) {
   IgemmParams p;

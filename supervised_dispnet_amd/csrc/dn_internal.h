@@ -110,6 +110,17 @@ static inline unsigned fastdiv_magic(unsigned d) { return d <= 1 ? 0xFFFFFFFFu :
 
 int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p);
 
+// one row of the batched weight re-lay table (dn_pack_entry_fill / dn_pack_many): everything a pack kernel takes as arguments
+struct PackEntry {
+  IgemmParams p;
+  const float* w;
+  float* wp;
+  long long total;      // elements the kernel walks (direct: packed elements; Winograd: wino_packed_elems)
+  int wino;             // 1: Winograd fragment-order transform, 0: direct [phase][Npad][K] layout
+  int NS;               // Winograd: Npad / 32
+};
+int launch_wino_pack_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream);
+
 // floor(n/d) on the device with the plan's magic (estimate is exact or one low; branch-free fix-up); *rem = n - q*d
 __device__ __forceinline__ unsigned fastdiv_dev(unsigned n, unsigned d, unsigned M, unsigned* rem) {
   unsigned q = __umulhi(n, M);

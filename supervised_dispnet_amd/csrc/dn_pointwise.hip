@@ -117,8 +117,9 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __re
                                                                const float* __restrict__ conv_bias, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* running_mean, float* running_var,
                                                                float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
-                                                               float* shift) {
+                                                               float* shift, long long* num_batches_tracked) {
   const int c = blockIdx.x;
+  if (num_batches_tracked != nullptr && c == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;   // nn.BatchNorm2d's step counter
   __shared__ double red[kThreads];
   __shared__ double s_mean;
   double s1 = 0.0;
@@ -355,6 +356,29 @@ __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __res
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) out[c] = (float)s;
+}
+
+// both BatchNorm-backward sums of a channel in one launch: out0[c] = sum_r partial[r][c][offset], out1[c] = sum_r partial[r][c][offset + 1]
+__global__ void __launch_bounds__(256) colsum2_finalize_kernel(const float* __restrict__ partial, int rows, int C, int stride, int offset,
+                                                               float* __restrict__ out0, float* __restrict__ out1) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = lane; r < rows; r += 64) {
+    const float* q = partial + ((long long)r * C + c) * stride + offset;
+    s0 += (double)q[0];
+    s1 += (double)q[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o);
+    s1 += __shfl_xor(s1, o);
+  }
+  if (lane == 0) {
+    out0[c] = (float)s0;
+    out1[c] = (float)s1;
+  }
 }
 
 __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(float* __restrict__ dz_dy, const float* __restrict__ y,
@@ -757,11 +781,12 @@ int32_t dn_reduce_blocks(int64_t rows, int32_t C) { return reduce_blocks(rows, C
 
 int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count, const float* conv_bias, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                   float* scale, float* shift, dn_stream_t stream) {
+                   float* scale, float* shift, int64_t* num_batches_tracked, dn_stream_t stream) {
   DN_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, DN_ERR_BAD_ARG,
              "dn_bn_finalize: bad argument");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, as_stream(stream), partial, rows, C, (double)count, conv_bias, gamma,
-                     beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                     beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                     reinterpret_cast<long long*>(num_batches_tracked));
   return check_launch("bn_finalize_kernel");
 }
 
@@ -815,8 +840,8 @@ int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply: need C%%4==0");
   DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: partial layout");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset + 1, dgamma);
+  hipLaunchKernelGGL(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
+                     dgamma);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, dz_dy, y, mean, invstd, gamma, dgamma, dbeta,
                      (long long)rows, C, (float)(1.0 / (double)rows));
   return check_launch("bn_bwd_apply");

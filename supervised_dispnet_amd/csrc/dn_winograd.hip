@@ -108,7 +108,7 @@ long long wino_packed_elems(const IgemmParams& p) { return (long long)(wino_ktot
 // ------------------------------------------------------------------------------------------------ weight transform
 // wp[k/8][pos][n/32][lane][e] = U_pos[n][k],  k = 8*(k/8) + 4*(lane >> 5) + e,  n = 32*(n/32) + (lane & 31):  exactly the
 // float4 a lane feeds to four consecutive v_mfma_f32_32x32x2_f32 as the B operand (the two half-waves hold k 0-3 / 4-7).
-__global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
+__device__ __forceinline__ void wino_pack_body(const IgemmParams& p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
   // one thread per (8-k group, 32-cout group, lane, e) = one (n, k) pair: 9 weight loads, all 16 positions written
   const long long npairs = total >> 4;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < npairs; idx += (long long)gridDim.x * blockDim.x) {
@@ -164,6 +164,21 @@ __global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ 
       dst[(long long)(4 * i + 3) * NS * 256] = u3;
     }
   }
+}
+
+__global__ void wino_pack_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
+  wino_pack_body(p, w, wp, NS, total);
+}
+
+// every Winograd layer of a step in ONE launch: blockIdx.y walks the table (dn_pack_many), x is the per-entry grid-stride
+__global__ void wino_pack_many_kernel(const PackEntry* __restrict__ tab) {
+  const PackEntry& e = tab[blockIdx.y];
+  wino_pack_body(e.p, e.w, e.wp, e.NS, e.total);
+}
+
+int launch_wino_pack_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(wino_pack_many_kernel, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
+  return check_launch("wino_pack_many_kernel");
 }
 
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream) {

@@ -185,6 +185,17 @@ class stream_scope(object):
         return False
 
 
+def _nbt_ptr(bn):
+    """nn.BatchNorm2d.num_batches_tracked (int64 scalar on the device, bumped inside dn_bn_finalize) or None when untracked."""
+    t = getattr(bn, "num_batches_tracked", None)
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.int64:
+        t += 1
+        return None
+    return t.data_ptr()
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 
@@ -326,25 +337,106 @@ class ConvLayer:
         return d
 
     def packed(self, kind, desc):
-        """Packed weights for `kind`, re-laid only when the parameter changed."""
+        """Packed weights for `kind`, re-laid only when the parameter changed.  Every (layer, kind, layout) re-lay is also entered
+        in the device's PackTable, so that from the second optimizer step on ALL of them run as one batched launch at the start of
+        the forward pass (prepack_all) and this method only hands out the buffers."""
         w = self.m.weight
         lib = _lib.load()
         layout = lib.dn_conv_weight_layout(C.byref(desc))     # direct or Winograd: depends on the geometry of this call
-        key = (w.data_ptr(), w._version, PARAM_EPOCH, tuple(desc.in_[i].C for i in range(desc.n_in)),
-               tuple(desc.out[i].C for i in range(desc.n_out)))
+        split = (tuple(desc.in_[i].C for i in range(desc.n_in)), tuple(desc.out[i].C for i in range(desc.n_out)))
+        key = (w.data_ptr(), w._version, PARAM_EPOCH) + split
         hit = self._packed.get((kind, layout))
         if hit is not None and hit[0] == key:
+            return hit[1]
+        table = pack_table(w.device) if w.is_cuda else None
+        if table is not None and hit is not None and hit[0][:2] + hit[0][3:] == key[:2] + key[3:] and table.fresh(hit[1], PARAM_EPOCH):
+            self._packed[(kind, layout)] = (key, hit[1])      # re-laid by the batched launch of this epoch
             return hit[1]
         n = lib.dn_conv_packed_weight_elems(C.byref(desc))
         if n < 0:
             raise _lib.DispnetHipError("dn_conv_packed_weight_elems: " + _lib.last_error())
-        buf = torch.empty(max(int(n), 1), dtype=torch.float32, device=w.device)
+        n = max(int(n), 1)
+        buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else torch.empty(n, dtype=torch.float32, device=w.device)
         wc = w.detach()
-        if not wc.is_contiguous():
+        contiguous = wc.is_contiguous()
+        if not contiguous:
             wc = wc.contiguous()
         _lib.call("dn_conv_pack_weights", C.byref(desc), wc.data_ptr(), buf.data_ptr(), _stream())
         self._packed[(kind, layout)] = (key, buf)
+        if table is not None and contiguous:
+            table.register((id(self), kind, layout) + split, desc, w, buf)
         return buf
+
+
+class PackTable(object):
+    """All weight re-lays of a training step as ONE batched launch (dn_pack_many) instead of ~53 launches of 6-8 us each.
+    Rows are collected the first time a (layer, kind, layout) is packed the ordinary way; the table is uploaded when it changed and
+    replayed at the start of the first forward after every optimizer step.  A row is dropped when its weight tensor moved."""
+    MAX_ROWS = 512
+
+    def __init__(self, device):
+        self.device = device
+        self.rows = {}                  # key -> [entry bytes, wino flag, weight tensor, packed buffer, weight ptr]
+        self.dirty = True
+        self.dev_table = None
+        self.counts = (0, 0)
+        self.epoch = -1                 # PARAM_EPOCH whose weights the buffers of `covered` hold
+        self.covered = set()
+        self.esize = int(_lib.load().dn_pack_entry_bytes())
+
+    def register(self, key, desc, w, buf):
+        if len(self.rows) >= self.MAX_ROWS:
+            self.rows.clear()
+        entry = (C.c_char * self.esize)()
+        wino = _lib.load().dn_pack_entry_fill(C.byref(desc), w.data_ptr(), buf.data_ptr(), entry)
+        if wino < 0:
+            raise _lib.DispnetHipError("dn_pack_entry_fill: " + _lib.last_error())
+        self.rows[key] = [bytes(entry), int(wino), w, buf, w.data_ptr()]
+        self.dirty = True
+
+    def fresh(self, buf, epoch):
+        return self.epoch == epoch and buf.data_ptr() in self.covered
+
+    def run(self, epoch):
+        """Re-lay every registered row from the current weights (called once per optimizer step, before the forward)."""
+        if self.epoch == epoch or not self.rows:
+            return
+        stale = [k for k, r in self.rows.items() if r[2].data_ptr() != r[4]]
+        for k in stale:
+            del self.rows[k]
+            self.dirty = True
+        if not self.rows:
+            return
+        if self.dirty:
+            direct = [r for r in self.rows.values() if r[1] == 0]
+            wino = [r for r in self.rows.values() if r[1] == 1]
+            blob = b"".join(r[0] for r in direct + wino)
+            self.dev_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+            self.counts = (len(direct), len(wino))
+            self.covered = {r[3].data_ptr() for r in direct + wino}
+            self.dirty = False
+        _lib.call("dn_pack_many", self.dev_table.data_ptr(), self.counts[0], self.counts[1], _stream())
+        self.epoch = epoch
+
+
+_PACK_TABLES = {}
+
+
+def pack_table(device):
+    t = _PACK_TABLES.get(device)
+    if t is None:
+        t = _PACK_TABLES[device] = PackTable(device)
+    return t
+
+
+def prepack_all(device):
+    """Start of a recorded forward pass: one batched re-lay of every packed weight the previous steps used (no-op when nothing
+    changed since the last call or DN_NO_PACK_TABLE is set)."""
+    if os.environ.get("DN_NO_PACK_TABLE"):
+        return
+    t = _PACK_TABLES.get(device)
+    if t is not None:
+        t.run(PARAM_EPOCH)
 
 
 def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None):
@@ -575,8 +667,7 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
         _lib.call("dn_bn_finalize", partial.data_ptr(), prow, Cn, y.rows, _ptr(layer.m.bias.detach()) if layer.m.bias is not None else None,
                   bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                   bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps, y.mean.data_ptr(), y.invstd.data_ptr(),
-                  y.scale.data_ptr(), y.shift.data_ptr(), _stream())
-        bn.num_batches_tracked += 1
+                  y.scale.data_ptr(), y.shift.data_ptr(), _nbt_ptr(bn), _stream())
     else:
         _lib.call("dn_bn_eval_affine", Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                   bn.running_var.data_ptr(), bn.eps, y.scale.data_ptr(), y.shift.data_ptr(), _stream())
@@ -663,8 +754,7 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
         _lib.call("dn_bn_finalize", partial.data_ptr(), prow, Cn, y.rows, _ptr(layer.m.bias.detach()) if layer.m.bias is not None else None,
                   stat_bn.weight.data_ptr(), stat_bn.bias.data_ptr(), stat_bn.running_mean.data_ptr(), stat_bn.running_var.data_ptr(),
                   stat_bn.momentum if stat_bn.momentum is not None else BN_MOMENTUM, stat_bn.eps, scratch[0].data_ptr(),
-                  scratch[1].data_ptr(), scratch[2].data_ptr(), scratch[3].data_ptr(), _stream())
-        stat_bn.num_batches_tracked += 1
+                  scratch[1].data_ptr(), scratch[2].data_ptr(), scratch[3].data_ptr(), _nbt_ptr(stat_bn), _stream())
 
     def backward():
         if y.grad is None:

@@ -77,6 +77,8 @@ class HipNetFunction(torch.autograd.Function):
         sink = engine.GradSink()
         in_acts = [engine.Act.from_nchw(x, needs_grad=recording and ctx.needs_input_grad[3 + i]) for i, x in enumerate(inputs)]
         with engine.stream_scope():
+            if inputs:
+                engine.prepack_all(inputs[0].device)
             outs = net._hip_forward(tape, sink, *in_acts)     # list[Act]
         ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
         results = tuple(a.t if a.planar else (a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2)) for a in outs)

