@@ -186,6 +186,19 @@ int dn_bn_relu_bwd_reduce(float* da_dz, const float* y, const float* scale, cons
 int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset, int64_t rows,
                     int32_t C, float* dgamma, float* dbeta, dn_stream_t stream);
+/* The two passes above without a materialised dz: the *_sums calls only produce the partial sums (no full-size write), and the
+ * apply_* calls re-derive dz on the fly -- from da and the ReLU mask (y*scale+shift > 0; `da_dy` is overwritten with dy), or from
+ * the pooled gradient and the arg-max codes (`dy` [N,H,W,C] is written; the sparse full-resolution dz of a max-pool never exists). */
+int dn_bn_relu_bwd_sums(const float* da, const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        int64_t rows, int32_t C, float* partial, dn_stream_t stream);
+int dn_bn_relu_pool_bwd_sums(const float* dpooled, const uint8_t* idx, const float* y, const float* mean, const float* invstd, int32_t N,
+                             int32_t H, int32_t W, int32_t C, float* partial, dn_stream_t stream);
+int dn_bn_bwd_apply_relu(float* da_dy, const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                         const float* gamma, const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset,
+                         int64_t rows, int32_t C, float* dgamma, float* dbeta, dn_stream_t stream);
+int dn_bn_bwd_apply_pool(const float* dpooled, const uint8_t* idx, const float* y, const float* mean, const float* invstd, const float* gamma,
+                         const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset, int32_t N, int32_t H,
+                         int32_t W, int32_t C, float* dy, float* dgamma, float* dbeta, dn_stream_t stream);
 int32_t dn_reduce_blocks(int64_t rows, int32_t C);   /* rows of `partial` the reduce kernels above write */
 
 /* g_pre = g * act'(.) in place, using the stored POST-activation tensor y_post; also per-channel partial sums

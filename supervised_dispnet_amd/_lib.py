@@ -65,6 +65,10 @@ SIGNATURES = {
     "dn_bn_finalize": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dn_bn_eval_affine": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "dn_bn_relu_pool_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_bn_relu_bwd_sums": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "dn_bn_relu_pool_bwd_sums": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_bn_bwd_apply_relu": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "dn_bn_bwd_apply_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "dn_maxpool2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "dn_bn_relu_pool_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dn_bn_relu_bwd_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),

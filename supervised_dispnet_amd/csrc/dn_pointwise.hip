@@ -281,13 +281,16 @@ struct PoolBwdOp {
         acc[e][1] += g * (yv - mu.v[e]) * is.v[e];
       }
     }
+    if (dz != nullptr) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) stv<V>(dz + base + ((long long)(q >> 1) * W + (q & 1)) * C, out[q]);
+      for (int q = 0; q < 4; ++q) stv<V>(dz + base + ((long long)(q >> 1) * W + (q & 1)) * C, out[q]);
+    }
   }
 };
 
 struct BnReluBwdOp {
   static constexpr int NACC = 2;
+  int write;                      // 0: sums only (the apply pass re-derives the mask from y, dn_bn_bwd_apply_relu)
   float* da_dz;
   const float* y;
   const float* scale;
@@ -307,7 +310,7 @@ struct BnReluBwdOp {
       acc[e][0] += dz;
       acc[e][1] += dz * (yv.v[e] - mu.v[e]) * is.v[e];
     }
-    stv<V>(da_dz + o, g);
+    if (write) stv<V>(da_dz + o, g);
   }
 };
 
@@ -401,6 +404,73 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(float* __restric
       dz[e] = ga[e] * is[e] * (dz[e] - db[e] * inv_count - xhat * dg[e] * inv_count);
     }
     *reinterpret_cast<f32x4*>(dz_dy + o) = dz;
+  }
+}
+
+// The same BatchNorm backward with the ReLU mask / the max-pool routing RE-DERIVED here instead of read back from a materialised dz:
+// the reduce pass then only produces the two sums (no full-size write), and after a pool the sparse full-resolution dz never exists.
+//   relu:  dz = da * (y*scale+shift > 0)                                   (da is overwritten with dy)
+//   pool:  dz[n, 2py+a, 2px+b, c] = dpooled[n,py,px,c] if idx says (a,b) is the arg-max and the pooled value was > 0, else 0
+__global__ void __launch_bounds__(kThreads) bn_bwd_apply_relu_kernel(float* __restrict__ da_dy, const float* __restrict__ y,
+                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                                     const float* __restrict__ dbeta, long long rows, int C, float inv_count) {
+  const int G = C / 4;
+  const long long total = rows * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int c = (int)(i % G) * 4;
+    const long long o = i * 4;
+    f32x4 dz = *reinterpret_cast<const f32x4*>(da_dy + o);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), dg = *reinterpret_cast<const f32x4*>(dgamma + c),
+                db = *reinterpret_cast<const f32x4*>(dbeta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = (yv[e] * sc[e] + sh[e] > 0.f) ? dz[e] : 0.f;
+      const float xhat = (yv[e] - mu[e]) * is[e];
+      dz[e] = ga[e] * is[e] * (z - db[e] * inv_count - xhat * dg[e] * inv_count);
+    }
+    *reinterpret_cast<f32x4*>(da_dy + o) = dz;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) bn_bwd_apply_pool_kernel(const float* __restrict__ dpooled, const uint8_t* __restrict__ idx,
+                                                                     const float* __restrict__ y, const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int N,
+                                                                     int H, int W, int C, float inv_count, float* __restrict__ dy) {
+  const int G = C / 4, PH = H / 2, PW = W / 2;
+  const long long total = (long long)N * PH * PW * G;
+  for (long long i = blockIdx.x * (long long)kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int g = (int)(i % G);
+    long long pix = i / G;
+    const int px = (int)(pix % PW);
+    pix /= PW;
+    const int py = (int)(pix % PH), n = (int)(pix / PH);
+    const int c = g * 4;
+    const f32x4 dp = *reinterpret_cast<const f32x4*>(dpooled + i * 4);
+    const uchar4 code = *reinterpret_cast<const uchar4*>(idx + i * 4);
+    const int cd[4] = {code.x, code.y, code.z, code.w};
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), dg = *reinterpret_cast<const f32x4*>(dgamma + c),
+                db = *reinterpret_cast<const f32x4*>(dbeta + c);
+    const long long base = (((long long)n * H + 2 * py) * W + 2 * px) * C + c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long o = base + ((long long)(q >> 1) * W + (q & 1)) * C;
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+      f32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = ((cd[e] & 4) && (cd[e] & 3) == q) ? dp[e] : 0.f;
+        const float xhat = (yv[e] - mu[e]) * is[e];
+        out[e] = ga[e] * is[e] * (z - db[e] * inv_count - xhat * dg[e] * inv_count);
+      }
+      *reinterpret_cast<f32x4*>(dy + o) = out;
+    }
   }
 }
 
@@ -825,12 +895,63 @@ int dn_bn_relu_pool_bwd(const float* dpooled, const uint8_t* idx, const float* y
   return launch_colreduce(op, (long long)N * (H / 2) * (W / 2), C, partial, as_stream(stream), "bn_relu_pool_bwd");
 }
 
+int dn_bn_relu_pool_bwd_sums(const float* dpooled, const uint8_t* idx, const float* y, const float* mean, const float* invstd, int32_t N,
+                             int32_t H, int32_t W, int32_t C, float* partial, dn_stream_t stream) {
+  DN_REQUIRE(dpooled && idx && y && mean && invstd && partial, DN_ERR_BAD_ARG, "dn_bn_relu_pool_bwd_sums: null pointer");
+  DN_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, DN_ERR_UNSUPPORTED, "dn_bn_relu_pool_bwd_sums: need C%%4==0 and even H,W");
+  PoolBwdOp op{dpooled, idx, y, mean, invstd, nullptr, H / 2, W / 2, H, W, C};
+  return launch_colreduce(op, (long long)N * (H / 2) * (W / 2), C, partial, as_stream(stream), "bn_relu_pool_bwd_sums");
+}
+
 int dn_bn_relu_bwd_reduce(float* da_dz, const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
                           int64_t rows, int32_t C, float* partial, dn_stream_t stream) {
   DN_REQUIRE(da_dz && y && scale && shift && mean && invstd && partial && rows > 0 && C > 0, DN_ERR_BAD_ARG,
              "dn_bn_relu_bwd_reduce: bad argument");
-  BnReluBwdOp op{da_dz, y, scale, shift, mean, invstd, C};
+  BnReluBwdOp op{1, da_dz, y, scale, shift, mean, invstd, C};
   return launch_colreduce(op, rows, C, partial, as_stream(stream), "bn_relu_bwd_reduce");
+}
+
+int dn_bn_relu_bwd_sums(const float* da, const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        int64_t rows, int32_t C, float* partial, dn_stream_t stream) {
+  DN_REQUIRE(da && y && scale && shift && mean && invstd && partial && rows > 0 && C > 0, DN_ERR_BAD_ARG, "dn_bn_relu_bwd_sums: bad argument");
+  BnReluBwdOp op{0, const_cast<float*>(da), y, scale, shift, mean, invstd, C};
+  return launch_colreduce(op, rows, C, partial, as_stream(stream), "bn_relu_bwd_sums");
+}
+
+static int bn_bwd_sums_to_params(const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset, int32_t C,
+                                 float* dgamma, float* dbeta, hipStream_t s, const char* who) {
+  DN_REQUIRE(partial && dgamma && dbeta && partial_rows > 0, DN_ERR_BAD_ARG, "%s: bad argument", who);
+  DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "%s: need C%%4==0", who);
+  DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "%s: partial layout", who);
+  hipLaunchKernelGGL(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
+                     dgamma);
+  return DN_OK;
+}
+
+int dn_bn_bwd_apply_relu(float* da_dy, const float* y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                         const float* gamma, const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset,
+                         int64_t rows, int32_t C, float* dgamma, float* dbeta, dn_stream_t stream) {
+  DN_REQUIRE(da_dy && y && scale && shift && mean && invstd && gamma && rows > 0, DN_ERR_BAD_ARG, "dn_bn_bwd_apply_relu: bad argument");
+  hipStream_t s = as_stream(stream);
+  int rc = bn_bwd_sums_to_params(partial, partial_rows, partial_stride, partial_offset, C, dgamma, dbeta, s, "dn_bn_bwd_apply_relu");
+  if (rc != DN_OK) return rc;
+  hipLaunchKernelGGL(bn_bwd_apply_relu_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean, invstd, gamma,
+                     dgamma, dbeta, (long long)rows, C, (float)(1.0 / (double)rows));
+  return check_launch("bn_bwd_apply_relu");
+}
+
+int dn_bn_bwd_apply_pool(const float* dpooled, const uint8_t* idx, const float* y, const float* mean, const float* invstd, const float* gamma,
+                         const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset, int32_t N, int32_t H,
+                         int32_t W, int32_t C, float* dy, float* dgamma, float* dbeta, dn_stream_t stream) {
+  DN_REQUIRE(dpooled && idx && y && mean && invstd && gamma && dy && N > 0, DN_ERR_BAD_ARG, "dn_bn_bwd_apply_pool: bad argument");
+  DN_REQUIRE(H % 2 == 0 && W % 2 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply_pool: need even H, W");
+  hipStream_t s = as_stream(stream);
+  int rc = bn_bwd_sums_to_params(partial, partial_rows, partial_stride, partial_offset, C, dgamma, dbeta, s, "dn_bn_bwd_apply_pool");
+  if (rc != DN_OK) return rc;
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, s, dpooled, idx, y, mean, invstd, gamma, dgamma, dbeta, N,
+                     H, W, C, (float)(1.0 / ((double)N * H * W)), dy);
+  return check_launch("bn_bwd_apply_pool");
 }
 
 int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float* invstd, const float* gamma, const float* partial,

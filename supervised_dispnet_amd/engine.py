@@ -35,6 +35,9 @@ PARAM_EPOCH = 0
 # for every implicit-GEMM launch, bracketed with HIP events on the launch stream.  None = off (zero overhead).
 PROFILE = None
 
+# DN_BN_MATERIALIZE=1: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back) for A/B runs and the equivalence test
+BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
+
 # True while graph.GraphedStep records a step into a hipGraph (nothing in the engine may synchronise or time launches then)
 CAPTURING = False
 
@@ -209,7 +212,7 @@ def require_cuda(t, what):
 class Act:
     """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
     __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
-                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar")
+                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar", "pool_src")
 
     def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
         self.t = t
@@ -222,6 +225,8 @@ class Act:
         self.partial_stride, self.partial_offset = 2, 0
         self.no_relu = False            # pending BatchNorm affine WITHOUT ReLU (bottleneck bn3 / downsample BN): only
                                         # block_bn_add_relu may consume it
+        self.pool_src = None            # (dpooled, idx): the gradient arrives through a 2x2 max-pool and is expanded by the BatchNorm
+                                        # backward itself (dn_bn_bwd_apply_pool); .grad is then only the destination buffer
         self.planar = False             # .t is [N,C,H,W] (a network OUTPUT the caller's API wants planar: ord_c1, decode_c)
         self.needs_grad = needs_grad
         self.strides = strides or (H * W * C, W * C, C, 1)   # (n, h, w, c) element strides
@@ -677,15 +682,21 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
             return
         g = y.grad
         if training:
-            if not y.grad_is_dz:
+            relu_pending = not y.grad_is_dz           # g is dL/d(relu output): the mask is applied by the kernels below
+            if relu_pending:
                 if y.no_relu:
                     raise RuntimeError("a ReLU-less BatchNorm output must be consumed by block_bn_add_relu")
                 nblk = _lib.load().dn_reduce_blocks(y.rows, Cn)
                 y.partial = torch.empty((nblk, Cn, 2), dtype=torch.float32, device=dev)
                 y.partial_rows = nblk
-                hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 12, "dn_bn_relu_bwd_reduce", g.data_ptr(),
-                         y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
-                         y.partial.data_ptr(), _stream())
+                if BN_MATERIALIZE_DZ:
+                    hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 12, "dn_bn_relu_bwd_reduce", g.data_ptr(),
+                             y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
+                             y.partial.data_ptr(), _stream())
+                else:                                 # sums only: the apply pass re-derives the mask from y (one full-size write less)
+                    hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 8, "dn_bn_relu_bwd_sums", g.data_ptr(),
+                             y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
+                             y.partial.data_ptr(), _stream())
             # written straight into the optimizer arena's gradient slices when there is one (no copy launches)
             dgamma = sink.dest(bn.weight)
             dbeta = sink.dest(bn.bias)
@@ -693,9 +704,22 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
                 dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
             if dbeta is None:
                 dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
-            hbm_call("dn::bn_bwd_apply_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
-                     y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride,
-                     y.partial_offset, y.rows, Cn, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
+            if y.pool_src is not None:                # gradient through the 2x2 max-pool: expanded here, never materialised as dz
+                dpooled, pidx = y.pool_src
+                hbm_call("dn::bn_bwd_apply_pool_kernel", y.rows * Cn * 8 + y.rows * Cn * 5 // 4, "dn_bn_bwd_apply_pool", dpooled.data_ptr(),
+                         pidx.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(),
+                         y.partial_rows, y.partial_stride, y.partial_offset, y.N, y.H, y.W, Cn, g.data_ptr(), dgamma.data_ptr(),
+                         dbeta.data_ptr(), _stream())
+                y.pool_src = None
+            elif relu_pending and not BN_MATERIALIZE_DZ:
+                hbm_call("dn::bn_bwd_apply_relu_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply_relu", g.data_ptr(), y_t.data_ptr(),
+                         y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(),
+                         y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn, dgamma.data_ptr(),
+                         dbeta.data_ptr(), _stream())
+            else:
+                hbm_call("dn::bn_bwd_apply_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
+                         y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride,
+                         y.partial_offset, y.rows, Cn, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
             sink.put(bn.weight, dgamma)
             sink.put(bn.bias, dbeta)
         else:
@@ -729,9 +753,17 @@ def block_pool(tape, y):
         y.partial_rows = nblk
         y.grad = y.new_like()
         y.grad_is_dz = True
-        hbm_call("dn::colreduce_kernel<dn::PoolBwdOp, 4>", y.rows * y.C * 4 * 2.25 + y.rows * y.C // 4, "dn_bn_relu_pool_bwd",
-                 p.grad.data_ptr(), idx.data_ptr(), y.t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.N, y.H, y.W, y.C,
-                 y.grad.data_ptr(), y.partial.data_ptr(), _stream())
+        if BN_MATERIALIZE_DZ:
+            hbm_call("dn::colreduce_kernel<dn::PoolBwdOp, 4>", y.rows * y.C * 4 * 2.25 + y.rows * y.C // 4, "dn_bn_relu_pool_bwd",
+                     p.grad.data_ptr(), idx.data_ptr(), y.t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.N, y.H, y.W, y.C,
+                     y.grad.data_ptr(), y.partial.data_ptr(), _stream())
+        else:
+            # sums only; the BatchNorm backward of the producing layer (block_conv_bn) expands (dpooled, idx) into dy in ITS pass:
+            # the full-resolution dz (three quarters zeros) is never written nor read back
+            hbm_call("dn::colreduce_kernel<dn::PoolBwdOp, 4>", y.rows * y.C * 4 * 1.25 + y.rows * y.C // 4, "dn_bn_relu_pool_bwd_sums",
+                     p.grad.data_ptr(), idx.data_ptr(), y.t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.N, y.H, y.W, y.C,
+                     y.partial.data_ptr(), _stream())
+            y.pool_src = (p.grad, idx)
         p.grad = None
 
     tape.push(backward)

@@ -82,3 +82,23 @@ def test_graph_replay_is_bitwise_the_eager_step(batch, h, w):
         assert torch.allclose(sg[k].float(), se[k].float(), rtol=1e-5, atol=2e-7), k
     # the optimizer state round-trips with the device-side counter
     assert opt_g.state_dict()["step"] == 7
+
+
+def test_bn_backward_without_materialised_dz_is_bitwise_the_two_pass_form(monkeypatch):
+    """engine.BN_MATERIALIZE_DZ: the reduce pass that only produces the sums + the apply pass that re-derives the ReLU mask / expands
+    the max-pool routing (dn_bn_relu_bwd_sums, dn_bn_relu_pool_bwd_sums, dn_bn_bwd_apply_relu, dn_bn_bwd_apply_pool) is the same
+    arithmetic as the r01 form that writes dz and reads it back: every gradient of a Disp_vgg_BN step agrees bit for bit."""
+    from supervised_dispnet_amd import engine
+    img, gt = bench.synthetic_batch(4, 128, 416, DEV, 3)
+    grads = {}
+    for mode in (False, True):
+        monkeypatch.setattr(engine, "BN_MATERIALIZE_DZ", mode)
+        net, opt = _make()
+        depth = [reciprocal(d) for d in net(img)]
+        loss = LF.l1_loss(gt, depth, "kitti")
+        opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[mode] = (loss.item(), opt.arena.flat_g.clone())
+    assert grads[False][0] == grads[True][0]
+    assert torch.equal(grads[False][1], grads[True][1])
