@@ -298,6 +298,9 @@ def main():
             torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    import gc
+    gc.collect()
+    gc.disable()                 # a generational collection inside the timed loop stalls the launch thread for milliseconds
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -307,6 +310,7 @@ def main():
         marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
