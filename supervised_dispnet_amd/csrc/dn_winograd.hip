@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;
   const int mb = q / NT, nb = q % NT;
-  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, te1 = 0, te2 = 0;
   if (DBG & 4) t0 = clock64();
 
   // ---- staging role: one 4x4 patch of VW channels per thread and chunk: 64 tiles x 4 float4 groups, or 32 tiles x 8 float2
@@ -258,22 +258,17 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     pn = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
     py = 2 * (int)ty - 1;
     px = 2 * (int)tx - 1;
+    // outer product of a 4-bit row mask and a 4-bit column mask (the prologue's instructions are issued between the partner block's
+    // MFMAs, ~40 cycles apiece: 16 compare-and-or chains were 4 k ticks of it)
+    unsigned colm = 0, rowm = 0;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) colm |= ((unsigned)(px + b) < (unsigned)p.IW) ? (1u << b) : 0u;
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        pmask |= (t < p.T && (unsigned)(py + a) < (unsigned)p.IH && (unsigned)(px + b) < (unsigned)p.IW) ? (1u << (4 * a + b)) : 0u;
+    for (int a = 0; a < 4; ++a) rowm |= ((unsigned)(py + a) < (unsigned)p.IH) ? (1u << (4 * a)) : 0u;
+    pmask = t < p.T ? rowm * colm : 0u;        // bit 4a + b = row bit a AND column bit b
   }
 
-  f32x16 acc[4][MTW][2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-      for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][m][nn][e] = 0.f;
+  f32x16 acc[4][MTW][2];          // zeroed below, AFTER the first operand's patch loads have been issued (128 moves under their latency)
 
   // B fragments straight from the packed weights: wcur -> this wave's slice of the current 16-k chunk
   const int NS = p.Npad / 32;
@@ -380,6 +375,18 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
 #pragma unroll
       for (int i = 0; i < 16; ++i) load_v(i);
       load_aff();
+      if (s == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[j][m][nn][e] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) affine_piece(i);
 #pragma unroll
@@ -478,6 +485,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     }
   }
 
+  if (DBG & 4) te1 = clock64();
   // ---- batch statistics of the pre-bias result: partial row MTW*mb + m covers tiles [32(MTW*mb+m), +32) = 128 pixels;
   //      (sum, M2 about the group's own mean), merged by dn_bn_finalize
   const int n_first = nb * WBN + 4 * c4;
@@ -561,18 +569,26 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     }
   }
 
+  if (DBG & 4) te2 = clock64();
   // ---- bias, activation, channel-split / accumulating stores: float4 along the channels when the four columns lie in one
   //      float4-addressable result, element-wise otherwise (the 1-channel disparity piece of a concat's input gradient)
+  // Every vector instruction of this phase is issued between the PARTNER block's MFMAs (one slot per 64 cycles while it is in its main
+  // loop -- measured with DN_WINO_DBG=4/12: 11.4 k of the epilogue's 14 k ticks were spent here, with or without the stores), so the
+  // common case is kept to a minimum of instructions: one address per tile, constant offsets for its four pixels, the result
+  // selection / activation / accumulate decisions taken once, outside the loops.
   if (n_first < p.Ntot) {
     int seg = 0;
     if (p.n_out > 1 && n_first >= p.out[1].n_begin) seg = 1;
     if (p.n_out > 2 && n_first >= p.out[2].n_begin) seg = 2;
-    const KResult& R = p.out[seg];
-    const bool fast4 = (n_first + 3 < R.n_begin + R.C) && ((R.n_begin | R.C) & 3) == 0 && (R.sw & 3) == 0 &&
-                       (reinterpret_cast<uintptr_t>(R.p) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
-    float* obase = R.p + (n_first - R.n_begin);
-    const long long sw = R.sw;
-    const bool accumulate = R.accumulate != 0;
+    // (field-wise selects instead of p.out[seg]: a per-lane index into the kernel arguments costs a round trip to memory)
+    float* Rp = seg == 0 ? p.out[0].p : (seg == 1 ? p.out[1].p : p.out[2].p);
+    const long long sw = seg == 0 ? p.out[0].sw : (seg == 1 ? p.out[1].sw : p.out[2].sw);
+    const int Rbeg = seg == 0 ? p.out[0].n_begin : (seg == 1 ? p.out[1].n_begin : p.out[2].n_begin);
+    const int RC = seg == 0 ? p.out[0].C : (seg == 1 ? p.out[1].C : p.out[2].C);
+    const bool accumulate = (seg == 0 ? p.out[0].accumulate : (seg == 1 ? p.out[1].accumulate : p.out[2].accumulate)) != 0;
+    const bool fast4 = (n_first + 3 < Rbeg + RC) && ((Rbeg | RC) & 3) == 0 && (sw & 3) == 0 && (reinterpret_cast<uintptr_t>(Rp) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    float* obase = Rp + (n_first - Rbeg);
     f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr) {
       if (fast4) bias = *reinterpret_cast<const f32x4*>(p.bias + n_first);
@@ -581,49 +597,83 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
         for (int e = 0; e < 4; ++e) bias[e] = n_first + e < p.Ntot ? p.bias[n_first + e] : 0.f;
       }
     }
+    const bool plain = p.act == DN_ACT_NONE;
+    if (fast4) {
+      const long long rowB = (long long)p.OW * sw;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int t = mb * BT + tg + 16 * k;
-      if (t < p.T) {
-        unsigned tx, ty;
-        const unsigned r = fastdiv_dev((unsigned)t, (unsigned)p.TW, p.mTW, &tx);
-        const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
-        const long long pix0 = ((long long)n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx;
+      for (int k = 0; k < NK; ++k) {
+        const int t = mb * BT + tg + 16 * k;
+        if (t < p.T) {
+          unsigned tx, ty;
+          const unsigned r = fastdiv_dev((unsigned)t, (unsigned)p.TW, p.mTW, &tx);
+          const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
+          float* o00 = obase + (((long long)n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * sw;
+          f32x4 v[2][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const long long pix = pix0 + (long long)a * p.OW + b;
-            f32x4 val;
+            for (int b = 0; b < 2; ++b) {
+              v[a][b] = Y[k][a][b] + bias;
+              if (!plain) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = wino_act(Y[k][a][b][e] + bias[e], p.act, p.act_p0, p.act_p1);
-            if (fast4) {
-              float* o = obase + pix * sw;
-              if (accumulate) val += *reinterpret_cast<const f32x4*>(o);
-              *reinterpret_cast<f32x4*>(o) = val;
-            } else {
+                for (int e = 0; e < 4; ++e) v[a][b][e] = wino_act(v[a][b][e], p.act, p.act_p0, p.act_p1);
+              }
+            }
+          if (accumulate) {                 // second writer of a skip connection: the four loads go out together
+            const f32x4 g00 = *reinterpret_cast<const f32x4*>(o00), g01 = *reinterpret_cast<const f32x4*>(o00 + sw);
+            const f32x4 g10 = *reinterpret_cast<const f32x4*>(o00 + rowB), g11 = *reinterpret_cast<const f32x4*>(o00 + rowB + sw);
+            v[0][0] += g00;
+            v[0][1] += g01;
+            v[1][0] += g10;
+            v[1][1] += g11;
+          }
+          if (!(DBG & 8) || v[0][0][0] == 12345.678f) {      // DBG 8: ablation without the stores
+            *reinterpret_cast<f32x4*>(o00) = v[0][0];
+            *reinterpret_cast<f32x4*>(o00 + sw) = v[0][1];
+            *reinterpret_cast<f32x4*>(o00 + rowB) = v[1][0];
+            *reinterpret_cast<f32x4*>(o00 + rowB + sw) = v[1][1];
+          }
+        }
+      }
+    } else {
+      // element-wise: the four columns straddle results or are not float4-addressable (the 1-channel disparity piece of a concat's
+      // input gradient)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int t = mb * BT + tg + 16 * k;
+        if (t < p.T) {
+          unsigned tx, ty;
+          const unsigned r = fastdiv_dev((unsigned)t, (unsigned)p.TW, p.mTW, &tx);
+          const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
+          const long long pix0 = ((long long)n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const long long pix = pix0 + (long long)a * p.OW + b;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const int col = n_first + e;
                 if (col < p.Ntot) {
+                  const float val = wino_act(Y[k][a][b][e] + bias[e], p.act, p.act_p0, p.act_p1);
                   int sg = 0;
                   if (p.n_out > 1 && col >= p.out[1].n_begin) sg = 1;
                   if (p.n_out > 2 && col >= p.out[2].n_begin) sg = 2;
                   const KResult& Q = p.out[sg];
                   float* o = Q.p + pix * Q.sw + (col - Q.n_begin);
-                  *o = Q.accumulate ? *o + val[e] : val[e];
+                  *o = Q.accumulate ? *o + val : val;
                 }
               }
             }
-          }
+        }
       }
     }
   }
   if (DBG & 4) {
     t3 = clock64();
     if (tid == 0) {
-      long long* o = reinterpret_cast<long long*>(p.ws) + (size_t)blockIdx.x * 4;
-      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+      long long* o = reinterpret_cast<long long*>(p.ws) + (size_t)blockIdx.x * 8;
+      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = te1; o[5] = te2;
     }
   }
 }
@@ -652,6 +702,10 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
   const int dbg = knobs().wino_dbg, mtw = knobs().wino_mtw;
+  if (dbg == 12) {                       // timestamps + no result stores (ablation, tools/wino_timing.py 12)
+    p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
+    return p.any_affine ? launch_wino_variant<1, true, 12>(p, stream) : launch_wino_variant<1, false, 12>(p, stream);
+  }
   if (dbg == 4) {
     p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
     if (mtw == 1) return p.any_affine ? launch_wino_variant<1, true, 4>(p, stream) : launch_wino_variant<1, false, 4>(p, stream);

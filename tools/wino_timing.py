@@ -5,7 +5,8 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import torch, torch.nn as nn
 from supervised_dispnet_amd import engine
 dev = torch.device("cuda:0")
-buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+buf = torch.zeros(1 << 21, dtype=torch.int64, device=dev)
+BN_STATS = len(sys.argv) > 2 and sys.argv[2] == "bn"
 os.environ["DN_WINO_DBG"] = sys.argv[1] if len(sys.argv) > 1 else "4"
 os.environ["DN_WINO_DBGPTR"] = hex(buf.data_ptr())
 for cin, cout, H, W in [(64, 64, 128, 416), (128, 128, 64, 208), (256, 256, 32, 104), (512, 512, 16, 52)]:
@@ -13,14 +14,16 @@ for cin, cout, H, W in [(64, 64, 128, 416), (128, 128, 64, 208), (256, 256, 32, 
     layer = engine.ConvLayer(mod)
     x = engine.Act(torch.randn(32, H, W, cin, device=dev), 32, H, W, cin)
     for _ in range(3):
-        engine.conv_forward(layer, [engine.Piece(x)])
+        engine.conv_forward(layer, [engine.Piece(x)], bn_stats=BN_STATS)
     torch.cuda.synchronize()
     bt = 64 if os.environ.get('DN_WINO_MTW') == '2' else 32
     nblk = ((32 * H * W // 4 + bt - 1) // bt) * (cout // 64)
-    t = buf[: ((nblk + 7) // 8 * 8) * 4].view(-1, 4).cpu()
+    t = buf[: ((nblk + 7) // 8 * 8) * 8].view(-1, 8).cpu()
     t = t[t[:, 3] > 0]
     pro = (t[:, 1] - t[:, 0]).float().mean().item(); loop = (t[:, 2] - t[:, 1]).float().mean().item(); epi = (t[:, 3] - t[:, 2]).float().mean().item()
     nch = cin // 16
     print("cin%d cout%d %dx%d: blocks %d prologue %.0f loop %.0f (%.0f per chunk; MFMA time of the two co-resident blocks 8192) epilogue %.0f  [clock64 ticks]" % (cin, cout, H, W, len(t), pro, loop, loop / nch, epi))
     span = (t[:, 3].max() - t[:, 0].min()).item()
     print("   kernel span %d ticks" % span)
+    ex = (t[:, 4] - t[:, 2]).float().mean().item(); st = (t[:, 5] - t[:, 4]).float().mean().item(); so = (t[:, 3] - t[:, 5]).float().mean().item()
+    print("   epilogue: output transform + cross-wave exchange %.0f | statistics %.0f | bias/act/stores %.0f" % (ex, st, so))
