@@ -40,6 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 matrix peak (only for a --compute bf16 kernel, never the headline)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E spec (6.29 TB/s measured float4 copy there)
 WINO_EXEC = 16.0 / 36.0              # F(2x2,3x3): 16 element-wise products per 2x2 tile instead of 36 MACs
@@ -228,6 +229,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16"],
+                    help="bf16: bf16 multiplies / fp32 accumulation in the Winograd forward and input-gradient kernels (the 'mixed "
+                         "precision' mode of BASELINE configs[4]); tensors in HBM and every other kernel stay fp32.  Never the headline.")
     ap.add_argument("--graph", default="0", choices=["0", "1"],
                     help="1: replay the whole step (fwd + loss + bwd + Adam) as ONE captured hipGraph.  Off by default: measured on "
                          "ROCm 7.2 the replay is 1-4 %% SLOWER than the eager launches at every batch size (profiles/r02_strong_1gpu.txt)")
@@ -267,6 +271,7 @@ def main():
     from supervised_dispnet_amd.functional import reciprocal
     from supervised_dispnet_amd.optim import FusedAdam
 
+    engine.set_compute(args.compute)
     metric, netname, H, W, cfg_batch, ds, gflop_img = CONFIGS[args.config]
     if args.scaling == "strong":
         if args.global_batch % world:
@@ -357,8 +362,9 @@ def main():
         name, (fl, sec, n) = max(mf.items(), key=lambda kv: kv[1][1])
         wino = "wino_" in name
         ach = execf(name, fl) / sec / 1e12
-        roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(name),
+        kpeak = PEAK_BF16_MFMA_TFLOPS if ("wino_conv_kernel" in name and name.endswith(", true>")) else PEAK_FP32_MFMA_TFLOPS      # the bf16 Winograd variant
+        roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": kpeak, "unit": "TFLOP/s",
+                    "frac": ach / kpeak, "traffic": pmc_traffic(name),
                     "frac_of_measured_peak": ach / peaks["mfma_f32_TFLOPs"], "measured_peak": peaks["mfma_f32_TFLOPs"],
                     "algorithm": "winograd F(2x2,3x3): executes 16/36 of the direct multiply-accumulates" if wino else "direct implicit GEMM",
                     "credited_achieved": fl / sec / 1e12, "credited_frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -388,7 +394,9 @@ def main():
             "metric": metric, "value": total_images / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec_step * 1e3, "ms_per_step_median": statistics.median(per_step_ms), "ms_per_step_min": min(per_step_ms),
             "ms_per_step_max": max(per_step_ms), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if args.compute == "f32" else "bf16 multiply / f32 accumulate in the Winograd forward + input gradient; f32 tensors, f32 everywhere else",
+            "data": "synthetic",
             "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "launch": "one hipGraph replay per step" if graphed else "eager launches", "graph_fallback": graph_note},

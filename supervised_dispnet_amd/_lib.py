@@ -12,6 +12,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
 CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
 LOSS_L1, LOSS_L2, LOSS_BERHU, LOSS_SCALE_INV = 0, 1, 2, 3
 LOSS_STATS = 8
@@ -36,7 +37,7 @@ class ConvDesc(C.Structure):
                 ("n_in", C.c_int32), ("in_", Operand * DN_MAX_OPERANDS),
                 ("n_out", C.c_int32), ("out", Result * DN_MAX_OPERANDS),
                 ("w_packed", _f32p), ("bias", _f32p), ("act", C.c_int32), ("act_p0", C.c_float), ("act_p1", C.c_float),
-                ("bn_partial", _f32p), ("pad_mode", C.c_int32)]
+                ("bn_partial", _f32p), ("pad_mode", C.c_int32), ("compute", C.c_int32)]
 
 
 _P = C.POINTER
@@ -53,7 +54,7 @@ SIGNATURES = {
     "dn_conv_pack_weights": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
     "dn_pack_entry_bytes": (_i64, []),
     "dn_pack_entry_fill": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
-    "dn_pack_many": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "dn_pack_many": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "dn_conv_weight_layout": (_i32, [_P(ConvDesc)]),
     "dn_conv_bn_partial_rows": (_i32, [_P(ConvDesc)]),
     "dn_conv2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),

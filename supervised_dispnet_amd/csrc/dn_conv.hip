@@ -1550,7 +1550,10 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     if (head_fwd_eligible(d, p)) return launch_head_fwd(p, s);
     if (head_dgrad_eligible(d, p)) return launch_head_dgrad(p, s);
   }
-  if (wino_eligible(d, p)) return launch_wino_conv(p, s);
+  if (const int wl = wino_layout(d, p)) {
+    if (wl != 2) p.compute = DN_COMPUTE_F32;
+    return launch_wino_conv(p, s);
+  }
   if (stem_eligible(d, p)) return launch_stem(p, s);
   if (thin_conv_eligible(d, p)) return launch_thin_conv(p, s);
   // Few row tiles (the 4x13 / 8x26 decoder levels at b32: 13-52 tiles of 128 rows) leave most of the 256 CUs without a block;
@@ -1641,8 +1644,8 @@ int dn_pack_entry_fill(const dn_conv_desc* d, const float* w, float* w_packed, v
   if (rc != DN_OK) return rc;
   e->w = w;
   e->wp = w_packed;
-  if (wino_eligible(d, e->p)) {
-    e->wino = 1;
+  if (const int wl = wino_layout(d, e->p)) {
+    e->wino = wl;
     e->total = wino_packed_elems(e->p);
     e->NS = ((e->p.Ntot + 63) / 64 * 64) / 32;
   } else {
@@ -1654,8 +1657,8 @@ int dn_pack_entry_fill(const dn_conv_desc* d, const float* w, float* w_packed, v
   return e->wino;
 }
 
-int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, dn_stream_t stream) {
-  DN_REQUIRE(entries_dev && n_direct >= 0 && n_wino >= 0, DN_ERR_BAD_ARG, "dn_pack_many: bad argument");
+int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int32_t n_wino16, dn_stream_t stream) {
+  DN_REQUIRE(entries_dev && n_direct >= 0 && n_wino >= 0 && n_wino16 >= 0, DN_ERR_BAD_ARG, "dn_pack_many: bad argument");
   const PackEntry* tab = reinterpret_cast<const PackEntry*>(entries_dev);
   hipStream_t s = as_stream(stream);
   if (n_direct > 0) {
@@ -1663,7 +1666,11 @@ int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, dn_s
     int rc = check_launch("pack_weights_many_kernel");
     if (rc != DN_OK) return rc;
   }
-  if (n_wino > 0) return launch_wino_pack_many(tab, n_direct, n_wino, s);
+  if (n_wino > 0) {
+    int rc = launch_wino_pack_many(tab, n_direct, n_wino, s);
+    if (rc != DN_OK) return rc;
+  }
+  if (n_wino16 > 0) return launch_wino_pack16_many(tab, n_direct + n_wino, n_wino16, s);
   return DN_OK;
 }
 
@@ -1672,7 +1679,7 @@ int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed,
   int rc = build_plan(d, false, &p);
   if (rc != DN_OK) return rc;
   DN_REQUIRE(w != nullptr && w_packed != nullptr, DN_ERR_BAD_ARG, "null weight pointer");
-  if (wino_eligible(d, p)) return launch_wino_pack(p, w, w_packed, as_stream(stream));
+  if (const int wl = wino_layout(d, p)) return wl == 2 ? launch_wino_pack16(p, w, w_packed, as_stream(stream)) : launch_wino_pack(p, w, w_packed, as_stream(stream));
   const KPhase& last = p.ph[p.nphases - 1];
   const long long total = last.w_off + (long long)p.Npad * last.nchunks * kChunk;
   if (total == 0) return DN_OK;

@@ -311,6 +311,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   }
   (void)n_uniform;
   p->tile_store = knobs().no_tile_store ? 0 : 1;
+  p->compute = d->compute == DN_COMPUTE_BF16 ? DN_COMPUTE_BF16 : DN_COMPUTE_F32;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;
@@ -365,7 +366,7 @@ int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d) {
 int32_t dn_conv_weight_layout(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (dn::build_plan(d, false, &p) != DN_OK) return -1;
-  return dn::wino_eligible(d, p) ? 1 : 0;
+  return dn::wino_layout(d, p);
 }
 
 int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d) {

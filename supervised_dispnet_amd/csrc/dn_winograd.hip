@@ -181,6 +181,93 @@ int launch_wino_pack_many(const PackEntry* tab_dev, int first, int n, hipStream_
   return check_launch("wino_pack_many_kernel");
 }
 
+// bf16 fragment order: wp16[k/16][pos][n/32][lane][e] = bf16(U_pos[n][k]),  k = 16*(k/16) + 8*(lane >> 5) + e (e = 0..7),
+// n = 32*(n/32) + (lane & 31): the 16 bytes a lane feeds to one v_mfma_f32_32x32x16_bf16 as the B operand
+__device__ __forceinline__ void wino_pack16_body(const IgemmParams& p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
+  __bf16* wp16 = reinterpret_cast<__bf16*>(wp);
+  const long long npairs = total >> 4;                       // (n, k) pairs, each written at 16 positions
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < npairs; idx += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const long long rest = idx >> 9;
+    const int nsub = (int)(rest % NS), kc16 = (int)(rest / NS);
+    const int k = kc16 * 16 + (lane >> 5) * 8 + e, n = nsub * 32 + (lane & 31);
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
+    int cc = -1, kb = 0;
+#pragma unroll
+    for (int s = 0; s < DN_MAX_OPERANDS; ++s) {
+      if (s < p.n_in) {
+        const int C = p.in[s].C;
+        if (k >= kb && k < kb + C) cc = p.in[s].ch_off + (k - kb);
+        kb += (C + WKC - 1) / WKC * WKC;
+      }
+    }
+    if (n < p.Ntot && cc >= 0) {
+      const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + cc) : ((long long)cc * p.D1 + n)) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int a = p.tdy[t] + 1, b = p.tdx[t] + 1;
+        const float v = w[base + p.tr[t] * 3 + p.ts[t]];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb)
+            if (aa == a && bb == b) g[aa][bb] = v;
+      }
+    }
+    float t4[4][3];
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float g0 = g[0][bb], g1 = g[1][bb], g2 = g[2][bb];
+      t4[0][bb] = g0;
+      t4[1][bb] = 0.5f * (g0 + g1 + g2);
+      t4[2][bb] = 0.5f * (g0 - g1 + g2);
+      t4[3][bb] = g2;
+    }
+    __bf16* dst = wp16 + (((long long)kc16 * 16 * NS + nsub) * 64 + lane) * 8 + e;
+    const long long posB = (long long)NS * 64 * 8;             // elements between two positions
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u0 = t4[i][0], u1 = 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]), u2 = 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]), u3 = t4[i][2];
+      dst[(4 * i + 0) * posB] = (__bf16)u0;
+      dst[(4 * i + 1) * posB] = (__bf16)u1;
+      dst[(4 * i + 2) * posB] = (__bf16)u2;
+      dst[(4 * i + 3) * posB] = (__bf16)u3;
+    }
+  }
+}
+
+__global__ void wino_pack16_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
+  wino_pack16_body(p, w, wp, NS, total);
+}
+
+__global__ void wino_pack16_many_kernel(const PackEntry* __restrict__ tab) {
+  const PackEntry& e = tab[blockIdx.y];
+  wino_pack16_body(e.p, e.w, e.wp, e.NS, e.total);
+}
+
+int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(wino_pack16_many_kernel, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
+  return check_launch("wino_pack16_many_kernel");
+}
+
+int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, hipStream_t stream) {
+  const long long total = wino_packed_elems(p);              // (n, k) pairs x 16 positions, as for the fp32 layout
+  int blocks = (int)(((total >> 4) + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wino_pack16_kernel, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
+  return check_launch("wino_pack16_kernel");
+}
+
+// 0: not a Winograd layer; 1: fp32 Winograd; 2: bf16-multiply Winograd (descriptor compute = DN_COMPUTE_BF16 on the default tile variant)
+int wino_layout(const dn_conv_desc* d, const IgemmParams& p) {
+  if (!wino_eligible(d, p)) return 0;
+  return (p.compute == DN_COMPUTE_BF16 && knobs().wino_mtw == 1 && knobs().wino_dbg == 0) ? 2 : 1;
+}
+
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream) {
   const long long total = wino_packed_elems(p);
   int blocks = (int)(((total >> 4) + 255) / 256);
@@ -210,6 +297,15 @@ struct WinoCfg {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// bf16-multiply / fp32-accumulate variant (descriptor compute = DN_COMPUTE_BF16, BF = true below): the transformed input tiles are
+// rounded to bf16 on their way into LDS ([position][tile][16 k], 48-byte tile rows: the 16-byte fragment reads of a 16-lane group
+// and the dword staging stores land on distinct banks), the transformed weights are packed as bf16 in fragment order, and one
+// v_mfma_f32_32x32x16_bf16 consumes a whole 16-channel chunk of one position: 8 matrix instructions (256 cycles) per chunk
+// instead of 64 (4096).  The kernel is then bound by the staging work and by HBM, not by the matrix pipe; activations, weights
+// (master copy), accumulators, transforms, statistics and everything outside this kernel stay fp32.
+constexpr int W16_ROWB = 48;                          // bytes of one tile's 16 bf16 (+16 padding)
 template <int VW> struct VecOf;
 template <> struct VecOf<4> { typedef f32x4 type; };
 template <> struct VecOf<2> { typedef f32x2 type; };
@@ -227,9 +323,11 @@ __device__ __forceinline__ typename VecOf<VW>::type buffer_load_vec(__amdgpu_buf
   }
 }
 
-template <int MTW, bool HA, int DBG>
+template <int MTW, bool HA, int DBG, bool BF = false>
 __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const IgemmParams p) {
+  static_assert(!BF || MTW == 1, "the bf16 variant exists for the two-blocks-per-CU tile only");
   using Cfg = WinoCfg<MTW>;
+  constexpr int PLANE16 = Cfg::BT * W16_ROWB, BUF16 = 16 * PLANE16;      // BF: one position plane / one 16-channel chunk
   constexpr int BT = Cfg::BT, HALFB = Cfg::HALFB, POSB = Cfg::POSB, SUBB = Cfg::SUBB, BUFB = Cfg::BUFB;
   extern __shared__ __align__(16) float smem[];
   char* smemB = reinterpret_cast<char*>(smem);
@@ -283,14 +381,32 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     breg[slot][1] = *reinterpret_cast<const f32x4*>(wcur + 1024);
   };
   auto advance_b = [&](int j_loaded) { wcur += j_loaded == 3 ? wstep8B - 3 * (size_t)wjB : (size_t)wjB; };
-  load_b(0);
-  advance_b(0);
-  load_b(1);
-  advance_b(1);
-  load_b(2);
-  advance_b(2);
   const int stA = (k0 >> 3) * SUBB + ((k0 >> 2) & 1) * HALFB + st_tile * 16 + (k0 & 3) * 4;   // staging store offset in a buffer (+ pos * POSB)
   const int frA = (4 * wave) * POSB + (lane >> 5) * HALFB + (lane & 31) * 16;  // fragment read offset in an 8-k group
+  // BF: staging store (one dword = channels k0, k0+1 as bf16) and fragment read (8 bf16 = k 8*(lane>>5)..+7 of tile lane&31)
+  const int stA16 = st_tile * W16_ROWB + k0 * 2;                                 // (+ pos * PLANE16)
+  const int frA16 = (4 * wave) * PLANE16 + (lane & 31) * W16_ROWB + (lane >> 5) * 16;
+  // BF weights: wp16[chunk][pos][n/32][lane][8 bf16]: 1 KiB per (chunk, position, 32 couts)
+  const char* wcur16 = reinterpret_cast<const char*>(p.w) + ((size_t)(4 * wave) * NS + 2 * nb) * 1024 + lane * 16;
+  const size_t wchunk16B = (size_t)16 * NS * 1024;
+  bf16x8 breg16[4][2];
+  auto load_b16 = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) breg16[j][nn] = *reinterpret_cast<const bf16x8*>(wcur16 + (size_t)j * wjB + nn * 1024);
+    wcur16 += wchunk16B;
+  };
+  if constexpr (!BF) {
+    load_b(0);
+    advance_b(0);
+    load_b(1);
+    advance_b(1);
+    load_b(2);
+    advance_b(2);
+  } else {
+    load_b16();
+  }
 
   // slot schedule (compile-time): NSL slots per 16-channel chunk, one MFMA each; H = first slot of the second 8-k group
   constexpr int NSL = 64 * MTW, H = NSL / 2, GRP = 8 * MTW;     // GRP = MFMAs per (8-k group, position j)
@@ -360,6 +476,21 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       v[12 + b] = d1 - v[12 + b];
     };
     auto col_piece = [&](int b2, int i, int half) {    // (B^T d) B and the LDS stores of transform row i
+      if constexpr (BF) {
+        char* dst16 = smemB + b2 * BUF16 + stA16 + (4 * i) * PLANE16;
+        auto put = [&](int pos, const fV& val) {
+          const bf16x2 h = __builtin_convertvector(val, bf16x2);              // v_cvt_pk_bf16_f32 (round to nearest even)
+          *reinterpret_cast<unsigned*>(dst16 + pos * PLANE16) = __builtin_bit_cast(unsigned, h);
+        };
+        if (half == 0) {
+          put(0, v[4 * i + 0] - v[4 * i + 2]);
+          put(1, v[4 * i + 1] + v[4 * i + 2]);
+        } else {
+          put(2, v[4 * i + 2] - v[4 * i + 1]);
+          put(3, v[4 * i + 1] - v[4 * i + 3]);
+        }
+        return;
+      }
       char* dst = smemB + b2 * BUFB + stA + (4 * i) * POSB;
       if (half == 0) {
         *reinterpret_cast<fV*>(dst + 0 * POSB) = v[4 * i + 0] - v[4 * i + 2];
@@ -400,6 +531,37 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     __syncthreads();
     if (DBG & 4) t1 = clock64();
 
+    if constexpr (BF) {
+      for (int c = 0; c < nch; ++c) {
+        const bool more = c + 1 < nch;
+        cnB = (more ? c + 1 : c) * (WKC * 4);          // the last chunk re-fetches itself into the idle buffer: no branch
+        const char* Ab16 = smemB + buf * BUF16 + frA16;
+        bf16x8 fa16[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa16[j] = *reinterpret_cast<const bf16x8*>(Ab16 + j * PLANE16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) load_v(i);        // next chunk's patch: in flight under the MFMAs and the weight loads
+        load_aff();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+            acc[j][0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa16[j], breg16[j][nn], acc[j][0][nn], 0, 0, 0);
+        load_b16();                                     // next chunk's weights (the buffer carries one chunk of slack)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) affine_piece(i);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) row_piece(b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          col_piece(buf ^ 1, i, 0);
+          col_piece(buf ^ 1, i, 1);
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
+      continue;
+    }
     for (int c = 0; c < nch; ++c) {
       const bool more = c + 1 < nch;
       cnB = (more ? c + 1 : c) * (WKC * 4);            // the last chunk re-fetches itself into the idle buffer: no branch
@@ -678,19 +840,23 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   }
 }
 
-template <int MTW, bool HA, int DBG>
+template <int MTW, bool HA, int DBG, bool BF = false>
 static int launch_wino_variant(const IgemmParams& p, hipStream_t stream) {
   using Cfg = WinoCfg<MTW>;
-  auto kernel = wino_conv_kernel<MTW, HA, DBG>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+  auto kernel = wino_conv_kernel<MTW, HA, DBG, BF>;
+  // BF: two 16-channel chunks of bf16 planes, or the epilogue's cross-wave exchange + statistics scratch, whichever is larger
+  constexpr size_t lds16a = (size_t)2 * 16 * Cfg::BT * W16_ROWB, lds16b = (size_t)(4 * Cfg::BT * WZLD + MTW * 5 * 64) * sizeof(float);
+  constexpr size_t lds = BF ? (lds16a > lds16b ? lds16a : lds16b) : Cfg::LDS;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
-    set_error("hipFuncSetAttribute(wino_conv_kernel, %zu): %s", Cfg::LDS, hipGetErrorString(e));
+    set_error("hipFuncSetAttribute(wino_conv_kernel, %zu): %s", lds, hipGetErrorString(e));
     return DN_ERR_LAUNCH;
   }
   const int tiles = ((p.T + Cfg::BT - 1) / Cfg::BT) * (p.Npad / WBN);
   dim3 grid((tiles + 7) / 8 * 8);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), Cfg::LDS, stream, p);
-  set_last_kernel("dn::wino_conv_kernel<%d, %s, %d>", MTW, HA ? "true" : "false", DBG);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  if (BF) set_last_kernel("dn::wino_conv_kernel<%d, %s, %d, true>", MTW, HA ? "true" : "false", DBG);
+  else set_last_kernel("dn::wino_conv_kernel<%d, %s, %d>", MTW, HA ? "true" : "false", DBG);
   return check_launch("wino_conv_kernel");
 }
 
@@ -702,6 +868,8 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
   const int dbg = knobs().wino_dbg, mtw = knobs().wino_mtw;
+  if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variant may be used)
+    return p.any_affine ? launch_wino_variant<1, true, 0, true>(p, stream) : launch_wino_variant<1, false, 0, true>(p, stream);
   if (dbg == 12) {                       // timestamps + no result stores (ablation, tools/wino_timing.py 12)
     p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
     return p.any_affine ? launch_wino_variant<1, true, 12>(p, stream) : launch_wino_variant<1, false, 12>(p, stream);

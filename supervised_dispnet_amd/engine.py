@@ -38,6 +38,21 @@ PROFILE = None
 # DN_BN_MATERIALIZE=1: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back) for A/B runs and the equivalence test
 BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
 
+# Arithmetic of the matrix-core kernels that offer a choice (dn_conv_desc.compute): "f32" (default; what every parity statement and the
+# headline benchmark use) or "bf16" = bf16 multiplies with fp32 accumulation in the Winograd forward / input-gradient kernels -- the
+# "mixed precision" mode of BASELINE configs[4].  Tensors in HBM, statistics, transforms and all other kernels stay fp32.
+# DN_COMPUTE=bf16 or set_compute("bf16").
+COMPUTE = _lib.COMPUTE_BF16 if os.environ.get("DN_COMPUTE", "f32").lower() == "bf16" else _lib.COMPUTE_F32
+
+
+def set_compute(mode):
+    global COMPUTE
+    if mode not in ("f32", "bf16"):
+        raise ValueError("compute mode is 'f32' or 'bf16', got %r" % (mode,))
+    COMPUTE = _lib.COMPUTE_BF16 if mode == "bf16" else _lib.COMPUTE_F32
+    bump_param_epoch()
+
+
 # True while graph.GraphedStep records a step into a hipGraph (nothing in the engine may synchronise or time launches then)
 CAPTURING = False
 
@@ -339,6 +354,7 @@ class ConvLayer:
         d.N, d.IH, d.IW, d.OH, d.OW = N, IH, IW, OH, OW
         d.R, d.S, d.stride, d.pad = self.R, self.S, self.stride, self.pad
         d.pad_mode = 1 if (self.reflect and kind == CONV_FWD) else 0
+        d.compute = COMPUTE
         return d
 
     def packed(self, kind, desc):
@@ -384,7 +400,7 @@ class PackTable(object):
         self.rows = {}                  # key -> [entry bytes, wino flag, weight tensor, packed buffer, weight ptr]
         self.dirty = True
         self.dev_table = None
-        self.counts = (0, 0)
+        self.counts = (0, 0, 0)
         self.epoch = -1                 # PARAM_EPOCH whose weights the buffers of `covered` hold
         self.covered = set()
         self.esize = int(_lib.load().dn_pack_entry_bytes())
@@ -413,14 +429,14 @@ class PackTable(object):
         if not self.rows:
             return
         if self.dirty:
-            direct = [r for r in self.rows.values() if r[1] == 0]
-            wino = [r for r in self.rows.values() if r[1] == 1]
-            blob = b"".join(r[0] for r in direct + wino)
+            kinds = [[r for r in self.rows.values() if r[1] == k] for k in (0, 1, 2)]      # direct, Winograd fp32, Winograd bf16
+            ordered = kinds[0] + kinds[1] + kinds[2]
+            blob = b"".join(r[0] for r in ordered)
             self.dev_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
-            self.counts = (len(direct), len(wino))
-            self.covered = {r[3].data_ptr() for r in direct + wino}
+            self.counts = tuple(len(k) for k in kinds)
+            self.covered = {r[3].data_ptr() for r in ordered}
             self.dirty = False
-        _lib.call("dn_pack_many", self.dev_table.data_ptr(), self.counts[0], self.counts[1], _stream())
+        _lib.call("dn_pack_many", self.dev_table.data_ptr(), self.counts[0], self.counts[1], self.counts[2], _stream())
         self.epoch = epoch
 
 

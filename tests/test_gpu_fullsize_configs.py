@@ -260,6 +260,63 @@ def test_config5_dorn_full_batch_32x128x416_step():
     assert torch.isfinite(opt.arena.flat_p).all() and 5e-5 < float(moved.max()) <= 1.001e-4
 
 
+def test_config5_mixed_precision_mode_vs_fp32():
+    """BASELINE configs[4] is the reference's mixed-precision run.  engine.set_compute("bf16") = bf16 multiplies with fp32
+    accumulation in the Winograd forward / input-gradient kernels (23 of the 27 convolutions of Disp_vgg_BN_DORN, 91 % of the
+    multiply-accumulates); tensors, BatchNorm statistics, weight gradients, the ordinal head, the loss and Adam stay fp32.
+    Checked against the fp32 mode of the same network on the same inputs (itself pinned to the reference's golden above).
+    STATED TOLERANCES of the mixed-precision mode (13 stacked bf16-product layers, batch statistics renormalise each; measured values
+    in brackets): ordinal probabilities max |dP| <= 0.02 (0.0053), mean |dP| <= 1e-3 (2.3e-4); decoded labels identical wherever no
+    fp32 probability lies within 0.02 of the 0.5 threshold; loss relative 1e-3 (1e-7); whole gradient vector relative L2 <= 1e-2
+    over the decoder + head (1.6e-3) and <= 0.15 over the encoder (0.09: ReLU / max-pool masks of a freshly initialised network flip
+    under a 4e-3 perturbation of their inputs, the same mechanism tests/test_gpu_models.py documents between two fp32 kernels)."""
+    b = 4
+    x, gt, mask = dorn80_inputs(b)
+    res = {}
+    try:
+        for mode in ("f32", "bf16"):
+            engine.set_compute(mode)
+            net = models.Disp_vgg_BN_DORN(datasets="kitti", ordinal_c=80, with_classifier=False)
+            _fresh(net, "vggdorn80")
+            net.to(DEV).train()
+            engine.PROFILE = []
+            tgt, dec, ordc, loss = _dorn_run(b, x, gt, mask, net)
+            loss.backward()
+            torch.cuda.synchronize()
+            prof, engine.PROFILE = engine.PROFILE, None
+            names = [r[0] for r in prof]
+            grads = {n: p.grad.detach().double().cpu() for n, p in net.named_parameters() if p.grad is not None and not _is_pre_bn_conv_bias(n)}
+            res[mode] = (dec.cpu(), ordc.detach().cpu(), float(loss.item()), grads, names)
+    finally:
+        engine.PROFILE = None
+        engine.set_compute("f32")
+    is_bf = lambda n: "wino_conv_kernel" in n and n.endswith(", true>")
+    nbf = sum(is_bf(n) for n in res["bf16"][4])
+    assert nbf >= 30 and not any(is_bf(n) for n in res["f32"][4]), nbf      # the bf16 kernels are what ran
+    d0, o0, l0, g0, _ = res["f32"]
+    d1, o1, l1, g1, _ = res["bf16"]
+    dP = (o1 - o0).abs()
+    flips = (d1 != d0).float().mean().item()
+    worst = int((d1 - d0).abs().max())
+    print("mixed precision vs fp32: max|dP| %.4f mean|dP| %.2e, decode differs on %.3f %% (worst %d bins), loss %.6f vs %.6f" % (
+        float(dP.max()), float(dP.mean()), 100 * flips, worst, l1, l0))
+    rels = {}
+    for block in ("features.", ""):
+        names = [n for n in g0 if n.startswith("features.") == (block == "features.")]
+        num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in names)
+        den = sum(float(g0[n].pow(2).sum()) for n in names)
+        rels[block or "decoder"] = (num / den) ** 0.5
+        print("  gradient block %-10s relative L2 %.3e over %d tensors" % (block or "decoder", rels[block or "decoder"], len(names)))
+    assert float(dP.max()) <= 0.02 and float(dP.mean()) <= 1e-3
+    # decoded label = number of P > 0.5: may only differ where some fp32 probability lies within the stated dP bound of 0.5 (at
+    # initialisation that is most of the image: every P starts near 0.5; measured 6.5 % of the pixels differ, by at most 4 bins)
+    safe = ((o0 - 0.5).abs() > 0.02).all(1, keepdim=True)
+    assert torch.equal(d1[safe], d0[safe])
+    assert abs(l1 - l0) <= 1e-3 * abs(l0)
+    assert float(dP.max()) > 1e-6                                                          # (bf16 really was used)
+    assert rels["features."] <= 0.15 and rels["decoder"] <= 1e-2, rels
+
+
 # ================================================================================================ config 4
 N4, H4, W4 = 16, 480, 640
 

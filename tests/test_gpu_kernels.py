@@ -299,6 +299,71 @@ def test_winograd_error_vs_fp64(monkeypatch):
     assert errs["wino"] <= 4.0 * errs["direct"] + 2e-6 * scale
 
 
+def _rel_l2(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return float((got - want).norm() / (want.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("case", ["plain_128_64", "bn_pending_64_128", "concat_64_64_1"])
+def test_winograd_bf16_compute_mode(case):
+    """dn_conv_desc.compute = DN_COMPUTE_BF16 (BASELINE configs[4]'s mixed precision): the Winograd forward / input gradient multiply
+    bf16-rounded transformed tiles and weights on v_mfma_f32_32x32x16_bf16 and accumulate in fp32.  Against the fp32 Winograd kernel
+    on the same inputs.  Stated tolerance: relative L2 error <= 8e-3 and max error <= 3 % of the result's magnitude (two operands
+    rounded to 8 significant bits: 2^-9 rms each, ~3e-3 expected); the kernel name proves which variant ran; the weight gradient has
+    no bf16 variant and must be bit-identical."""
+    torch.manual_seed(11)
+    N, H, W = 3, 18, 22
+    try:
+        res = {}
+        for mode in ("f32", "bf16"):
+            engine.set_compute(mode)
+            torch.manual_seed(12)
+            if case == "plain_128_64":
+                mod = nn.Conv2d(128, 64, 3, 1, 1).to(DEV)
+                xa = engine.Act(torch.randn(N, H, W, 128, device=DEV), N, H, W, 128)
+                pieces = [engine.Piece(xa)]
+                cout = 64
+            elif case == "bn_pending_64_128":
+                mod = nn.Conv2d(64, 128, 3, 1, 1).to(DEV)
+                xa = engine.Act(torch.randn(N, H, W, 64, device=DEV), N, H, W, 64)
+                xa.scale = torch.rand(64, device=DEV) + 0.5
+                xa.shift = torch.randn(64, device=DEV) * 0.3
+                pieces = [engine.Piece(xa)]
+                cout = 128
+            else:
+                mod = nn.Conv2d(129, 64, 3, 1, 1).to(DEV)
+                a = engine.Act(torch.randn(N, H, W, 64, device=DEV), N, H, W, 64)
+                b = engine.Act(torch.randn(N, H, W, 64, device=DEV), N, H, W, 64)
+                d = engine.Act(torch.rand(N, H // 2, W // 2, 1, device=DEV) * 2, N, H // 2, W // 2, 1)
+                pieces = [engine.Piece(a), engine.Piece(b), engine.Piece(d, up=True)]
+                cout = 64
+            layer = engine.ConvLayer(mod)
+            y, _, _ = engine.conv_forward(layer, pieces, ACT_LEAKY, 0.1, 0.0)
+            kf = _lib.load().dn_last_kernel().decode()
+            dy = torch.randn(N, H, W, cout, device=DEV)
+            outs = [y]
+            if case != "bn_pending_64_128":          # (the gradient w.r.t. a pre-BatchNorm tensor goes through the BN kernels)
+                engine.conv_dgrad(layer, dy, N, H, W, pieces, (H, W))
+                kd = _lib.load().dn_last_kernel().decode()
+                outs += [pc.act.grad for pc in pieces]
+            else:
+                kd = kf
+            dw = engine.conv_wgrad(layer, pieces, dy, (H, W))
+            torch.cuda.synchronize()
+            res[mode] = (outs, kf, kd, dw)
+    finally:
+        engine.set_compute("f32")
+    assert res["bf16"][1].endswith(", true>") and res["bf16"][2].endswith(", true>"), res["bf16"][1:3]
+    assert "wino_conv_kernel" in res["f32"][1] and not res["f32"][1].endswith(", true>")
+    assert torch.equal(res["bf16"][3], res["f32"][3])
+    for i, (got, want) in enumerate(zip(res["bf16"][0], res["f32"][0])):
+        rel = _rel_l2(got, want)
+        mx = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-30)
+        print("%s[%d]: relative L2 %.3g, max error / magnitude %.3g" % (case, i, rel, mx))
+        assert 1e-5 < rel <= 8e-3, (case, i, rel)        # (the lower bound: bf16 really was used)
+        assert mx <= 3e-2, (case, i, mx)
+
+
 def test_bilinear_up2_matches_interpolate():
     x = rnd(2, 1, 5, 7, seed=1).requires_grad_()
     ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)[:, :, :9, :14]
