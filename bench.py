@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-warmup", type=int, default=2)
-    ap.add_argument("--compute", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--compute", default="f32", choices=["f32", "f32x3", "bf16"],
                     help="bf16: bf16 multiplies / fp32 accumulation in the Winograd forward and input-gradient kernels (the 'mixed "
                          "precision' mode of BASELINE configs[4]); tensors in HBM and every other kernel stay fp32.  Never the headline.")
     ap.add_argument("--graph", default="0", choices=["0", "1"],
@@ -362,7 +362,7 @@ def main():
         name, (fl, sec, n) = max(mf.items(), key=lambda kv: kv[1][1])
         wino = "wino_" in name
         ach = execf(name, fl) / sec / 1e12
-        kpeak = PEAK_BF16_MFMA_TFLOPS if ("wino_conv_kernel" in name and name.endswith(", true>")) else PEAK_FP32_MFMA_TFLOPS      # the bf16 Winograd variant
+        kpeak = PEAK_BF16_MFMA_TFLOPS if ("wino_conv_kernel" in name and name.endswith((", 1>", ", 3>"))) else PEAK_FP32_MFMA_TFLOPS      # the bf16 Winograd variant
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": kpeak, "unit": "TFLOP/s",
                     "frac": ach / kpeak, "traffic": pmc_traffic(name),
                     "frac_of_measured_peak": ach / peaks["mfma_f32_TFLOPs"], "measured_peak": peaks["mfma_f32_TFLOPs"],
@@ -395,7 +395,9 @@ def main():
             "ms_per_step": sec_step * 1e3, "ms_per_step_median": statistics.median(per_step_ms), "ms_per_step_min": min(per_step_ms),
             "ms_per_step_max": max(per_step_ms), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.compute == "f32" else "bf16 multiply / f32 accumulate in the Winograd forward + input gradient; f32 tensors, f32 everywhere else",
+            "dtype": {"f32": "f32",
+                      "f32x3": "f32 (Winograd forward + input gradient form each f32 product from three exact bf16 pieces per operand on the bf16 matrix cores, f32 accumulate; error vs fp64 = the f32 instruction's)",
+                      "bf16": "bf16 multiply / f32 accumulate in the Winograd forward + input gradient; f32 tensors, f32 everywhere else"}[args.compute],
             "data": "synthetic",
             "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "final_loss": final_loss,

@@ -113,13 +113,19 @@ typedef struct dn_conv_desc {
   int32_t pad_mode;                /* 0: zero padding; 1: reflection padding (nn.ReflectionPad2d(pad) in front of the conv,
                                       layers.py:124-136).  Reflection is honoured by DN_CONV_FWD and by the weight gradient;
                                       its input gradient = DN_CONV_DGRAD with pad 0 on the padded extent + dn_reflect_fold. */
-  int32_t compute;                 /* DN_COMPUTE_F32 (0, default) or DN_COMPUTE_BF16: bf16 multiplies with fp32 accumulation on the
-                                      matrix cores where a kernel offers it (today: the Winograd forward / input gradient, layout 2 of
-                                      dn_conv_weight_layout); tensors, statistics and all other kernels stay fp32.  The "mixed
-                                      precision" mode of BASELINE configs[4]; never used by the fp32 headline configuration. */
+  int32_t compute;                 /* Arithmetic of the matrix-core kernels that offer a choice (today: the Winograd forward / input
+                                      gradient); tensors, statistics, transforms and all other kernels are fp32 in every mode.
+                                      DN_COMPUTE_F32 (0, default): fp32 FMA chain on v_mfma_f32_32x32x2_f32.
+                                      DN_COMPUTE_BF16: operands ROUNDED to bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- the
+                                        "mixed precision" mode of BASELINE configs[4]; ~4e-3 relative error per layer.
+                                      DN_COMPUTE_F32X3: fp32 products on the bf16 matrix cores: each fp32 operand is split EXACTLY
+                                        into three bf16 pieces (x = x0 + x1 + x2) and the six partial products of weight <= 2^-16
+                                        (x0y0, x0y1, x1y0, x0y2, x1y1, x2y0) are accumulated in fp32; what is dropped is below
+                                        2^-24 of |x||y|, the rounding an fp32 FMA chain commits itself (measured against fp64: the
+                                        same error as DN_COMPUTE_F32 or less, tools/ubench/bf16x3.hip, tests/test_gpu_kernels.py). */
 } dn_conv_desc;
 
-enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1 };
+enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2 };
 
 /* Elements of the packed weight buffer for desc->kind (depends on R,S,stride,pad, operand/result channels). */
 int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d);
@@ -128,15 +134,16 @@ int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d);
 int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed, dn_stream_t stream);
 /* Every weight re-lay of a training step in (at most) two launches.  The caller keeps a table of dn_pack_entry_bytes()-sized rows:
  * dn_pack_entry_fill() writes one row on the HOST for (descriptor, framework weights, packed destination) and returns 1 for a
- * Winograd-layout row, 2 for a bf16 Winograd row, 0 for a direct-layout row (<0: error); the caller orders the rows direct, Winograd,
- * bf16 Winograd, copies the table to the device once, and calls dn_pack_many(device table, #direct, #winograd, #bf16, stream) after
- * every optimizer step (same arithmetic as
+ * Winograd-layout row, 2 for a bf16 Winograd row, 3 for a three-piece bf16 Winograd row, 0 for a direct-layout row (<0: error); the
+ * caller orders the rows direct, Winograd, bf16, three-piece, copies the table to the device once, and calls dn_pack_many(device table,
+ * #direct, #winograd, #bf16, #three-piece, stream) after every optimizer step (same arithmetic as
  * dn_conv_pack_weights per row; the pointers in the rows must still be valid). */
 int64_t dn_pack_entry_bytes(void);
 int dn_pack_entry_fill(const dn_conv_desc* d, const float* w, float* w_packed, void* entry_host);
-int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int32_t n_wino_bf16, dn_stream_t stream);
+int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int32_t n_wino_bf16, int32_t n_wino_x3, dn_stream_t stream);
 /* Which packed layout dn_conv_pack_weights produces for this descriptor: 0 = implicit-GEMM [phase][Npad][K chunks], 2 = the Winograd
- * layout below rounded to bf16 (descriptor compute = DN_COMPUTE_BF16), 1 = Winograd
+ * layout below rounded to bf16 (descriptor compute = DN_COMPUTE_BF16), 3 = the same as three exact bf16 pieces (DN_COMPUTE_F32X3),
+ * 1 = Winograd
  * F(2x2,3x3) transformed weights in MFMA fragment order (3x3 / stride 1 / pad 1 layers with 16-aligned channels and even
  * extents that fill the kernel's tiles).  The layout depends on the geometry, not only on the weights: a caller that caches
  * packed weights must key the cache on it (the same layer at another resolution may pick the other algorithm). */

@@ -12,7 +12,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
-COMPUTE_F32, COMPUTE_BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F32X3 = 0, 1, 2
 CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
 LOSS_L1, LOSS_L2, LOSS_BERHU, LOSS_SCALE_INV = 0, 1, 2, 3
 LOSS_STATS = 8
@@ -54,7 +54,7 @@ SIGNATURES = {
     "dn_conv_pack_weights": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
     "dn_pack_entry_bytes": (_i64, []),
     "dn_pack_entry_fill": (C.c_int, [_P(ConvDesc), _vp, _vp, _vp]),
-    "dn_pack_many": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
+    "dn_pack_many": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
     "dn_conv_weight_layout": (_i32, [_P(ConvDesc)]),
     "dn_conv_bn_partial_rows": (_i32, [_P(ConvDesc)]),
     "dn_conv2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),

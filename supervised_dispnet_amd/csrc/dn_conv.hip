@@ -1551,7 +1551,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     if (head_dgrad_eligible(d, p)) return launch_head_dgrad(p, s);
   }
   if (const int wl = wino_layout(d, p)) {
-    if (wl != 2) p.compute = DN_COMPUTE_F32;
+    p.compute = wl == 2 ? DN_COMPUTE_BF16 : (wl == 3 ? DN_COMPUTE_F32X3 : DN_COMPUTE_F32);
     return launch_wino_conv(p, s);
   }
   if (stem_eligible(d, p)) return launch_stem(p, s);
@@ -1657,8 +1657,8 @@ int dn_pack_entry_fill(const dn_conv_desc* d, const float* w, float* w_packed, v
   return e->wino;
 }
 
-int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int32_t n_wino16, dn_stream_t stream) {
-  DN_REQUIRE(entries_dev && n_direct >= 0 && n_wino >= 0 && n_wino16 >= 0, DN_ERR_BAD_ARG, "dn_pack_many: bad argument");
+int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int32_t n_wino16, int32_t n_wino_x3, dn_stream_t stream) {
+  DN_REQUIRE(entries_dev && n_direct >= 0 && n_wino >= 0 && n_wino16 >= 0 && n_wino_x3 >= 0, DN_ERR_BAD_ARG, "dn_pack_many: bad argument");
   const PackEntry* tab = reinterpret_cast<const PackEntry*>(entries_dev);
   hipStream_t s = as_stream(stream);
   if (n_direct > 0) {
@@ -1670,7 +1670,11 @@ int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int3
     int rc = launch_wino_pack_many(tab, n_direct, n_wino, s);
     if (rc != DN_OK) return rc;
   }
-  if (n_wino16 > 0) return launch_wino_pack16_many(tab, n_direct + n_wino, n_wino16, s);
+  if (n_wino16 > 0) {
+    int rc = launch_wino_pack16_many(tab, n_direct + n_wino, n_wino16, 1, s);
+    if (rc != DN_OK) return rc;
+  }
+  if (n_wino_x3 > 0) return launch_wino_pack16_many(tab, n_direct + n_wino + n_wino16, n_wino_x3, 3, s);
   return DN_OK;
 }
 
@@ -1679,7 +1683,8 @@ int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed,
   int rc = build_plan(d, false, &p);
   if (rc != DN_OK) return rc;
   DN_REQUIRE(w != nullptr && w_packed != nullptr, DN_ERR_BAD_ARG, "null weight pointer");
-  if (const int wl = wino_layout(d, p)) return wl == 2 ? launch_wino_pack16(p, w, w_packed, as_stream(stream)) : launch_wino_pack(p, w, w_packed, as_stream(stream));
+  if (const int wl = wino_layout(d, p))
+    return wl == 1 ? launch_wino_pack(p, w, w_packed, as_stream(stream)) : launch_wino_pack16(p, w, w_packed, wl == 3 ? 3 : 1, as_stream(stream));
   const KPhase& last = p.ph[p.nphases - 1];
   const long long total = last.w_off + (long long)p.Npad * last.nchunks * kChunk;
   if (total == 0) return DN_OK;

@@ -99,7 +99,7 @@ struct IgemmParams {
   int wg_uniform;                // every operand: C % 32 == 0, float4-addressable, no upsample (weight-gradient fast path)
   int any_affine;                // some operand carries a pending BN-apply + ReLU
   int reflect;                   // gather with ReflectionPad2d index mapping instead of zero fill
-  int compute;                   // DN_COMPUTE_F32 / DN_COMPUTE_BF16 (descriptor field; honoured by the Winograd forward / input gradient)
+  int compute;                   // DN_COMPUTE_F32 / _BF16 / _F32X3 (descriptor field; honoured by the Winograd forward / input gradient)
   int tile_store;                // epilogue may stage the result tile in LDS and store whole pixels (off: DN_NO_TILE_STORE)
   // Winograd F(2x2,3x3) launches only (dn_winograd.hip)
   int T, TH, TW;                 // 2x2 output tiles: total, per image column / row
@@ -117,12 +117,13 @@ struct PackEntry {
   const float* w;
   float* wp;
   long long total;      // elements the kernel walks (direct: packed elements; Winograd: wino_packed_elems)
-  int wino;             // 0: direct [phase][Npad][K] layout, 1: Winograd fragment-order transform (fp32), 2: the same as bf16
+  int wino;             // 0: direct [phase][Npad][K] layout, 1: Winograd fragment-order transform (fp32), 2: the same as bf16, 3: as three bf16 pieces
   int NS;               // Winograd: Npad / 32
 };
 int launch_wino_pack_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream);
-int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream);
-int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, hipStream_t stream);
+int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, int pieces, hipStream_t stream);
+int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, int pieces, hipStream_t stream);
+long long wino_packed_floats(const IgemmParams& p, int layout);
 int wino_layout(const dn_conv_desc* d, const IgemmParams& p);
 
 // floor(n/d) on the device with the plan's magic (estimate is exact or one low; branch-free fix-up); *rem = n - q*d

@@ -311,7 +311,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   }
   (void)n_uniform;
   p->tile_store = knobs().no_tile_store ? 0 : 1;
-  p->compute = d->compute == DN_COMPUTE_BF16 ? DN_COMPUTE_BF16 : DN_COMPUTE_F32;
+  p->compute = (d->compute == DN_COMPUTE_BF16 || d->compute == DN_COMPUTE_F32X3) ? d->compute : DN_COMPUTE_F32;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;
@@ -358,7 +358,7 @@ int dn_device_arch_ok(void) {
 int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (dn::build_plan(d, false, &p) != DN_OK) return -1;
-  if (dn::wino_eligible(d, p)) return dn::wino_packed_elems(p);
+  if (const int wl = dn::wino_layout(d, p)) return dn::wino_packed_floats(p, wl);
   const dn::KPhase& last = p.ph[p.nphases - 1];
   return last.w_off + (int64_t)p.Npad * last.nchunks * dn::kChunk;
 }

@@ -181,8 +181,19 @@ int launch_wino_pack_many(const PackEntry* tab_dev, int first, int n, hipStream_
   return check_launch("wino_pack_many_kernel");
 }
 
-// bf16 fragment order: wp16[k/16][pos][n/32][lane][e] = bf16(U_pos[n][k]),  k = 16*(k/16) + 8*(lane >> 5) + e (e = 0..7),
-// n = 32*(n/32) + (lane & 31): the 16 bytes a lane feeds to one v_mfma_f32_32x32x16_bf16 as the B operand
+// bf16 fragment order: wp16[k/16][pos][n/32][piece][lane][e] = piece_s(U_pos[n][k]),  k = 16*(k/16) + 8*(lane >> 5) + e (e = 0..7),
+// n = 32*(n/32) + (lane & 31): the 16 bytes a lane feeds to one v_mfma_f32_32x32x16_bf16 as the B operand.
+//   NSPL = 1 (DN_COMPUTE_BF16) : piece_0 = U rounded to bf16 (nearest even)
+//   NSPL = 3 (DN_COMPUTE_F32X3): U = piece_0 + piece_1 + piece_2 EXACTLY (each piece the bf16 rounding of what the previous ones left;
+//                                3 x 8 significant bits hold any fp32 value)
+__device__ __forceinline__ void wino_split3(float x, __bf16* pc) {
+  pc[0] = (__bf16)x;
+  const float r1 = x - (float)pc[0];        // exact (Sterbenz), at most 16 significant bits
+  pc[1] = (__bf16)r1;
+  pc[2] = (__bf16)(r1 - (float)pc[1]);      // exact, at most 8 significant bits: the conversion does not round
+}
+
+template <int NSPL>
 __device__ __forceinline__ void wino_pack16_body(const IgemmParams& p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
   __bf16* wp16 = reinterpret_cast<__bf16*>(wp);
   const long long npairs = total >> 4;                       // (n, k) pairs, each written at 16 positions
@@ -227,45 +238,68 @@ __device__ __forceinline__ void wino_pack16_body(const IgemmParams& p, const flo
       t4[2][bb] = 0.5f * (g0 - g1 + g2);
       t4[3][bb] = g2;
     }
-    __bf16* dst = wp16 + (((long long)kc16 * 16 * NS + nsub) * 64 + lane) * 8 + e;
-    const long long posB = (long long)NS * 64 * 8;             // elements between two positions
+    __bf16* dst = wp16 + ((((long long)kc16 * 16 * NS + nsub) * NSPL) * 64 + lane) * 8 + e;
+    const long long posB = (long long)NS * NSPL * 64 * 8;     // elements between two positions
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float u0 = t4[i][0], u1 = 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]), u2 = 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]), u3 = t4[i][2];
-      dst[(4 * i + 0) * posB] = (__bf16)u0;
-      dst[(4 * i + 1) * posB] = (__bf16)u1;
-      dst[(4 * i + 2) * posB] = (__bf16)u2;
-      dst[(4 * i + 3) * posB] = (__bf16)u3;
+      float u[4];
+      u[0] = t4[i][0];
+      u[1] = 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]);
+      u[2] = 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]);
+      u[3] = t4[i][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (NSPL == 1) {
+          dst[(4 * i + j) * posB] = (__bf16)u[j];
+        } else {
+          __bf16 pc[3];
+          wino_split3(u[j], pc);
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp) dst[(4 * i + j) * posB + sp * 512] = pc[sp];
+        }
+      }
     }
   }
 }
 
+template <int NSPL>
 __global__ void wino_pack16_kernel(const IgemmParams p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
-  wino_pack16_body(p, w, wp, NS, total);
+  wino_pack16_body<NSPL>(p, w, wp, NS, total);
 }
 
+template <int NSPL>
 __global__ void wino_pack16_many_kernel(const PackEntry* __restrict__ tab) {
   const PackEntry& e = tab[blockIdx.y];
-  wino_pack16_body(e.p, e.w, e.wp, e.NS, e.total);
+  wino_pack16_body<NSPL>(e.p, e.w, e.wp, e.NS, e.total);
 }
 
-int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(wino_pack16_many_kernel, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
+int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, int pieces, hipStream_t stream) {
+  if (pieces == 3) hipLaunchKernelGGL(wino_pack16_many_kernel<3>, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
+  else hipLaunchKernelGGL(wino_pack16_many_kernel<1>, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
   return check_launch("wino_pack16_many_kernel");
 }
 
-int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, hipStream_t stream) {
+int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, int pieces, hipStream_t stream) {
   const long long total = wino_packed_elems(p);              // (n, k) pairs x 16 positions, as for the fp32 layout
   int blocks = (int)(((total >> 4) + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wino_pack16_kernel, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
+  if (pieces == 3) hipLaunchKernelGGL(wino_pack16_kernel<3>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
+  else hipLaunchKernelGGL(wino_pack16_kernel<1>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
   return check_launch("wino_pack16_kernel");
 }
 
-// 0: not a Winograd layer; 1: fp32 Winograd; 2: bf16-multiply Winograd (descriptor compute = DN_COMPUTE_BF16 on the default tile variant)
+// 0: not a Winograd layer; 1: fp32 Winograd; 2: bf16-multiply Winograd (descriptor compute = DN_COMPUTE_BF16); 3: fp32 products from
+// three bf16 pieces per operand (DN_COMPUTE_F32X3) -- the last two on the default tile variant only
 int wino_layout(const dn_conv_desc* d, const IgemmParams& p) {
   if (!wino_eligible(d, p)) return 0;
-  return (p.compute == DN_COMPUTE_BF16 && knobs().wino_mtw == 1 && knobs().wino_dbg == 0) ? 2 : 1;
+  if (knobs().wino_mtw != 1 || (knobs().wino_dbg != 0 && knobs().wino_dbg < 16)) return 1;
+  return p.compute == DN_COMPUTE_BF16 ? 2 : (p.compute == DN_COMPUTE_F32X3 ? 3 : 1);
+}
+
+// floats of the packed buffer for a given layout (layout 3 holds three bf16 per element: 1.5 floats)
+long long wino_packed_floats(const IgemmParams& p, int layout) {
+  const long long n = wino_packed_elems(p);
+  return layout == 3 ? n + n / 2 : n;
 }
 
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream) {
@@ -305,6 +339,13 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // v_mfma_f32_32x32x16_bf16 consumes a whole 16-channel chunk of one position: 8 matrix instructions (256 cycles) per chunk
 // instead of 64 (4096).  The kernel is then bound by the staging work and by HBM, not by the matrix pipe; activations, weights
 // (master copy), accumulators, transforms, statistics and everything outside this kernel stay fp32.
+// F32X3 variant (PREC = 3): fp32 products on the bf16 matrix cores.  Staging is the fp32 kernel's (fp32 planes in LDS, same layout,
+// double-buffered, two blocks per CU); a wave reads the 8 fp32 values of its A fragment (two ds_read_b128) and splits them EXACTLY
+// into three bf16 pieces in registers (x = x0 + x1 + x2: round, subtract, round, subtract -- each transformed value is consumed by
+// exactly one wave, so splitting at the consumer costs the same vector work as splitting at the producer and needs neither 1.5x the
+// LDS nor 48 registers of pending pieces); the weights are packed as three pieces; SIX matrix instructions per (position, 32 couts):
+// x0y2, x2y0, x1y1, x1y0, x0y1, x0y0 -- 48 per chunk = 1536 cycles against the 4096 of the fp32 instruction, and unlike that one they
+// leave the vector ALUs to the wave: ~6 vector instructions issue under each of them (tools/ubench/agpr_issue.hip).
 constexpr int W16_ROWB = 48;                          // bytes of one tile's 16 bf16 (+16 padding)
 template <int VW> struct VecOf;
 template <> struct VecOf<4> { typedef f32x4 type; };
@@ -323,11 +364,13 @@ __device__ __forceinline__ typename VecOf<VW>::type buffer_load_vec(__amdgpu_buf
   }
 }
 
-template <int MTW, bool HA, int DBG, bool BF = false>
+template <int MTW, bool HA, int DBG, int PREC = 0>     // PREC 0: fp32 matrix instruction, 1: bf16 operands, 3: three bf16 pieces per operand
 __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const IgemmParams p) {
-  static_assert(!BF || MTW == 1, "the bf16 variant exists for the two-blocks-per-CU tile only");
+  constexpr bool BF = PREC != 0;
+  static_assert(!BF || MTW == 1, "the bf16 variants exist for the two-blocks-per-CU tile only");
   using Cfg = WinoCfg<MTW>;
-  constexpr int PLANE16 = Cfg::BT * W16_ROWB, BUF16 = 16 * PLANE16;      // BF: one position plane / one 16-channel chunk
+  constexpr int ROW16 = W16_ROWB;
+  constexpr int PLANE16 = Cfg::BT * ROW16, BUF16 = 16 * PLANE16;      // PREC 1: one position plane / one 16-channel chunk
   constexpr int BT = Cfg::BT, HALFB = Cfg::HALFB, POSB = Cfg::POSB, SUBB = Cfg::SUBB, BUFB = Cfg::BUFB;
   extern __shared__ __align__(16) float smem[];
   char* smemB = reinterpret_cast<char*>(smem);
@@ -384,28 +427,42 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   const int stA = (k0 >> 3) * SUBB + ((k0 >> 2) & 1) * HALFB + st_tile * 16 + (k0 & 3) * 4;   // staging store offset in a buffer (+ pos * POSB)
   const int frA = (4 * wave) * POSB + (lane >> 5) * HALFB + (lane & 31) * 16;  // fragment read offset in an 8-k group
   // BF: staging store (one dword = channels k0, k0+1 as bf16) and fragment read (8 bf16 = k 8*(lane>>5)..+7 of tile lane&31)
-  const int stA16 = st_tile * W16_ROWB + k0 * 2;                                 // (+ pos * PLANE16)
-  const int frA16 = (4 * wave) * PLANE16 + (lane & 31) * W16_ROWB + (lane >> 5) * 16;
-  // BF weights: wp16[chunk][pos][n/32][lane][8 bf16]: 1 KiB per (chunk, position, 32 couts)
-  const char* wcur16 = reinterpret_cast<const char*>(p.w) + ((size_t)(4 * wave) * NS + 2 * nb) * 1024 + lane * 16;
-  const size_t wchunk16B = (size_t)16 * NS * 1024;
-  bf16x8 breg16[4][2];
+  const int stA16 = st_tile * ROW16 + k0 * 2;                                    // (+ pos * PLANE16, + 32 * piece)
+  const int frA16 = (4 * wave) * PLANE16 + (lane & 31) * ROW16 + (lane >> 5) * 16;
+  // BF weights: wp16[chunk][pos][n/32][piece][lane][8 bf16]: 1 KiB per (chunk, position, 32 couts, piece)
+  constexpr int NPC = PREC == 3 ? 3 : 1;
+  const char* wcur16 = reinterpret_cast<const char*>(p.w) + ((size_t)(4 * wave) * NS + 2 * nb) * (1024 * NPC) + lane * 16;
+  const size_t wchunk16B = (size_t)16 * NS * 1024 * NPC, wj16B = (size_t)NS * 1024 * NPC;
+  bf16x8 breg16[PREC == 1 ? 4 : 1][2];
   auto load_b16 = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn) breg16[j][nn] = *reinterpret_cast<const bf16x8*>(wcur16 + (size_t)j * wjB + nn * 1024);
+      for (int nn = 0; nn < 2; ++nn) breg16[PREC == 1 ? j : 0][nn] = *reinterpret_cast<const bf16x8*>(wcur16 + (size_t)j * wj16B + nn * 1024);
     wcur16 += wchunk16B;
   };
-  if constexpr (!BF) {
+  // PREC 3: weight unit u = 2 j + half of a chunk = the three pieces of one (position, 32 couts); two units of registers, refilled
+  // piece by piece as the matrix instructions of unit u release them with the pieces of unit u + 2 (which may lie in the next chunk /
+  // operand / the slack chunk): 24 registers, 9-11 matrix instructions of lead
+  bf16x8 bq[PREC == 3 ? 2 : 1][3];
+  auto load_b3 = [&](int u, int piece) {               // u = 0 .. 9 relative to the current chunk's base pointer wcur16
+    const size_t off = (size_t)(u >> 3) * wchunk16B + (size_t)((u & 7) >> 1) * wj16B + (size_t)(u & 1) * 3072 + (size_t)piece * 1024;
+    bq[PREC == 3 ? (u & 1) : 0][piece] = *reinterpret_cast<const bf16x8*>(wcur16 + off);
+  };
+  if constexpr (PREC == 0) {
     load_b(0);
     advance_b(0);
     load_b(1);
     advance_b(1);
     load_b(2);
     advance_b(2);
-  } else {
+  } else if constexpr (PREC == 1) {
     load_b16();
+  } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) load_b3(u, piece);
   }
 
   // slot schedule (compile-time): NSL slots per 16-channel chunk, one MFMA each; H = first slot of the second 8-k group
@@ -430,10 +487,11 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     float relu_floor = 0.f;
     int cnB = 0;                       // byte offset (channels) of the chunk whose loads are issued next
 
-    auto load_v = [&](int i) {
+    auto load_v_t = [&](int i, auto sc_tag, unsigned mask) __attribute__((always_inline)) {
+      constexpr bool SC1 = decltype(sc_tag)::value;
       const int a = i >> 2, b = i & 3;
-      const bool ok = (pmask >> i) & 1u;
-      if (scalar1) {
+      const bool ok = (mask >> i) & 1u;
+      if constexpr (SC1) {
         int off = (pn * (int)S.sn + ((py + a) >> S.up) * (int)S.sh + ((px + b) >> S.up) * (int)S.sw) * 4;
         off = (ok && k0 == 0) ? off : -1;
         const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
@@ -447,6 +505,10 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       asm volatile("" : "+v"(off));
       off = ok ? off : -1;                               // past num_records: the buffer load returns zeros
       v[i] = buffer_load_vec<VW>(rsrc, off);
+    };
+    auto load_v = [&](int i) __attribute__((always_inline)) {
+      if (scalar1) load_v_t(i, std::true_type{}, pmask);
+      else load_v_t(i, std::false_type{}, pmask);
     };
     auto load_aff = [&]() {
       if constexpr (HA) {
@@ -463,7 +525,9 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     auto affine_piece = [&](int i) {
       if constexpr (HA) {
         // clamp to [floor, cap]: floor = 0 is the ReLU, cap = 0 re-zeroes a halo pixel the BatchNorm shift lifted (one v_med3 each)
-        const float cap = ((pmask >> i) & 1u) ? __builtin_huge_valf() : 0.f;
+        unsigned pm = pmask;
+        if constexpr (PREC == 3) asm volatile("" : "+v"(pm));     // (keeps the 16 caps from being hoisted out of the chunk loop into registers)
+        const float cap = ((pm >> i) & 1u) ? __builtin_huge_valf() : 0.f;
 #pragma unroll
         for (int e = 0; e < VW; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc4[e], sh4[e]), relu_floor, cap);
       }
@@ -476,7 +540,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       v[12 + b] = d1 - v[12 + b];
     };
     auto col_piece = [&](int b2, int i, int half) {    // (B^T d) B and the LDS stores of transform row i
-      if constexpr (BF) {
+      if constexpr (PREC == 1) {
         char* dst16 = smemB + b2 * BUF16 + stA16 + (4 * i) * PLANE16;
         auto put = [&](int pos, const fV& val) {
           const bf16x2 h = __builtin_convertvector(val, bf16x2);              // v_cvt_pk_bf16_f32 (round to nearest even)
@@ -531,7 +595,81 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     __syncthreads();
     if (DBG & 4) t1 = clock64();
 
-    if constexpr (BF) {
+    if constexpr (PREC == 3) {
+      // One chunk = 48 matrix instructions (slot m = 12 j + 2 t + half); the side work of a slot is what the wave issues while that
+      // instruction executes: the fp32 kernel's staging of the NEXT chunk (patch loads, pending BatchNorm, transform, LDS stores) and
+      // the split of the next position's A fragment.
+      const int frA3 = (4 * wave) * POSB + (lane >> 5) * SUBB + (lane & 31) * 16;   // lane (tile, g): k 8g..8g+7 = 8-k group g, both halves
+      f32x4 raw[2];
+      bf16x8 fa3[2][3];
+      auto read_raw = [&](const char* Ab, int j) {
+        raw[0] = *reinterpret_cast<const f32x4*>(Ab + j * POSB);
+        raw[1] = *reinterpret_cast<const f32x4*>(Ab + j * POSB + HALFB);
+      };
+      auto split_pair = [&](int slot, int q) {          // channels 2q, 2q+1 of the fragment: x = h + m + l exactly
+        const f32x2 x = f32x2{raw[q >> 1][2 * (q & 1)], raw[q >> 1][2 * (q & 1) + 1]};
+        if constexpr (DBG & 16) {                       // ablation (timing only, wrong results): no split arithmetic
+          const bf16x2 h = __builtin_convertvector(x, bf16x2);
+          fa3[slot][0][2 * q] = h[0]; fa3[slot][0][2 * q + 1] = h[1];
+          fa3[slot][1][2 * q] = h[1]; fa3[slot][1][2 * q + 1] = h[0];
+          fa3[slot][2][2 * q] = h[0]; fa3[slot][2][2 * q + 1] = h[0];
+          return;
+        }
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        fa3[slot][0][2 * q] = h[0]; fa3[slot][0][2 * q + 1] = h[1];
+        fa3[slot][1][2 * q] = m[0]; fa3[slot][1][2 * q + 1] = m[1];
+        fa3[slot][2][2 * q] = l[0]; fa3[slot][2][2 * q + 1] = l[1];
+      };
+      // (a 1-channel piece is a single chunk: what the loop "re-fetches" for it is never used, so its loads are masked off instead of
+      //  carrying the gather path's instruction stream and branches through every slot)
+      const unsigned lmask = scalar1 ? 0u : pmask;
+      for (int c = 0; c < nch; ++c) {
+        const bool more = c + 1 < nch;
+        cnB = (more ? c + 1 : c) * (WKC * 4);            // the last chunk re-fetches itself into the idle buffer: no branch
+        const char* Ab = smemB + buf * BUFB + frA3;
+        read_raw(Ab, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_pair(0, q);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<48>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int j = m / 12, q12 = m % 12, nn = q12 / 6, t = q12 % 6, u = 2 * j + nn;      // u: weight unit of this chunk
+          // x0y2, x0y1, x1y1, x0y0, x1y0, x2y0: the weight pieces are released in the order 2, 1, 0
+          // (a chain of dependent matrix instructions on one accumulator issues at the full rate: tools/ubench/agpr_issue.hip)
+          constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+          acc[j][0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[j & 1][AS[t]], bq[u & 1][BS[t]], acc[j][0][nn], 0, 0, 0);
+          // ---- side work of this slot
+          if constexpr (!(DBG & 32)) {                             // (DBG 32: ablation without the weight stream)
+            if constexpr (t == 1) load_b3(u + 2, 2);
+            if constexpr (t == 3) load_b3(u + 2, 1);
+            if constexpr (t == 0 && m > 0) load_b3(u + 1, 0);     // (piece 0 of the previous unit's successor: released by its last instruction)
+          }
+          if constexpr (j < 3 && q12 == 1) read_raw(Ab, j + 1);
+          if constexpr (j < 3 && q12 >= 6 && q12 < 10) split_pair((j + 1) & 1, q12 - 6);
+          constexpr bool STG = !(DBG & 64);                       // (DBG 64: ablation without the staging of the next chunk)
+          if constexpr (STG && m >= 2 && m < 18) load_v_t(m - 2, std::false_type{}, lmask);
+          if constexpr (STG && m == 18) load_aff();
+          // transform + stores of the next chunk: 16 affine pieces, 4 row pieces, 8 column pieces over slots 22 .. 47
+          if constexpr (STG && m >= 22 && m < 30) {
+            affine_piece(2 * (m - 22));
+            affine_piece(2 * (m - 22) + 1);
+          }
+          if constexpr (STG && m >= 30 && m < 34) row_piece(m - 30);
+          if constexpr (STG && m >= 34 && m < 42) col_piece(buf ^ 1, (m - 34) / 2, (m - 34) % 2);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (!(DBG & 32)) load_b3(9, 0);        // piece 0 of unit 1 of the next chunk
+        wcur16 += wchunk16B;
+        __syncthreads();
+        buf ^= 1;
+      }
+      continue;
+    }
+    if constexpr (PREC == 1) {
       for (int c = 0; c < nch; ++c) {
         const bool more = c + 1 < nch;
         cnB = (more ? c + 1 : c) * (WKC * 4);          // the last chunk re-fetches itself into the idle buffer: no branch
@@ -840,13 +978,14 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   }
 }
 
-template <int MTW, bool HA, int DBG, bool BF = false>
+template <int MTW, bool HA, int DBG, int PREC = 0>
 static int launch_wino_variant(const IgemmParams& p, hipStream_t stream) {
   using Cfg = WinoCfg<MTW>;
-  auto kernel = wino_conv_kernel<MTW, HA, DBG, BF>;
-  // BF: two 16-channel chunks of bf16 planes, or the epilogue's cross-wave exchange + statistics scratch, whichever is larger
-  constexpr size_t lds16a = (size_t)2 * 16 * Cfg::BT * W16_ROWB, lds16b = (size_t)(4 * Cfg::BT * WZLD + MTW * 5 * 64) * sizeof(float);
-  constexpr size_t lds = BF ? (lds16a > lds16b ? lds16a : lds16b) : Cfg::LDS;
+  auto kernel = wino_conv_kernel<MTW, HA, DBG, PREC>;
+  // PREC 1: two 16-channel chunks of bf16 planes, or the epilogue's cross-wave exchange + statistics scratch, whichever is larger
+  constexpr size_t lds16a = (size_t)2 * 16 * Cfg::BT * W16_ROWB;
+  constexpr size_t lds16b = (size_t)(4 * Cfg::BT * WZLD + MTW * 5 * 64) * sizeof(float);
+  constexpr size_t lds = PREC == 1 ? (lds16a > lds16b ? lds16a : lds16b) : Cfg::LDS;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino_conv_kernel, %zu): %s", lds, hipGetErrorString(e));
@@ -855,8 +994,7 @@ static int launch_wino_variant(const IgemmParams& p, hipStream_t stream) {
   const int tiles = ((p.T + Cfg::BT - 1) / Cfg::BT) * (p.Npad / WBN);
   dim3 grid((tiles + 7) / 8 * 8);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
-  if (BF) set_last_kernel("dn::wino_conv_kernel<%d, %s, %d, true>", MTW, HA ? "true" : "false", DBG);
-  else set_last_kernel("dn::wino_conv_kernel<%d, %s, %d>", MTW, HA ? "true" : "false", DBG);
+  set_last_kernel("dn::wino_conv_kernel<%d, %s, %d, %d>", MTW, HA ? "true" : "false", DBG, PREC);
   return check_launch("wino_conv_kernel");
 }
 
@@ -868,8 +1006,17 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
   const int dbg = knobs().wino_dbg, mtw = knobs().wino_mtw;
-  if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variant may be used)
-    return p.any_affine ? launch_wino_variant<1, true, 0, true>(p, stream) : launch_wino_variant<1, false, 0, true>(p, stream);
+  if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variants may be used)
+    return p.any_affine ? launch_wino_variant<1, true, 0, 1>(p, stream) : launch_wino_variant<1, false, 0, 1>(p, stream);
+  if (p.compute == DN_COMPUTE_F32X3) {
+    switch (knobs().wino_dbg) {            // 16 / 32 / 64 / 112: timing ablations of the three-piece variant (wrong results)
+      case 16: return p.any_affine ? launch_wino_variant<1, true, 16, 3>(p, stream) : launch_wino_variant<1, false, 16, 3>(p, stream);
+      case 32: return p.any_affine ? launch_wino_variant<1, true, 32, 3>(p, stream) : launch_wino_variant<1, false, 32, 3>(p, stream);
+      case 64: return p.any_affine ? launch_wino_variant<1, true, 64, 3>(p, stream) : launch_wino_variant<1, false, 64, 3>(p, stream);
+      case 112: return p.any_affine ? launch_wino_variant<1, true, 112, 3>(p, stream) : launch_wino_variant<1, false, 112, 3>(p, stream);
+      default: return p.any_affine ? launch_wino_variant<1, true, 0, 3>(p, stream) : launch_wino_variant<1, false, 0, 3>(p, stream);
+    }
+  }
   if (dbg == 12) {                       // timestamps + no result stores (ablation, tools/wino_timing.py 12)
     p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
     return p.any_affine ? launch_wino_variant<1, true, 12>(p, stream) : launch_wino_variant<1, false, 12>(p, stream);

@@ -38,19 +38,27 @@ PROFILE = None
 # DN_BN_MATERIALIZE=1: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back) for A/B runs and the equivalence test
 BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
 
-# Arithmetic of the matrix-core kernels that offer a choice (dn_conv_desc.compute): "f32" (default; what every parity statement and the
-# headline benchmark use) or "bf16" = bf16 multiplies with fp32 accumulation in the Winograd forward / input-gradient kernels -- the
-# "mixed precision" mode of BASELINE configs[4].  Tensors in HBM, statistics, transforms and all other kernels stay fp32.
-# DN_COMPUTE=bf16 or set_compute("bf16").
-COMPUTE = _lib.COMPUTE_BF16 if os.environ.get("DN_COMPUTE", "f32").lower() == "bf16" else _lib.COMPUTE_F32
+# Arithmetic of the matrix-core kernels that offer a choice (dn_conv_desc.compute, include/dispnet_hip.h), today the Winograd forward /
+# input-gradient kernels.  Tensors in HBM, statistics, transforms and all other kernels are fp32 in every mode.
+#   "f32"   fp32 FMA chain on the fp32 matrix instruction
+#   "f32x3" fp32 products on the bf16 matrix cores: operands split exactly into three bf16 pieces, six partial products, fp32
+#           accumulation -- the same error against fp64 as "f32" (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64)
+#   "bf16"  operands rounded to bf16, fp32 accumulation: the "mixed precision" mode of BASELINE configs[4]
+# DN_COMPUTE=... or set_compute(...).
+COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f32x3": _lib.COMPUTE_F32X3}
+COMPUTE = COMPUTE_MODES.get(os.environ.get("DN_COMPUTE", "f32").lower(), _lib.COMPUTE_F32)
 
 
 def set_compute(mode):
     global COMPUTE
-    if mode not in ("f32", "bf16"):
-        raise ValueError("compute mode is 'f32' or 'bf16', got %r" % (mode,))
-    COMPUTE = _lib.COMPUTE_BF16 if mode == "bf16" else _lib.COMPUTE_F32
+    if mode not in COMPUTE_MODES:
+        raise ValueError("compute mode is one of %s, got %r" % (sorted(COMPUTE_MODES), mode))
+    COMPUTE = COMPUTE_MODES[mode]
     bump_param_epoch()
+
+
+def compute_mode():
+    return [k for k, v in COMPUTE_MODES.items() if v == COMPUTE][0]
 
 
 # True while graph.GraphedStep records a step into a hipGraph (nothing in the engine may synchronise or time launches then)
@@ -400,7 +408,7 @@ class PackTable(object):
         self.rows = {}                  # key -> [entry bytes, wino flag, weight tensor, packed buffer, weight ptr]
         self.dirty = True
         self.dev_table = None
-        self.counts = (0, 0, 0)
+        self.counts = (0, 0, 0, 0)
         self.epoch = -1                 # PARAM_EPOCH whose weights the buffers of `covered` hold
         self.covered = set()
         self.esize = int(_lib.load().dn_pack_entry_bytes())
@@ -429,14 +437,14 @@ class PackTable(object):
         if not self.rows:
             return
         if self.dirty:
-            kinds = [[r for r in self.rows.values() if r[1] == k] for k in (0, 1, 2)]      # direct, Winograd fp32, Winograd bf16
-            ordered = kinds[0] + kinds[1] + kinds[2]
+            kinds = [[r for r in self.rows.values() if r[1] == k] for k in (0, 1, 2, 3)]   # direct, Winograd fp32 / bf16 / 3 x bf16
+            ordered = kinds[0] + kinds[1] + kinds[2] + kinds[3]
             blob = b"".join(r[0] for r in ordered)
             self.dev_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
             self.counts = tuple(len(k) for k in kinds)
             self.covered = {r[3].data_ptr() for r in ordered}
             self.dirty = False
-        _lib.call("dn_pack_many", self.dev_table.data_ptr(), self.counts[0], self.counts[1], self.counts[2], _stream())
+        _lib.call("dn_pack_many", self.dev_table.data_ptr(), *self.counts, _stream())
         self.epoch = epoch
 
 

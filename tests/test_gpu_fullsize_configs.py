@@ -290,7 +290,7 @@ def test_config5_mixed_precision_mode_vs_fp32():
     finally:
         engine.PROFILE = None
         engine.set_compute("f32")
-    is_bf = lambda n: "wino_conv_kernel" in n and n.endswith(", true>")
+    is_bf = lambda n: "wino_conv_kernel" in n and n.endswith(", 1>")
     nbf = sum(is_bf(n) for n in res["bf16"][4])
     assert nbf >= 30 and not any(is_bf(n) for n in res["f32"][4]), nbf      # the bf16 kernels are what ran
     d0, o0, l0, g0, _ = res["f32"]

@@ -283,20 +283,31 @@ def test_winograd_error_vs_fp64(monkeypatch):
     x = torch.rand(N, H, W, cin, device=DEV)               # non-negative like a post-ReLU activation (the unfavourable case)
     ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), mod.weight.detach().double().cpu(), mod.bias.detach().double().cpu(), padding=1)
     ref = ref.permute(0, 2, 3, 1)
-    errs = {}
-    for tag, env in (("wino", None), ("direct", "1")):
-        if env is None:
-            monkeypatch.delenv("DN_NO_WINOGRAD", raising=False)
-        else:
-            monkeypatch.setenv("DN_NO_WINOGRAD", env)
-        _lib.load().dn_reload_knobs()
-        layer = engine.ConvLayer(mod)
-        y, _, _ = engine.conv_forward(layer, [engine.Piece(engine.Act(x, N, H, W, cin))])
-        torch.cuda.synchronize()
-        errs[tag] = float((y.double().cpu() - ref).abs().max())
+    errs, l2 = {}, {}
+    try:
+        for tag, env, mode in (("wino", None, "f32"), ("direct", "1", "f32"), ("wino_f32x3", None, "f32x3")):
+            if env is None:
+                monkeypatch.delenv("DN_NO_WINOGRAD", raising=False)
+            else:
+                monkeypatch.setenv("DN_NO_WINOGRAD", env)
+            _lib.load().dn_reload_knobs()
+            engine.set_compute(mode)
+            layer = engine.ConvLayer(mod)
+            y, _, _ = engine.conv_forward(layer, [engine.Piece(engine.Act(x, N, H, W, cin))])
+            torch.cuda.synchronize()
+            assert ("wino_conv_kernel" in _lib.load().dn_last_kernel().decode()) == (env is None)
+            errs[tag] = float((y.double().cpu() - ref).abs().max())
+            l2[tag] = float((y.double().cpu() - ref).norm() / ref.norm())
+    finally:
+        engine.set_compute("f32")
     scale = float(ref.abs().max())
-    print("max |err| vs fp64: winograd %.3g, direct %.3g (result magnitude %.3g)" % (errs["wino"], errs["direct"], scale))
+    print("max |err| vs fp64: winograd %.3g, direct %.3g, winograd on three-piece bf16 products %.3g (result magnitude %.3g)" % (
+        errs["wino"], errs["direct"], errs["wino_f32x3"], scale))
+    print("relative L2 vs fp64: winograd %.3g, direct %.3g, three-piece %.3g" % (l2["wino"], l2["direct"], l2["wino_f32x3"]))
     assert errs["wino"] <= 4.0 * errs["direct"] + 2e-6 * scale
+    # the three-piece products are fp32 products: the same error level as the fp32 matrix instruction (stated: <= 1.5x + 2e-7 of the magnitude)
+    assert errs["wino_f32x3"] <= 1.5 * errs["wino"] + 2e-7 * scale
+    assert l2["wino_f32x3"] <= 1.5 * l2["wino"]
 
 
 def _rel_l2(got, want):
@@ -304,23 +315,33 @@ def _rel_l2(got, want):
     return float((got - want).norm() / (want.norm() + 1e-300))
 
 
-@pytest.mark.parametrize("case", ["plain_128_64", "bn_pending_64_128", "concat_64_64_1"])
-def test_winograd_bf16_compute_mode(case):
-    """dn_conv_desc.compute = DN_COMPUTE_BF16 (BASELINE configs[4]'s mixed precision): the Winograd forward / input gradient multiply
-    bf16-rounded transformed tiles and weights on v_mfma_f32_32x32x16_bf16 and accumulate in fp32.  Against the fp32 Winograd kernel
-    on the same inputs.  Stated tolerance: relative L2 error <= 8e-3 and max error <= 3 % of the result's magnitude (two operands
-    rounded to 8 significant bits: 2^-9 rms each, ~3e-3 expected); the kernel name proves which variant ran; the weight gradient has
-    no bf16 variant and must be bit-identical."""
+@pytest.mark.parametrize("mode", ["bf16", "f32x3"])
+@pytest.mark.parametrize("case", ["plain_128_64", "bn_pending_64_128", "concat_64_64_1", "long_k_512_64"])
+def test_winograd_compute_modes(case, mode):
+    """dn_conv_desc.compute on the Winograd forward / input gradient, against the fp32 matrix-instruction kernel on the same inputs.
+    bf16  (BASELINE configs[4]'s mixed precision): transformed tiles and weights ROUNDED to bf16, fp32 accumulation on
+          v_mfma_f32_32x32x16_bf16.  Stated tolerance: relative L2 error <= 8e-3, max error <= 3 % of the result's magnitude
+          (two operands rounded to 8 significant bits, 2^-9 rms each; measured 4e-3).
+    f32x3 every fp32 operand split exactly into three bf16 pieces, six partial products, fp32 accumulation: an fp32 result.  Stated
+          tolerance: the agreement two fp32 summation orders have (the same bound test_winograd_path_is_taken_and_matches_direct puts
+          between the Winograd and the direct kernel): rtol 1e-4 / atol 1e-5 of the magnitude, relative L2 <= 2e-6.
+    The kernel name proves which variant ran; the weight gradient has no such variant and must be bit-identical."""
     torch.manual_seed(11)
     N, H, W = 3, 18, 22
+    suffix = {"bf16": ", 1>", "f32x3": ", 3>"}[mode]
     try:
         res = {}
-        for mode in ("f32", "bf16"):
-            engine.set_compute(mode)
+        for m in ("f32", mode):
+            engine.set_compute(m)
             torch.manual_seed(12)
             if case == "plain_128_64":
                 mod = nn.Conv2d(128, 64, 3, 1, 1).to(DEV)
                 xa = engine.Act(torch.randn(N, H, W, 128, device=DEV), N, H, W, 128)
+                pieces = [engine.Piece(xa)]
+                cout = 64
+            elif case == "long_k_512_64":
+                mod = nn.Conv2d(512, 64, 3, 1, 1).to(DEV)
+                xa = engine.Act(torch.rand(N, H, W, 512, device=DEV), N, H, W, 512)       # non-negative: no cancellation in the sums
                 pieces = [engine.Piece(xa)]
                 cout = 64
             elif case == "bn_pending_64_128":
@@ -350,18 +371,22 @@ def test_winograd_bf16_compute_mode(case):
                 kd = kf
             dw = engine.conv_wgrad(layer, pieces, dy, (H, W))
             torch.cuda.synchronize()
-            res[mode] = (outs, kf, kd, dw)
+            res[m] = (outs, kf, kd, dw)
     finally:
         engine.set_compute("f32")
-    assert res["bf16"][1].endswith(", true>") and res["bf16"][2].endswith(", true>"), res["bf16"][1:3]
-    assert "wino_conv_kernel" in res["f32"][1] and not res["f32"][1].endswith(", true>")
-    assert torch.equal(res["bf16"][3], res["f32"][3])
-    for i, (got, want) in enumerate(zip(res["bf16"][0], res["f32"][0])):
+    assert "wino_conv_kernel" in res[mode][1] and res[mode][1].endswith(suffix) and res[mode][2].endswith(suffix), res[mode][1:3]
+    assert "wino_conv_kernel" in res["f32"][1] and res["f32"][1].endswith(", 0>")
+    assert torch.equal(res[mode][3], res["f32"][3])
+    for i, (got, want) in enumerate(zip(res[mode][0], res["f32"][0])):
         rel = _rel_l2(got, want)
         mx = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-30)
-        print("%s[%d]: relative L2 %.3g, max error / magnitude %.3g" % (case, i, rel, mx))
-        assert 1e-5 < rel <= 8e-3, (case, i, rel)        # (the lower bound: bf16 really was used)
-        assert mx <= 3e-2, (case, i, mx)
+        print("%s %s[%d]: relative L2 %.3g, max error / magnitude %.3g" % (mode, case, i, rel, mx))
+        if mode == "bf16":
+            assert 1e-5 < rel <= 8e-3, (case, i, rel)        # (the lower bound: bf16 really was used)
+            assert mx <= 3e-2, (case, i, mx)
+        else:
+            assert rel <= 2e-6, (case, i, rel)
+            close("%s[%d]" % (case, i), got, want, rtol=1e-4, atol_rel=1e-5)
 
 
 def test_bilinear_up2_matches_interpolate():

@@ -68,7 +68,7 @@ void run(const char* name) {
   double av = 0;
   for (int i = 0; i < blocks; ++i) av += h[i];
   av /= blocks;
-  printf("%-8s acc in %-8s %d waves/SIMD, %2d VALU/slot: ticks/MFMA %.1f | wall %.1f us\n", KIND ? "bf16x16" : "f32x2", AG ? "AccVGPR" : "VGPR", TPB / 256, FILL,
+  printf("%-8s acc in %-8s %d accumulators, %d waves/SIMD, %2d VALU/slot: ticks/MFMA %.1f | wall %.1f us\n", KIND ? "bf16x16" : "f32x2", AG ? "AccVGPR" : "VGPR", NACC, TPB / 256, FILL,
          av / (iters * 128.0), ms * 1e3);
   hipFree(out);
   hipFree(t);
@@ -88,6 +88,13 @@ void sweep() {
 }
 
 int main() {
+  // dependent chains: one / two accumulators per wave
+  run<1, 0, 1, 0, 256>("");
+  run<1, 0, 2, 0, 256>("");
+  run<1, 0, 1, 4, 256>("");
+  run<1, 0, 1, 0, 512>("");
+  run<1, 0, 2, 0, 512>("");
+  run<0, 0, 1, 0, 256>("");
   sweep<0, 0>();
   sweep<0, 1>();
   sweep<1, 0>();
