@@ -13,16 +13,24 @@ Rank 0 prints ONE JSON line.
   --config          vggbn128 (the headline) | vggbn480 | res50_480 | dorn128 | photo128: BASELINE.json configs[2..4] and the
                     480x640 secondary of SURVEY 8d produce their own lines (never the headline; `metric` says which).
 
+  --compute         f32x3 (default = the library's default) | f32 | bf16: arithmetic of the Winograd forward / input-gradient kernels.
+                    f32x3 forms every fp32 product on the bf16 matrix cores from three exact bf16 pieces per operand (six partial
+                    products, fp32 accumulation): an fp32 result -- error against fp64 at or below the fp32 instruction's
+                    (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64, tools/ubench/bf16x3.hip); every default run also times the
+                    same step with the fp32 matrix instruction (`f32_mfma_path`), so both numbers come from one run on one box.
+
 Besides the contract fields the line carries
-  roofline      the dominant MFMA-bound kernel (by time).  `achieved` = multiply-accumulates the kernel EXECUTES x 2 divided by
-                its launch durations (HIP events on the launch stream, instrumented steps after the timed region); `frac` =
-                achieved / 157.3 TFLOP/s (dense fp32 MFMA peak) and is <= 1 by construction.  The Winograd F(2x2,3x3) kernels
-                execute 16/36 of the direct convolution's MACs: the direct-FLOP rate BASELINE.md section 2 counts is reported
-                separately as `credited_achieved` / `credited_frac`.  `frac_of_measured_peak` divides by the register-resident
-                MFMA loop measured on this box in the same process (dn_ubench_mfma_f32).
+  roofline      the dominant matrix-pipe kernel (by time).  `achieved` = multiply-accumulates the kernel EXECUTES on its matrix pipe x 2
+                divided by its launch durations (HIP events on the launch stream, instrumented steps after the timed region); `peak` =
+                the dense peak of THAT pipe (2500 TFLOP/s bf16 for the f32x3 / bf16 Winograd variants, which execute six / one bf16
+                partial products per multiply; 157.3 TFLOP/s for the fp32 matrix instruction); `frac` <= 1 by construction.
+                `fp32_equivalent_achieved` counts each fp32 multiply-accumulate once (what a v_mfma_f32 kernel would have to sustain).
+                The Winograd F(2x2,3x3) kernels execute 16/36 of the direct convolution's MACs: the direct-FLOP rate BASELINE.md
+                section 2 counts is reported separately as `credited_achieved` / `credited_frac`.
   roofline_hbm  the slowest HBM-bound family of the step: algorithmic bytes (operands read once, results written once) over its
                 event time, against 8 TB/s and against the float4 copy rate measured on this box (dn_ubench_copy).
-  step_executed_frac  all conv-family launches' executed FLOPs over the step time, / 157.3.
+  step_executed_frac  all conv-family launches' fp32-equivalent executed FLOPs (each fp32 multiply-accumulate once) over the step time, / 157.3.
+  f32_mfma_path the same step timed with --compute f32 semantics (fp32 matrix instruction everywhere) after the headline region.
   cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU restatement pinned to the reference's golden vectors; kind "port")
                 running the same training step on this box's host cores per SURVEY 8d: batch 8, 2 warm-up + 5 timed steps.
 """
@@ -40,7 +48,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 matrix peak (only for a --compute bf16 kernel, never the headline)
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 matrix peak (the pipe the f32x3 / bf16 Winograd variants run on)
+X3_PRODUCTS = 6                      # f32x3: six bf16 partial products per fp32 multiply
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E spec (6.29 TB/s measured float4 copy there)
 WINO_EXEC = 16.0 / 36.0              # F(2x2,3x3): 16 element-wise products per 2x2 tile instead of 36 MACs
@@ -229,9 +238,13 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-warmup", type=int, default=2)
-    ap.add_argument("--compute", default="f32", choices=["f32", "f32x3", "bf16"],
-                    help="bf16: bf16 multiplies / fp32 accumulation in the Winograd forward and input-gradient kernels (the 'mixed "
-                         "precision' mode of BASELINE configs[4]); tensors in HBM and every other kernel stay fp32.  Never the headline.")
+    ap.add_argument("--compute", default="f32x3", choices=["f32", "f32x3", "bf16"],
+                    help="arithmetic of the Winograd forward / input-gradient kernels (tensors and every other kernel are fp32 in all modes). "
+                         "f32x3 (default, the library's default): fp32 products formed on the bf16 matrix cores from three exact bf16 pieces "
+                         "per operand, fp32 accumulation -- error vs fp64 at or below the fp32 instruction's (tests/test_gpu_kernels.py); "
+                         "f32: the fp32 matrix instruction (also timed in every default run: field f32_mfma_path); "
+                         "bf16: operands ROUNDED to bf16 (BASELINE configs[4]'s mixed precision; never the headline)")
+    ap.add_argument("--alt-steps", type=int, default=10, help="steps of the secondary timing with the fp32 matrix instruction (0: skip)")
     ap.add_argument("--graph", default="0", choices=["0", "1"],
                     help="1: replay the whole step (fwd + loss + bwd + Adam) as ONE captured hipGraph.  Off by default: measured on "
                          "ROCm 7.2 the replay is 1-4 %% SLOWER than the eager launches at every batch size (profiles/r02_strong_1gpu.txt)")
@@ -273,6 +286,8 @@ def main():
 
     engine.set_compute(args.compute)
     metric, netname, H, W, cfg_batch, ds, gflop_img = CONFIGS[args.config]
+    if args.compute == "bf16":
+        metric = metric.replace(", fp32)", ", mixed precision: bf16 multiplies / fp32 accumulation in the Winograd kernels)")
     if args.scaling == "strong":
         if args.global_batch % world:
             raise SystemExit("--global-batch %d does not divide over %d ranks" % (args.global_batch, world))
@@ -323,6 +338,33 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.item())
 
+    # ---- secondary timing (not `value`): the same step with the fp32 matrix instruction in the Winograd kernels, so that the line
+    #      carries both numbers from one run on one box
+    alt = None
+    if args.compute == "f32x3" and args.alt_steps > 0 and not graphed:
+        engine.set_compute("f32")
+        for _ in range(2):
+            eager_step()
+        gc.collect()
+        gc.disable()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.alt_steps):
+            eager_step()
+        fence()
+        adt = time.perf_counter() - t0
+        gc.enable()
+        if world > 1:
+            t = torch.tensor([adt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            adt = float(t.item())
+        alt = {"compute": "f32 (v_mfma_f32_32x32x2_f32 in every matrix kernel)", "value": batch * world * args.alt_steps / adt, "unit": "images/sec",
+               "ms_per_step": adt / args.alt_steps * 1e3, "steps": args.alt_steps}
+        engine.set_compute(args.compute)
+        for _ in range(2):
+            eager_step()
+        torch.cuda.synchronize()
+
     # ---- instrumented steps (not part of `value`): HIP events around every conv-family launch and every HBM-bound family
     roofline = roofline_hbm = None
     step_exec_flops = step_credited_flops = None
@@ -356,21 +398,38 @@ def main():
             else:
                 a = mf.setdefault(name, [0.0, 0.0, 0])
                 a[0] += flops; a[1] += sec; a[2] += 1
+        # multiply-accumulates x 2 the algorithm needs in fp32 terms (Winograd: 16/36 of the direct ones) ...
         execf = lambda k, fl: fl * (WINO_EXEC if "wino_" in k else 1.0)
+        # ... and what the matrix pipe the kernel runs on executes for them (f32x3: six bf16 partial products per fp32 multiply)
+        is_x3 = lambda k: "wino_conv_kernel" in k and k.endswith(", 3>")
+        is_bf = lambda k: "wino_conv_kernel" in k and k.endswith(", 1>")
+        pipef = lambda k, fl: execf(k, fl) * (X3_PRODUCTS if is_x3(k) else 1.0)
         step_credited_flops = sum(v[0] for v in mf.values()) / nps
         step_exec_flops = sum(execf(k, v[0]) for k, v in mf.items()) / nps
         name, (fl, sec, n) = max(mf.items(), key=lambda kv: kv[1][1])
         wino = "wino_" in name
-        ach = execf(name, fl) / sec / 1e12
-        kpeak = PEAK_BF16_MFMA_TFLOPS if ("wino_conv_kernel" in name and name.endswith((", 1>", ", 3>"))) else PEAK_FP32_MFMA_TFLOPS      # the bf16 Winograd variant
+        ach = pipef(name, fl) / sec / 1e12
+        on_bf16_pipe = is_x3(name) or is_bf(name)
+        kpeak = PEAK_BF16_MFMA_TFLOPS if on_bf16_pipe else PEAK_FP32_MFMA_TFLOPS
+        algo = "direct implicit GEMM"
+        if wino:
+            algo = "winograd F(2x2,3x3): executes 16/36 of the direct multiply-accumulates"
+            if is_x3(name):
+                algo += "; each fp32 product = six bf16 partial products (three exact bf16 pieces per operand) on v_mfma_f32_32x32x16_bf16, fp32 accumulation"
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": kpeak, "unit": "TFLOP/s",
                     "frac": ach / kpeak, "traffic": pmc_traffic(name),
-                    "frac_of_measured_peak": ach / peaks["mfma_f32_TFLOPs"], "measured_peak": peaks["mfma_f32_TFLOPs"],
-                    "algorithm": "winograd F(2x2,3x3): executes 16/36 of the direct multiply-accumulates" if wino else "direct implicit GEMM",
+                    "pipe": "bf16 matrix cores (dense peak 2500 TFLOP/s)" if on_bf16_pipe else "fp32 matrix instruction (157.3 TFLOP/s)",
+                    "fp32_equivalent_achieved": execf(name, fl) / sec / 1e12,
+                    "fp32_equivalent_frac_of_fp32_mfma_peak": execf(name, fl) / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "limiter": ("L2 -> CU bandwidth and vector-memory issue (ablations DN_WINO_DBG=32/64, DESIGN.md section 3), not the matrix pipe"
+                                if is_x3(name) else None),
+                    "frac_of_measured_peak": (ach / peaks["mfma_f32_TFLOPs"]) if not on_bf16_pipe else None, "measured_peak": peaks["mfma_f32_TFLOPs"],
+                    "algorithm": algo,
                     "credited_achieved": fl / sec / 1e12, "credited_frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                     "launches_per_step": n // nps, "avg_launch_ms": sec / n * 1e3, "avg_launch_gflop_executed": execf(name, fl) / n / 1e9,
                     "avg_launch_gflop_credited": fl / n / 1e9,
-                    "by_kernel": {k: {"tflops_executed": execf(k, v[0]) / v[1] / 1e12, "tflops_credited": v[0] / v[1] / 1e12,
+                    "by_kernel": {k: {"tflops_executed": pipef(k, v[0]) / v[1] / 1e12, "tflops_fp32_equivalent": execf(k, v[0]) / v[1] / 1e12,
+                                      "tflops_credited": v[0] / v[1] / 1e12,
                                       "ms_per_step": v[1] / nps * 1e3, "launches_per_step": v[2] // nps} for k, v in sorted(mf.items())}}
         if hb:
             name, (nb, sec, n) = max(hb.items(), key=lambda kv: kv[1][1])
@@ -406,7 +465,7 @@ def main():
             "step_credited_frac": (step_credited_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_credited_flops else None,
             "step_executed_frac": (step_exec_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_exec_flops else None,
             "baseline_md_gflop_per_img": gflop_img,
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "f32_mfma_path": alt, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -40,13 +40,15 @@ BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
 
 # Arithmetic of the matrix-core kernels that offer a choice (dn_conv_desc.compute, include/dispnet_hip.h), today the Winograd forward /
 # input-gradient kernels.  Tensors in HBM, statistics, transforms and all other kernels are fp32 in every mode.
-#   "f32"   fp32 FMA chain on the fp32 matrix instruction
-#   "f32x3" fp32 products on the bf16 matrix cores: operands split exactly into three bf16 pieces, six partial products, fp32
-#           accumulation -- the same error against fp64 as "f32" (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64)
-#   "bf16"  operands rounded to bf16, fp32 accumulation: the "mixed precision" mode of BASELINE configs[4]
+#   "f32x3" (default) fp32 products on the bf16 matrix cores: operands split exactly into three bf16 pieces, six partial products,
+#           fp32 accumulation -- an fp32 result: the same error against fp64 as "f32" or less
+#           (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64, ::test_winograd_compute_modes; the whole GPU suite -- oracle,
+#           reference goldens, fp64 yardsticks -- passes in either mode), 1.3x the fp32 instruction's speed on these kernels
+#   "f32"   fp32 FMA chain on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32)
+#   "bf16"  operands ROUNDED to bf16, fp32 accumulation: the "mixed precision" mode of BASELINE configs[4]; opt-in only
 # DN_COMPUTE=... or set_compute(...).
 COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f32x3": _lib.COMPUTE_F32X3}
-COMPUTE = COMPUTE_MODES.get(os.environ.get("DN_COMPUTE", "f32").lower(), _lib.COMPUTE_F32)
+COMPUTE = COMPUTE_MODES[os.environ.get("DN_COMPUTE", "f32x3").lower()]
 
 
 def set_compute(mode):

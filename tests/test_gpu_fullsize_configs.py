@@ -273,6 +273,7 @@ def test_config5_mixed_precision_mode_vs_fp32():
     b = 4
     x, gt, mask = dorn80_inputs(b)
     res = {}
+    prev = engine.compute_mode()
     try:
         for mode in ("f32", "bf16"):
             engine.set_compute(mode)
@@ -289,7 +290,7 @@ def test_config5_mixed_precision_mode_vs_fp32():
             res[mode] = (dec.cpu(), ordc.detach().cpu(), float(loss.item()), grads, names)
     finally:
         engine.PROFILE = None
-        engine.set_compute("f32")
+        engine.set_compute(prev)
     is_bf = lambda n: "wino_conv_kernel" in n and n.endswith(", 1>")
     nbf = sum(is_bf(n) for n in res["bf16"][4])
     assert nbf >= 30 and not any(is_bf(n) for n in res["f32"][4]), nbf      # the bf16 kernels are what ran

@@ -284,6 +284,7 @@ def test_winograd_error_vs_fp64(monkeypatch):
     ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), mod.weight.detach().double().cpu(), mod.bias.detach().double().cpu(), padding=1)
     ref = ref.permute(0, 2, 3, 1)
     errs, l2 = {}, {}
+    prev = engine.compute_mode()
     try:
         for tag, env, mode in (("wino", None, "f32"), ("direct", "1", "f32"), ("wino_f32x3", None, "f32x3")):
             if env is None:
@@ -299,7 +300,7 @@ def test_winograd_error_vs_fp64(monkeypatch):
             errs[tag] = float((y.double().cpu() - ref).abs().max())
             l2[tag] = float((y.double().cpu() - ref).norm() / ref.norm())
     finally:
-        engine.set_compute("f32")
+        engine.set_compute(prev)
     scale = float(ref.abs().max())
     print("max |err| vs fp64: winograd %.3g, direct %.3g, winograd on three-piece bf16 products %.3g (result magnitude %.3g)" % (
         errs["wino"], errs["direct"], errs["wino_f32x3"], scale))
@@ -329,6 +330,7 @@ def test_winograd_compute_modes(case, mode):
     torch.manual_seed(11)
     N, H, W = 3, 18, 22
     suffix = {"bf16": ", 1>", "f32x3": ", 3>"}[mode]
+    prev = engine.compute_mode()
     try:
         res = {}
         for m in ("f32", mode):
@@ -373,7 +375,7 @@ def test_winograd_compute_modes(case, mode):
             torch.cuda.synchronize()
             res[m] = (outs, kf, kd, dw)
     finally:
-        engine.set_compute("f32")
+        engine.set_compute(prev)
     assert "wino_conv_kernel" in res[mode][1] and res[mode][1].endswith(suffix) and res[mode][2].endswith(suffix), res[mode][1:3]
     assert "wino_conv_kernel" in res["f32"][1] and res["f32"][1].endswith(", 0>")
     assert torch.equal(res[mode][3], res["f32"][3])

@@ -13,6 +13,8 @@ Stated fp32 tolerances (north_star: "match the reference PyTorch-CPU forward to 
   losses / metrics (scalars)  rtol 1e-4
   integer results             exact
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -532,3 +534,44 @@ def test_pose_exp_net(golden, exp):
         m1, pe = net(tgt.to(DEV), [r.to(DEV) for r in refs])
     close("eval_pose(golden)", pe, g[tag + ":eval_pose"], rtol=1e-3, atol_rel=1e-4)
     assert (m1 is None) == (not exp)
+
+
+def test_default_compute_mode_is_f32x3_and_agrees_with_the_fp32_instruction():
+    """The library's default arithmetic for the Winograd forward / input gradient is "f32x3" (fp32 products from three exact bf16
+    pieces per operand on the bf16 matrix cores).  Every oracle / golden / fp64-yardstick test of this suite therefore exercises it
+    (and passes unchanged with DN_COMPUTE=f32).  Here: the whole Disp_vgg_BN forward + backward at the metric's 128x416 in both modes
+    on the same inputs.  Stated: disparities agree to rtol 2e-5 / atol 2e-6 of the magnitude (two fp32 summation orders through 26
+    layers); the loss to 1e-6 relative; the gradient vectors to a relative L2 of 5e-3 (encoder) / 1e-3 (decoder): what one ReLU /
+    max-pool mask decision flipping inside fp32 round-off costs, the same mechanism as between any two fp32 implementations."""
+    from supervised_dispnet_amd import engine
+    assert engine.compute_mode() == os.environ.get("DN_COMPUTE", "f32x3")
+    b, h, w = 2, 128, 416
+    x = detgen.image_batch(b, h, w, "modes:x")
+    gt = detgen.sparse_depth(b, h, w, "modes:gt", density=0.05)
+    res = {}
+    prev = engine.compute_mode()
+    try:
+        for mode in ("f32", "f32x3"):
+            engine.set_compute(mode)
+            net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+            detgen.fill_state_dict(net.state_dict(), "vggbn")
+            net.to(DEV).train()
+            disps = net(x.to(DEV))
+            depth = [reciprocal(d) for d in disps]
+            loss = LF.l1_loss(gt.to(DEV), depth, "kitti") + 0.1 * LF.smooth_loss(depth)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = ([d.detach().cpu() for d in disps], float(loss.item()),
+                         {n: p.grad.detach().double().cpu() for n, p in net.named_parameters() if not _is_pre_bn_conv_bias(n)})
+    finally:
+        engine.set_compute(prev)
+    for i, (a, c) in enumerate(zip(res["f32x3"][0], res["f32"][0])):
+        close("disp%d f32x3 vs f32" % i, a, c, rtol=2e-5, atol_rel=2e-6)
+    assert abs(res["f32x3"][1] - res["f32"][1]) <= 1e-6 * abs(res["f32"][1])
+    for block, bound in (("features.", 5e-3), ("", 1e-3)):
+        names = [n for n in res["f32"][2] if n.startswith("features.") == (block == "features.")]
+        num = sum(float((res["f32x3"][2][n] - res["f32"][2][n]).pow(2).sum()) for n in names)
+        den = sum(float(res["f32"][2][n].pow(2).sum()) for n in names)
+        rel = (num / den) ** 0.5
+        print("gradient block %-9s f32x3 vs f32: relative L2 %.3e" % (block or "decoder", rel))
+        assert rel <= bound, (block, rel)
