@@ -441,13 +441,17 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       for (int nn = 0; nn < 2; ++nn) breg16[PREC == 1 ? j : 0][nn] = *reinterpret_cast<const bf16x8*>(wcur16 + (size_t)j * wj16B + nn * 1024);
     wcur16 += wchunk16B;
   };
-  // PREC 3: weight unit u = 2 j + half of a chunk = the three pieces of one (position, 32 couts); two units of registers, refilled
-  // piece by piece as the matrix instructions of unit u release them with the pieces of unit u + 2 (which may lie in the next chunk /
-  // operand / the slack chunk): 24 registers, 9-11 matrix instructions of lead
-  bf16x8 bq[PREC == 3 ? 2 : 1][3];
-  auto load_b3 = [&](int u, int piece) {               // u = 0 .. 9 relative to the current chunk's base pointer wcur16
+  // PREC 3: weight unit u = 2 j + half of a chunk = the three pieces of one (position, 32 couts), streamed in the order they are
+  // released (piece 2, 1, 0): stream index g = 3 u + (2 - piece), 24 per chunk, held in a ring of WRING piece registers (WRING divides
+  // 24, so every slot of the unrolled chunk has a fixed register); the matrix instruction that releases piece g is followed by the
+  // request for piece g + WRING (which may lie in the next chunk / operand / the slack chunk): WRING = 8 -> 32 registers, 14-16 matrix
+  // instructions of lead
+  constexpr int WRING = 8;
+  bf16x8 bq[PREC == 3 ? WRING : 1];
+  auto load_b3 = [&](int g) {                          // g = stream index relative to the current chunk's base pointer wcur16 (0 .. 24 + WRING)
+    const int u = g / 3, piece = 2 - g % 3;
     const size_t off = (size_t)(u >> 3) * wchunk16B + (size_t)((u & 7) >> 1) * wj16B + (size_t)(u & 1) * 3072 + (size_t)piece * 1024;
-    bq[PREC == 3 ? (u & 1) : 0][piece] = *reinterpret_cast<const bf16x8*>(wcur16 + off);
+    bq[PREC == 3 ? g % WRING : 0] = *reinterpret_cast<const bf16x8*>(wcur16 + off);
   };
   if constexpr (PREC == 0) {
     load_b(0);
@@ -460,9 +464,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     load_b16();
   } else {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int piece = 0; piece < 3; ++piece) load_b3(u, piece);
+    for (int g = 0; g < WRING; ++g) load_b3(g);
   }
 
   // slot schedule (compile-time): NSL slots per 16-channel chunk, one MFMA each; H = first slot of the second 8-k group
@@ -641,12 +643,12 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
           // x0y2, x0y1, x1y1, x0y0, x1y0, x2y0: the weight pieces are released in the order 2, 1, 0
           // (a chain of dependent matrix instructions on one accumulator issues at the full rate: tools/ubench/agpr_issue.hip)
           constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
-          acc[j][0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[j & 1][AS[t]], bq[u & 1][BS[t]], acc[j][0][nn], 0, 0, 0);
+          acc[j][0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[j & 1][AS[t]], bq[(3 * u + 2 - BS[t]) % WRING], acc[j][0][nn], 0, 0, 0);
           // ---- side work of this slot
           if constexpr (!(DBG & 32)) {                             // (DBG 32: ablation without the weight stream)
-            if constexpr (t == 1) load_b3(u + 2, 2);
-            if constexpr (t == 3) load_b3(u + 2, 1);
-            if constexpr (t == 0 && m > 0) load_b3(u + 1, 0);     // (piece 0 of the previous unit's successor: released by its last instruction)
+            if constexpr (t == 1) load_b3(3 * u + WRING);          // piece 2 of this unit was released by instruction t = 0
+            if constexpr (t == 3) load_b3(3 * u + 1 + WRING);      // piece 1 by t = 2
+            if constexpr (t == 0 && m > 0) load_b3(3 * (u - 1) + 2 + WRING);     // piece 0 of the previous unit by its last instruction
           }
           if constexpr (j < 3 && q12 == 1) read_raw(Ab, j + 1);
           if constexpr (j < 3 && q12 >= 6 && q12 < 10) split_pair((j + 1) & 1, q12 - 6);
@@ -662,7 +664,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
           if constexpr (STG && m >= 34 && m < 42) col_piece(buf ^ 1, (m - 34) / 2, (m - 34) % 2);
           __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (!(DBG & 32)) load_b3(9, 0);        // piece 0 of unit 1 of the next chunk
+        if constexpr (!(DBG & 32)) load_b3(3 * 7 + 2 + WRING);      // successor of the last unit's piece 0
         wcur16 += wchunk16B;
         __syncthreads();
         buf ^= 1;
