@@ -378,6 +378,298 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
         }
 }
 
+// ------------------------------------------------------------------------------------------------ DN_COMPUTE_F32X3 variant
+// The same block (64 co x 64 ci x 16 positions, 8 waves, 8 tiles per chunk, the same LDS planes, the same epilogue), with every
+// fp32 product formed on the bf16 matrix cores from three exact bf16 pieces per operand (dn_winograd.hip, PREC = 3):
+//   * one v_mfma_f32_32x32x16_bf16 carries TWO partial products of the chunk's 8 tiles.  Its 16 k-slots are 8 per half-wave, and a
+//     half-wave's slots only ever meet the same half-wave's slots of the other operand -- so each half-wave simply uses ITS OWN four
+//     tiles (g, 2+g, 4+g, 6+g; g = lane >> 5: the tiles the fp32 kernel reads there) in slots 0-3 and again in slots 4-7, with a
+//     different piece:  (x0, x1) . (y0, y0) = x0y0 + x1y0,   (x0, x1) . (y1, y1) = x0y1 + x1y1,   (x0, x2) . (y2, y0) = x0y2 + x2y0,
+//     summed over both half-waves = all 8 tiles.  No cross-lane traffic; 3 matrix instructions (96 cycles) per (position, 32 co,
+//     32 ci) and chunk instead of 4 x 64 cycles of the fp32 instruction;
+//   * a lane splits its four values per fragment (x = x0 + x1 + x2 exactly: round, subtract, round, subtract): 18 vector
+//     instructions, issued under the matrix instructions of the previous group, LDS reads two groups ahead; operands are rebuilt in
+//     place one 3-instruction group after their last use;
+//   * one patch in flight per thread (the chunk is ~2.5x shorter, the vector ALUs are what the kernel is bound by, and the registers
+//     are needed for the operands): a wave requests its next chunk's patch + gradient tile at the top of one chunk and transforms +
+//     stores them during the next one; ONE barrier per chunk, placed after the last read of the current buffer / the last store
+//     into the next one (slot 14 of 24), so that the next chunk's first operands are built under the current chunk's tail.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool HA, int DBG = 0>     // DBG (timing ablations, wrong results): 1 no transform + stores, 2 no split arithmetic, 4 no global loads, 8 no LDS fragment reads
+__global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams p) {
+  extern __shared__ __align__(16) float smem[];
+  char* smemB = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Ktot = p.D1, Cout = p.Ntot;
+  const int CB = Cout / 64, KB = Ktot / 64;
+  const int total = CB * KB * p.splits;
+  const int per = (total + 7) >> 3;
+  const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || q >= total) return;
+  const int cib = q % KB, cob = (q / KB) % CB, split = q / (KB * CB);
+  const int T = p.T;
+  const int t_begin = split * p.m_per_split;
+  const int t_end = min(T, t_begin + p.m_per_split);
+  const int nchunks = (t_end - t_begin + GTC - 1) / GTC;
+
+  int s_op = 0;
+#pragma unroll
+  for (int i = 1; i < DN_MAX_OPERANDS; ++i)
+    if (i < p.n_in && cib * 64 >= p.in[i].ch_off) s_op = i;
+  const KOperand& S = p.in[s_op];
+  const int c_in_op = cib * 64 - S.ch_off;
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+
+  const int group = wave >> 2;                          // waves 0-3 stage the even chunks, waves 4-7 the odd ones
+  const int item_t = (tid & 255) >> 5;
+  const int item_c = (tid & 31) * 2;
+  const int stB = item_t * G_ROWB + item_c * 4;
+  const int pos0 = 4 * (wave >> 1) + 2 * (wave & 1);
+  const int frB = pos0 * G_PLANE + (lane >> 5) * G_ROWB + (lane & 31) * 4;
+
+  f32x16 acc[2][2][2];       // [pp][h (co half)][nn (ci half)]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][c][e] = 0.f;
+
+  f32x2 v[16], gv[4];
+  unsigned pm = 0;
+  f32x2 sc2, sh2;
+  const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
+  const int gpixB = Cout * 4, growB = p.OW * Cout * 4;
+  if constexpr (HA) {
+    const bool op_aff = S.scale != nullptr;
+    const f32x2 l1 = *reinterpret_cast<const f32x2*>((op_aff ? S.scale : S.p) + (op_aff ? c_in_op + item_c : 0));
+    const f32x2 l2 = *reinterpret_cast<const f32x2*>((op_aff ? S.shift : S.p) + (op_aff ? c_in_op + item_c : 0));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      sc2[e] = op_aff ? l1[e] : 1.f;
+      sh2[e] = op_aff ? l2[e] : 0.f;
+    }
+  }
+  const float relu_floor = (HA && S.scale != nullptr) ? 0.f : -__builtin_huge_valf();
+
+  auto decode_tile = [&](int target, unsigned* tx, unsigned* ty, int* n) -> bool {
+    const int t = t_begin + target * GTC + item_t;
+    const bool live = t < t_end;
+    const unsigned r = fastdiv_dev(live ? (unsigned)t : 0u, (unsigned)p.TW, p.mTW, tx);
+    *n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, ty);
+    return live;
+  };
+  auto load_patch = [&](int target) {
+    unsigned tx, ty;
+    int n;
+    const bool live = decode_tile(target, &tx, &ty, &n);
+    const int py = 2 * (int)ty - 1, px = 2 * (int)tx - 1;
+    const int off0 = (n * (int)S.sn + py * (int)S.sh + px * (int)S.sw + c_in_op + item_c) * 4;
+    unsigned cols = 0x6u | (px >= 0 ? 1u : 0u) | (px + 3 < p.IW ? 8u : 0u);
+    cols = live ? cols : 0u;
+    pm = (py >= 0 ? cols : 0u) | (cols << 4) | (cols << 8) | (py + 3 < p.IH ? cols << 12 : 0u);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int off = off0 + (i >> 2) * shB + (i & 3) * swB;
+      asm volatile("" : "+v"(off));
+      off = ((pm >> i) & 1u) ? off : -1;
+      v[i] = wg_buffer_load2(rsrcX, off);
+    }
+  };
+  auto load_grad = [&](int target) {
+    unsigned tx, ty;
+    int n;
+    const bool live = decode_tile(target, &tx, &ty, &n);
+    const int off0 = (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 64 + item_c) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = off0 + (i >> 1) * growB + (i & 1) * gpixB;
+      asm volatile("" : "+v"(off));
+      off = live ? off : -1;
+      gv[i] = wg_buffer_load2(rsrcG, off);
+    }
+  };
+  auto affine_piece = [&](int i) {
+    if constexpr (HA) {
+      unsigned pmv = pm;
+      asm volatile("" : "+v"(pmv));
+      const float cap = ((pmv >> i) & 1u) ? __builtin_huge_valf() : 0.f;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc2[e], sh2[e]), relu_floor, cap);
+    }
+  };
+  auto row_piece = [&](int b) {
+    const f32x2 d0 = v[0 + b], d1 = v[4 + b], d2 = v[8 + b];
+    v[0 + b] = d0 - d2;
+    v[4 + b] = d1 + d2;
+    v[8 + b] = d2 - d1;
+    v[12 + b] = d1 - v[12 + b];
+  };
+  auto col_piece = [&](int b2, int i) {
+    char* dst = smemB + b2 * G_BUFB + G_OPB + stB + (4 * i) * G_PLANE;
+    *reinterpret_cast<f32x2*>(dst + 0 * G_PLANE) = v[4 * i + 0] - v[4 * i + 2];
+    *reinterpret_cast<f32x2*>(dst + 1 * G_PLANE) = v[4 * i + 1] + v[4 * i + 2];
+    *reinterpret_cast<f32x2*>(dst + 2 * G_PLANE) = v[4 * i + 2] - v[4 * i + 1];
+    *reinterpret_cast<f32x2*>(dst + 3 * G_PLANE) = v[4 * i + 1] - v[4 * i + 3];
+  };
+  auto g_cols = [&](int b2, int i) {
+    char* dst = smemB + b2 * G_BUFB + stB + (4 * i) * G_PLANE;
+    f32x2 u0, u1;
+    if (i == 0) { u0 = gv[0]; u1 = gv[1]; }
+    else if (i == 1) { u0 = gv[0] + gv[2]; u1 = gv[1] + gv[3]; }
+    else if (i == 2) { u0 = gv[0] - gv[2]; u1 = gv[1] - gv[3]; }
+    else { u0 = gv[2]; u1 = gv[3]; }
+    *reinterpret_cast<f32x2*>(dst + 0 * G_PLANE) = u0;
+    *reinterpret_cast<f32x2*>(dst + 1 * G_PLANE) = u0 + u1;
+    *reinterpret_cast<f32x2*>(dst + 2 * G_PLANE) = u0 - u1;
+    *reinterpret_cast<f32x2*>(dst + 3 * G_PLANE) = u1;
+  };
+
+  // ---- operands of the matrix instructions: per co half h  A1 = (x0, x1), A3 = (x0, x2);  per ci half nn  B1 = (y0, y0),
+  //      B2 = (y1, y1), B3 = (y2, y0): two dwords (four own tiles) of the first piece, two of the second
+  wg_u32x4 Aop[2][2], Bop[2][3];
+  float raw[2][4];
+  unsigned Pk[3][2];                                    // pieces of the fragment being built: [piece][tile pair]
+  // build k of a chunk (3 matrix instructions each): what it produces and where it reads
+  //   0: B of (pp 0, nn 1)   1: A of (pp 0, h 1)   2: A of (pp 1, h 0)   3: B of (pp 1, nn 0)   4: B of (pp 1, nn 1)   5: A of (pp 1, h 1)
+  //   6: A of (pp 0, h 0) of the NEXT chunk       7: B of (pp 0, nn 0) of the NEXT chunk
+  auto issue_reads = [&](int k, const char* cur, const char* nxt) {
+    const bool isB = (k == 0 || k == 3 || k == 4 || k == 7);
+    const int pp = (k >= 2 && k <= 5) ? 1 : 0, half = (k == 0 || k == 1 || k == 4 || k == 5) ? 1 : 0;
+    const char* base = (k >= 6 ? nxt : cur) + (isB ? G_OPB : 0) + pp * G_PLANE + half * 128;
+    if constexpr (DBG & 8) return;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) raw[k & 1][ks] = *reinterpret_cast<const float*>(base + ks * 2 * G_ROWB);
+  };
+  auto split_half = [&](int k, int hf, unsigned (&P)[3][2]) {          // tiles (2 hf, 2 hf + 1) of the fragment: x = P0 + P1 + P2 exactly
+    const f32x2 x = f32x2{raw[k & 1][2 * hf], raw[k & 1][2 * hf + 1]};
+    if constexpr (DBG & 2) {
+      P[0][hf] = __builtin_bit_cast(unsigned, x[0]);
+      P[1][hf] = __builtin_bit_cast(unsigned, x[1]);
+      P[2][hf] = __builtin_bit_cast(unsigned, x[0]) ^ 0x11u;
+      return;
+    }
+    const wg_bf16x2 h = __builtin_convertvector(x, wg_bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+    const wg_bf16x2 m = __builtin_convertvector(r1, wg_bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    const wg_bf16x2 l = __builtin_convertvector(r2, wg_bf16x2);
+    P[0][hf] = __builtin_bit_cast(unsigned, h);
+    P[1][hf] = __builtin_bit_cast(unsigned, m);
+    P[2][hf] = __builtin_bit_cast(unsigned, l);
+  };
+  auto finish_build = [&](int k, int part) {                             // part 0 .. 2: spread over the three slots of the group
+    const bool isB = (k == 0 || k == 3 || k == 4 || k == 7);
+    const int half = (k == 0 || k == 1 || k == 4 || k == 5) ? 1 : 0;
+    if (part == 0) {
+      split_half(k, 0, Pk);
+    } else if (part == 1) {
+      split_half(k, 1, Pk);
+    } else {
+      if (isB) {
+        Bop[half][0] = wg_u32x4{Pk[0][0], Pk[0][1], Pk[0][0], Pk[0][1]};      // (y0, y0)
+        Bop[half][1] = wg_u32x4{Pk[1][0], Pk[1][1], Pk[1][0], Pk[1][1]};      // (y1, y1)
+        Bop[half][2] = wg_u32x4{Pk[2][0], Pk[2][1], Pk[0][0], Pk[0][1]};      // (y2, y0)
+      } else {
+        Aop[half][0] = wg_u32x4{Pk[0][0], Pk[0][1], Pk[1][0], Pk[1][1]};      // (x0, x1)
+        Aop[half][1] = wg_u32x4{Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]};      // (x0, x2)
+      }
+    }
+  };
+
+  // ---- prologue: group 0 stages chunk 0 completely; group 1 requests chunk 1 (it transforms + stores it during chunk 0)
+  if (group == 0) {
+    load_patch(0);
+    load_grad(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) affine_piece(i);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) row_piece(b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) col_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g_cols(0, i);
+  } else {
+    load_patch(1);
+    load_grad(1);
+  }
+  __syncthreads();
+  {
+    const char* b0 = smemB + frB;                      // the first two operands of chunk 0 (builds 6, 7 of "chunk -1") and the reads of build 0
+    issue_reads(6, b0, b0);
+    finish_build(6, 0); finish_build(6, 1); finish_build(6, 2);
+    issue_reads(7, b0, b0);
+    finish_build(7, 0); finish_build(7, 1); finish_build(7, 2);
+    issue_reads(0, b0, b0);
+    issue_reads(1, b0, b0);
+  }
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    const char* cur = smemB + buf * G_BUFB + frB;
+    const char* nxt = smemB + (buf ^ 1) * G_BUFB + frB;
+    auto body = [&](auto req_tag) __attribute__((always_inline)) {
+      constexpr bool REQ = decltype(req_tag)::value;       // request phase (loads for chunk c + 2), else transform + store phase (chunk c + 1)
+      if constexpr (REQ && !(DBG & 4)) {
+        load_patch(c + 2);
+        load_grad(c + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wg_static_for<24>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int pp = m / 12, q12 = m % 12, h = q12 / 6, nn = (q12 / 3) % 2, t = q12 % 3;
+        constexpr int grp = m / 3, part = m % 3;
+        const wg_u32x4 ao = Aop[h][t == 2 ? 1 : 0], bo = Bop[nn][t];
+        acc[pp][h][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, ao), __builtin_bit_cast(wg_bf16x8, bo), acc[pp][h][nn], 0, 0, 0);
+        // ---- side work of this slot: finish build `grp`; its last part frees its raw values: request the reads of build grp + 2
+        //      (builds 0-5 read the current buffer and are all requested by slot 11; 6, 7 and the next chunk's 0, 1 read the next
+        //      buffer and are requested after the barrier of slot 14)
+        finish_build(grp, part);
+        if constexpr (part == 2 && grp < 4) issue_reads(grp + 2, cur, nxt);
+        if constexpr (part == 2 && grp == 5) issue_reads(7, cur, nxt);
+        if constexpr (part == 2 && grp >= 6) issue_reads(grp - 6, nxt, nxt);
+        if constexpr (!REQ && !(DBG & 1)) {
+          if constexpr (m < 8) {
+            affine_piece(2 * m);
+            affine_piece(2 * m + 1);
+          }
+          if constexpr (m == 8 || m == 9) {
+            row_piece(2 * (m - 8));
+            row_piece(2 * (m - 8) + 1);
+          }
+          if constexpr (m >= 10 && m < 14) col_piece(buf ^ 1, m - 10);
+          if constexpr (m >= 2 && m < 10 && (m % 2) == 0) g_cols(buf ^ 1, (m - 2) / 2);
+        }
+        if constexpr (m == 14) __syncthreads();                   // all reads of `cur` are out, all stores into `nxt` are done
+        if constexpr (m == 14) issue_reads(6, cur, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    if (((c - group) & 1) == 0) body(std::true_type{});
+    else body(std::false_type{});
+  }
+
+  float* ws = p.ws + ((size_t)split * 16 + pos0) * (size_t)Cout * Ktot;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = cob * 64 + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = cib * 64 + 32 * nn + (lane & 31);
+          ws[(size_t)pp * Cout * Ktot + (size_t)row * Ktot + col] = acc[pp][h][nn][r];
+        }
+}
+
 // dU = sum over splits (with the sign of A's last row restored), dW = G^T dU G, written in the framework layout [co][ci][3][3].
 // One thread per 4 consecutive ci: float4 loads of the partials (the 16 positions x splits reads are independent streams).
 __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits, int dw_vec) {
@@ -442,7 +734,20 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
   const int dbg = knobs().wino_wg_dbg;
-  auto kernel = p.any_affine ? wino_wgrad_kernel<true, 0> : wino_wgrad_kernel<false, 0>;
+  const bool x3 = p.compute == DN_COMPUTE_F32X3 && (dbg == 0 || dbg >= 1000);
+  auto kernel = x3 ? (p.any_affine ? wino_wgrad_x3_kernel<true> : wino_wgrad_x3_kernel<false>)
+                   : (p.any_affine ? wino_wgrad_kernel<true, 0> : wino_wgrad_kernel<false, 0>);
+  if (x3) {
+    switch (dbg) {            // DN_WINO_WG_DBG = 1000 + bits: timing ablations of the three-piece variant
+      case 1001: kernel = wino_wgrad_x3_kernel<true, 1>; break;
+      case 1002: kernel = wino_wgrad_x3_kernel<true, 2>; break;
+      case 1004: kernel = wino_wgrad_x3_kernel<true, 4>; break;
+      case 1005: kernel = wino_wgrad_x3_kernel<true, 5>; break;
+      case 1008: kernel = wino_wgrad_x3_kernel<true, 8>; break;
+      case 1015: kernel = wino_wgrad_x3_kernel<true, 15>; break;
+      default: break;
+    }
+  }
   switch (dbg) {
     case 2: kernel = wino_wgrad_kernel<true, 2>; break;
     case 6: kernel = wino_wgrad_kernel<true, 6>; break;
@@ -459,7 +764,8 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   const int Ktot = wg_ktot(p);
   const int total = (p.Ntot / 64) * (Ktot / 64) * splits;
   hipLaunchKernelGGL(kernel, dim3((total + 7) / 8 * 8), dim3(512), kWgLds, stream, p);
-  set_last_kernel("dn::wino_wgrad_kernel<%s, %d>", p.any_affine ? "true" : "false", (dbg == 2 || dbg == 6 || dbg == 22 || dbg == 54 || dbg == 118) ? dbg : 0);
+  if (x3) set_last_kernel("dn::wino_wgrad_x3_kernel<%s>", p.any_affine ? "true" : "false");
+  else set_last_kernel("dn::wino_wgrad_kernel<%s, %d>", p.any_affine ? "true" : "false", (dbg == 2 || dbg == 6 || dbg == 22 || dbg == 54 || dbg == 118) ? dbg : 0);
   int rc = check_launch("wino_wgrad_kernel");
   if (rc != DN_OK) return rc;
   const long long slab = (long long)p.Ntot * Ktot;
