@@ -764,7 +764,7 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   const int Ktot = wg_ktot(p);
   const int total = (p.Ntot / 64) * (Ktot / 64) * splits;
   hipLaunchKernelGGL(kernel, dim3((total + 7) / 8 * 8), dim3(512), kWgLds, stream, p);
-  if (x3) set_last_kernel("dn::wino_wgrad_x3_kernel<%s>", p.any_affine ? "true" : "false");
+  if (x3) set_last_kernel("dn::wino_wgrad_x3_kernel<%s, 0>", p.any_affine ? "true" : "false");
   else set_last_kernel("dn::wino_wgrad_kernel<%s, %d>", p.any_affine ? "true" : "false", (dbg == 2 || dbg == 6 || dbg == 22 || dbg == 54 || dbg == 118) ? dbg : 0);
   int rc = check_launch("wino_wgrad_kernel");
   if (rc != DN_OK) return rc;

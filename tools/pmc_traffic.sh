@@ -7,7 +7,7 @@ out=$R/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  DN_WGRAD_STREAM=0 rocprofv3 --kernel-trace --pmc $c -d $out/$c -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline > $out/$c.log 2>&1 || echo "pass $c failed"
+  DN_WGRAD_STREAM=0 rocprofv3 --kernel-trace --pmc $c -d $out/$c -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline --alt-steps 0 > $out/$c.log 2>&1 || echo "pass $c failed"
 done
 cd $R
 python tools/pmc_traffic_summary.py $out > gpurun_out/pmc_${tag}_traffic.json
