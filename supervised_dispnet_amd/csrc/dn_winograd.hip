@@ -527,9 +527,19 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     auto affine_piece = [&](int i) {
       if constexpr (HA) {
         // clamp to [floor, cap]: floor = 0 is the ReLU, cap = 0 re-zeroes a halo pixel the BatchNorm shift lifted (one v_med3 each)
-        unsigned pm = pmask;
-        if constexpr (PREC == 3) asm volatile("" : "+v"(pm));     // (keeps the 16 caps from being hoisted out of the chunk loop into registers)
-        const float cap = ((pm >> i) & 1u) ? __builtin_huge_valf() : 0.f;
+        if constexpr (PREC == 3) {
+          // the vector ALUs are this variant's second resource: one packed fma for the pair, the cap from a signed bit-field extract
+          // (v_bfe_i32: -1 / 0) and one AND (+inf / 0), recomputed per chunk (the asm keeps the 16 caps from being hoisted into registers)
+          unsigned pm = pmask;
+          asm volatile("" : "+v"(pm));
+          const int msk = __builtin_amdgcn_sbfe((int)pm, i, 1);
+          const float cap = __builtin_bit_cast(float, msk & 0x7f800000);
+          const fV t = __builtin_elementwise_fma(v[i], sc4, sh4);
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[i][e] = __builtin_amdgcn_fmed3f(t[e], relu_floor, cap);
+          return;
+        }
+        const float cap = ((pmask >> i) & 1u) ? __builtin_huge_valf() : 0.f;
 #pragma unroll
         for (int e = 0; e < VW; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc4[e], sh4[e]), relu_floor, cap);
       }
