@@ -292,7 +292,7 @@ int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, int piec
 // three bf16 pieces per operand (DN_COMPUTE_F32X3) -- the last two on the default tile variant only
 int wino_layout(const dn_conv_desc* d, const IgemmParams& p) {
   if (!wino_eligible(d, p)) return 0;
-  if (knobs().wino_mtw != 1 || (knobs().wino_dbg != 0 && knobs().wino_dbg < 16)) return 1;
+  if (knobs().wino_mtw != 1 || (knobs().wino_dbg != 0 && knobs().wino_dbg != 4 && knobs().wino_dbg < 16)) return 1;
   return p.compute == DN_COMPUTE_BF16 ? 2 : (p.compute == DN_COMPUTE_F32X3 ? 3 : 1);
 }
 
@@ -1021,6 +1021,10 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variants may be used)
     return p.any_affine ? launch_wino_variant<1, true, 0, 1>(p, stream) : launch_wino_variant<1, false, 0, 1>(p, stream);
   if (p.compute == DN_COMPUTE_F32X3) {
+    if (knobs().wino_dbg == 4) {           // in-kernel timestamps (tools/wino_timing.py)
+      p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
+      return p.any_affine ? launch_wino_variant<1, true, 4, 3>(p, stream) : launch_wino_variant<1, false, 4, 3>(p, stream);
+    }
     switch (knobs().wino_dbg) {            // 16 / 32 / 64 / 112: timing ablations of the three-piece variant (wrong results)
       case 16: return p.any_affine ? launch_wino_variant<1, true, 16, 3>(p, stream) : launch_wino_variant<1, false, 16, 3>(p, stream);
       case 32: return p.any_affine ? launch_wino_variant<1, true, 32, 3>(p, stream) : launch_wino_variant<1, false, 32, 3>(p, stream);

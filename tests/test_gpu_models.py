@@ -575,3 +575,50 @@ def test_default_compute_mode_is_f32x3_and_agrees_with_the_fp32_instruction():
         rel = (num / den) ** 0.5
         print("gradient block %-9s f32x3 vs f32: relative L2 %.3e" % (block or "decoder", rel))
         assert rel <= bound, (block, rel)
+
+
+def test_training_trajectories_of_the_three_compute_modes():
+    """Thirty Adam steps of Disp_vgg_BN (L1 + smoothness, 4 x 128 x 416, the same initial weights and batch) in each arithmetic mode of
+    the Winograd kernels.  Training is a chaotic map (ReLU / max-pool decisions, Adam's normalisation), so trajectories of ANY two fp32
+    implementations drift apart; what is stated here is that the default three-piece mode tracks the fp32 instruction like another fp32
+    implementation would, and that the opt-in bf16 mixed-precision mode trains the same problem:
+      f32x3 vs f32: loss within 3 % at every step (measured 0.9 %; final 23.26 vs 23.19 from 40.55);
+      bf16 vs f32: mean loss of the last five steps within 10 % (measured 3 %; single steps differ by up to 23 % on the way: at this
+      learning rate, 1e-3, the curve is noisy in every mode);
+      every mode reduces the loss by at least a third over the 30 steps."""
+    from supervised_dispnet_amd import engine
+    b, h, w, steps = 4, 128, 416, 30
+    x = detgen.image_batch(b, h, w, "traj:x").to(DEV)
+    gt = detgen.sparse_depth(b, h, w, "traj:gt", density=0.3).to(DEV)
+    curves = {}
+    prev = engine.compute_mode()
+    try:
+        for mode in ("f32", "f32x3", "bf16"):
+            engine.set_compute(mode)
+            net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+            detgen.fill_state_dict(net.state_dict(), "vggbn")
+            net.to(DEV).train()
+            opt = FusedAdam(net._hot_parameters(), lr=1e-3, betas=(0.9, 0.999), production_order=net._grad_production_order())
+            losses = []
+            for _ in range(steps):
+                disps = net(x)
+                depth = [reciprocal(d) for d in disps]
+                loss = LF.l1_loss(gt, depth, "kitti") + 0.1 * LF.smooth_loss(depth)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.item()))
+            curves[mode] = np.array(losses)
+    finally:
+        engine.set_compute(prev)
+    ref = curves["f32"]
+    for mode in ("f32x3", "bf16"):
+        rel = np.abs(curves[mode] - ref) / np.abs(ref)
+        print("%-5s vs f32: max relative loss difference over %d steps %.3e (final %.5f vs %.5f; start %.5f)" % (
+            mode, steps, rel.max(), curves[mode][-1], ref[-1], ref[0]))
+    assert np.all(np.isfinite(ref)) and all(np.all(np.isfinite(c)) for c in curves.values())
+    assert (np.abs(curves["f32x3"] - ref) / np.abs(ref)).max() <= 3e-2
+    assert abs(curves["bf16"][-5:].mean() - ref[-5:].mean()) <= 0.1 * ref[-5:].mean()
+    for mode, c in curves.items():
+        print("%-5s loss: %s" % (mode, " ".join("%.4f" % v for v in c[::3])))
+        assert c[-1] <= (2.0 / 3.0) * c[0], (mode, c[0], c[-1])
