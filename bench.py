@@ -455,7 +455,7 @@ def main():
             "ms_per_step_max": max(per_step_ms), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f32": "f32",
-                      "f32x3": "f32 (Winograd forward + input gradient form each f32 product from three exact bf16 pieces per operand on the bf16 matrix cores, f32 accumulate; error vs fp64 = the f32 instruction's)",
+                      "f32x3": "f32 (Winograd forward / input gradient / weight gradient form each f32 product from three exact bf16 pieces per operand on the bf16 matrix cores, six partial products, f32 accumulate; error vs fp64 at or below the f32 matrix instruction's)",
                       "bf16": "bf16 multiply / f32 accumulate in the Winograd forward + input gradient; f32 tensors, f32 everywhere else"}[args.compute],
             "data": "synthetic",
             "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
