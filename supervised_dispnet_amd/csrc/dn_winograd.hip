@@ -292,8 +292,10 @@ int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, int piec
 // three bf16 pieces per operand (DN_COMPUTE_F32X3) -- the last two on the default tile variant only
 int wino_layout(const dn_conv_desc* d, const IgemmParams& p) {
   if (!wino_eligible(d, p)) return 0;
-  if (knobs().wino_mtw != 1 || (knobs().wino_dbg != 0 && knobs().wino_dbg != 4 && knobs().wino_dbg < 16)) return 1;
-  return p.compute == DN_COMPUTE_BF16 ? 2 : (p.compute == DN_COMPUTE_F32X3 ? 3 : 1);
+  if (knobs().wino_dbg != 0 && knobs().wino_dbg != 4 && knobs().wino_dbg < 16) return 1;
+  if (p.compute == DN_COMPUTE_F32X3) return 3;          // (either tile height)
+  if (knobs().wino_mtw != 1) return 1;
+  return p.compute == DN_COMPUTE_BF16 ? 2 : 1;
 }
 
 // floats of the packed buffer for a given layout (layout 3 holds three bf16 per element: 1.5 floats)
@@ -367,7 +369,7 @@ __device__ __forceinline__ typename VecOf<VW>::type buffer_load_vec(__amdgpu_buf
 template <int MTW, bool HA, int DBG, int PREC = 0>     // PREC 0: fp32 matrix instruction, 1: bf16 operands, 3: three bf16 pieces per operand
 __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const IgemmParams p) {
   constexpr bool BF = PREC != 0;
-  static_assert(!BF || MTW == 1, "the bf16 variants exist for the two-blocks-per-CU tile only");
+  static_assert(PREC != 1 || MTW == 1, "the bf16-rounded variant exists for the two-blocks-per-CU tile only");
   using Cfg = WinoCfg<MTW>;
   constexpr int ROW16 = W16_ROWB;
   constexpr int PLANE16 = Cfg::BT * ROW16, BUF16 = 16 * PLANE16;      // PREC 1: one position plane / one 16-channel chunk
@@ -579,8 +581,15 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
 
     // ---- pipeline fill for this operand (one exposed memory latency + transform per operand)
     {
+      if constexpr (DBG & 128) {            // ablation: what a prologue without its exposed memory latency would cost (timing only)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) load_v(i);
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[i][e] = 1.f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) load_v(i);
+      }
       load_aff();
       if (s == 0) {
         __builtin_amdgcn_sched_barrier(0);
@@ -612,19 +621,22 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       // instruction executes: the fp32 kernel's staging of the NEXT chunk (patch loads, pending BatchNorm, transform, LDS stores) and
       // the split of the next position's A fragment.
       const int frA3 = (4 * wave) * POSB + (lane >> 5) * SUBB + (lane & 31) * 16;   // lane (tile, g): k 8g..8g+7 = 8-k group g, both halves
-      f32x4 raw[2];
-      bf16x8 fa3[2][3];
+      f32x4 raw[MTW][2];
+      bf16x8 fa3[2][MTW][3];
       auto read_raw = [&](const char* Ab, int j) {
-        raw[0] = *reinterpret_cast<const f32x4*>(Ab + j * POSB);
-        raw[1] = *reinterpret_cast<const f32x4*>(Ab + j * POSB + HALFB);
+#pragma unroll
+        for (int mm = 0; mm < MTW; ++mm) {
+          raw[mm][0] = *reinterpret_cast<const f32x4*>(Ab + j * POSB + mm * 512);
+          raw[mm][1] = *reinterpret_cast<const f32x4*>(Ab + j * POSB + HALFB + mm * 512);
+        }
       };
-      auto split_pair = [&](int slot, int q) {          // channels 2q, 2q+1 of the fragment: x = h + m + l exactly
-        const f32x2 x = f32x2{raw[q >> 1][2 * (q & 1)], raw[q >> 1][2 * (q & 1) + 1]};
+      auto split_pair = [&](int slot, int mm, int q) {  // channels 2q, 2q+1 of the fragment of tile half mm: x = h + m + l exactly
+        const f32x2 x = f32x2{raw[mm][q >> 1][2 * (q & 1)], raw[mm][q >> 1][2 * (q & 1) + 1]};
         if constexpr (DBG & 16) {                       // ablation (timing only, wrong results): no split arithmetic
           const bf16x2 h = __builtin_convertvector(x, bf16x2);
-          fa3[slot][0][2 * q] = h[0]; fa3[slot][0][2 * q + 1] = h[1];
-          fa3[slot][1][2 * q] = h[1]; fa3[slot][1][2 * q + 1] = h[0];
-          fa3[slot][2][2 * q] = h[0]; fa3[slot][2][2 * q + 1] = h[0];
+          fa3[slot][mm][0][2 * q] = h[0]; fa3[slot][mm][0][2 * q + 1] = h[1];
+          fa3[slot][mm][1][2 * q] = h[1]; fa3[slot][mm][1][2 * q + 1] = h[0];
+          fa3[slot][mm][2][2 * q] = h[0]; fa3[slot][mm][2][2 * q + 1] = h[0];
           return;
         }
         const bf16x2 h = __builtin_convertvector(x, bf16x2);
@@ -632,9 +644,9 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
         const bf16x2 m = __builtin_convertvector(r1, bf16x2);
         const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
         const bf16x2 l = __builtin_convertvector(r2, bf16x2);
-        fa3[slot][0][2 * q] = h[0]; fa3[slot][0][2 * q + 1] = h[1];
-        fa3[slot][1][2 * q] = m[0]; fa3[slot][1][2 * q + 1] = m[1];
-        fa3[slot][2][2 * q] = l[0]; fa3[slot][2][2 * q + 1] = l[1];
+        fa3[slot][mm][0][2 * q] = h[0]; fa3[slot][mm][0][2 * q + 1] = h[1];
+        fa3[slot][mm][1][2 * q] = m[0]; fa3[slot][mm][1][2 * q + 1] = m[1];
+        fa3[slot][mm][2][2 * q] = l[0]; fa3[slot][mm][2][2 * q + 1] = l[1];
       };
       // (a 1-channel piece is a single chunk: what the loop "re-fetches" for it is never used, so its loads are masked off instead of
       //  carrying the gather path's instruction stream and branches through every slot)
@@ -645,33 +657,42 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
         const char* Ab = smemB + buf * BUFB + frA3;
         read_raw(Ab, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) split_pair(0, q);
+        for (int mm = 0; mm < MTW; ++mm)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) split_pair(0, mm, q);
         __builtin_amdgcn_sched_barrier(0);
-        static_for<48>([&](auto mc) __attribute__((always_inline)) {
+        // slot m = SL j + 6 MTW half + MTW t + tile half: the MTW tile halves of a product share its weight piece
+        constexpr int SL = 12 * MTW;
+        static_for<4 * SL>([&](auto mc) __attribute__((always_inline)) {
           constexpr int m = decltype(mc)::value;
-          constexpr int j = m / 12, q12 = m % 12, nn = q12 / 6, t = q12 % 6, u = 2 * j + nn;      // u: weight unit of this chunk
+          constexpr int j = m / SL, q12 = m % SL, nn = q12 / (6 * MTW), r6 = q12 % (6 * MTW), t = r6 / MTW, mm = r6 % MTW, u = 2 * j + nn;   // u: weight unit
           // x0y2, x0y1, x1y1, x0y0, x1y0, x2y0: the weight pieces are released in the order 2, 1, 0
           // (a chain of dependent matrix instructions on one accumulator issues at the full rate: tools/ubench/agpr_issue.hip)
           constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
-          acc[j][0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[j & 1][AS[t]], bq[(3 * u + 2 - BS[t]) % WRING], acc[j][0][nn], 0, 0, 0);
+          acc[j][mm][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[j & 1][mm][AS[t]], bq[(3 * u + 2 - BS[t]) % WRING], acc[j][mm][nn], 0, 0, 0);
           // ---- side work of this slot
-          if constexpr (!(DBG & 32)) {                             // (DBG 32: ablation without the weight stream)
-            if constexpr (t == 1) load_b3(3 * u + WRING);          // piece 2 of this unit was released by instruction t = 0
+          if constexpr (!(DBG & 32) && mm == 0) {                  // (DBG 32: ablation without the weight stream)
+            if constexpr (t == 1) load_b3(3 * u + WRING);          // piece 2 of this unit was released by the instructions t = 0
             if constexpr (t == 3) load_b3(3 * u + 1 + WRING);      // piece 1 by t = 2
             if constexpr (t == 0 && m > 0) load_b3(3 * (u - 1) + 2 + WRING);     // piece 0 of the previous unit by its last instruction
           }
           if constexpr (j < 3 && q12 == 1) read_raw(Ab, j + 1);
-          if constexpr (j < 3 && q12 >= 6 && q12 < 10) split_pair((j + 1) & 1, q12 - 6);
+          if constexpr (j < 3 && q12 >= 6 * MTW && q12 < 10 * MTW) split_pair((j + 1) & 1, (q12 - 6 * MTW) / 4, (q12 - 6 * MTW) % 4);
           constexpr bool STG = !(DBG & 64);                       // (DBG 64: ablation without the staging of the next chunk)
           if constexpr (STG && m >= 2 && m < 18) load_v_t(m - 2, std::false_type{}, lmask);
           if constexpr (STG && m == 18) load_aff();
-          // transform + stores of the next chunk: 16 affine pieces, 4 row pieces, 8 column pieces over slots 22 .. 47
-          if constexpr (STG && m >= 22 && m < 30) {
-            affine_piece(2 * (m - 22));
-            affine_piece(2 * (m - 22) + 1);
+          // transform + stores of the next chunk: 16 affine pieces, 4 row pieces, 8 column pieces from slot 22 MTW on
+          constexpr int A0 = 22 * MTW, R0 = A0 + 8 * MTW, C0 = R0 + 4;
+          if constexpr (STG && m >= A0 && m < R0) {
+            if constexpr (MTW == 1) {
+              affine_piece(2 * (m - A0));
+              affine_piece(2 * (m - A0) + 1);
+            } else {
+              affine_piece(m - A0);
+            }
           }
-          if constexpr (STG && m >= 30 && m < 34) row_piece(m - 30);
-          if constexpr (STG && m >= 34 && m < 42) col_piece(buf ^ 1, (m - 34) / 2, (m - 34) % 2);
+          if constexpr (STG && m >= R0 && m < R0 + 4) row_piece(m - R0);
+          if constexpr (STG && m >= C0 && m < C0 + 8) col_piece(buf ^ 1, (m - C0) / 2, (m - C0) % 2);
           __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (!(DBG & 32)) load_b3(3 * 7 + 2 + WRING);      // successor of the last unit's piece 0
@@ -1021,6 +1042,11 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variants may be used)
     return p.any_affine ? launch_wino_variant<1, true, 0, 1>(p, stream) : launch_wino_variant<1, false, 0, 1>(p, stream);
   if (p.compute == DN_COMPUTE_F32X3) {
+    // (the 64-tile / one-block-per-CU form of this variant -- the loop below is written for either tile height -- moves 37 % fewer bytes
+    //  through the texture addresser, the weight pieces being fetched once per 64 tiles, and was measured 5-10 % SLOWER on every layer
+    //  but one: a single wave per SIMD stalls on every wait; DN_WINO_MTW=3 selects it for such measurements)
+    if (knobs().wino_dbg == 0 && mtw == 3)
+      return p.any_affine ? launch_wino_variant<2, true, 0, 3>(p, stream) : launch_wino_variant<2, false, 0, 3>(p, stream);
     if (knobs().wino_dbg == 4) {           // in-kernel timestamps (tools/wino_timing.py)
       p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
       return p.any_affine ? launch_wino_variant<1, true, 4, 3>(p, stream) : launch_wino_variant<1, false, 4, 3>(p, stream);
@@ -1030,6 +1056,7 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
       case 32: return p.any_affine ? launch_wino_variant<1, true, 32, 3>(p, stream) : launch_wino_variant<1, false, 32, 3>(p, stream);
       case 64: return p.any_affine ? launch_wino_variant<1, true, 64, 3>(p, stream) : launch_wino_variant<1, false, 64, 3>(p, stream);
       case 112: return p.any_affine ? launch_wino_variant<1, true, 112, 3>(p, stream) : launch_wino_variant<1, false, 112, 3>(p, stream);
+      case 128: return p.any_affine ? launch_wino_variant<1, true, 128, 3>(p, stream) : launch_wino_variant<1, false, 128, 3>(p, stream);
       default: return p.any_affine ? launch_wino_variant<1, true, 0, 3>(p, stream) : launch_wino_variant<1, false, 0, 3>(p, stream);
     }
   }
