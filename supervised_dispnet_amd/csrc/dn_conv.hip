@@ -1473,18 +1473,31 @@ __global__ void pack_weights_many_kernel(const PackEntry* __restrict__ tab) {
   pack_weights_body(e.p, e.w, e.wp, e.total);
 }
 
-__global__ void wgrad_reduce_kernel(const IgemmParams p, float* __restrict__ dw) {
+// 64 consecutive packed elements per block (coalesced 256-byte rows of every split slab); the four waves take the splits z = w, w + 4,
+// ... and meet through LDS in a fixed order (deterministic).  The thin full-resolution layers have a few thousand weights and hundreds
+// of splits: one thread per element walking all of them serially ran 10 blocks for up to 90 us.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const IgemmParams p, float* __restrict__ dw) {
+  __shared__ float part[4][64];
   const KPhase& ph = p.ph[0];
   const int Kp = ph.nchunks * kChunk;
   const long long total = (long long)p.Ntot * Kp;
   const long long slab = (long long)p.Npad * Kp;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(idx / Kp), k = (int)(idx - (long long)n * Kp);
-    const long long dst = packed_to_framework(p, ph, n, k);
-    if (dst < 0) continue;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (long long base = blockIdx.x * 64ll; base < total; base += (long long)gridDim.x * 64) {
+    const long long idx = base + lane;
+    const bool live = idx < total;
     float s = 0.f;
-    for (int z = 0; z < p.splits; ++z) s += p.ws[z * slab + idx];
-    dw[dst] = s;
+    if (live)
+      for (int z = w; z < p.splits; z += 4) s += p.ws[z * slab + idx];
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && live) {
+      const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+      const int n = (int)(idx / Kp), k = (int)(idx - (long long)n * Kp);
+      const long long dst = packed_to_framework(p, ph, n, k);
+      if (dst >= 0) dw[dst] = tot;
+    }
+    __syncthreads();
   }
 }
 
@@ -1775,8 +1788,8 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
   }
   if (rc != DN_OK) return rc;
   const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, dw);
   return check_launch("wgrad_reduce_kernel");
 }

@@ -671,53 +671,60 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
 }
 
 // dU = sum over splits (with the sign of A's last row restored), dW = G^T dU G, written in the framework layout [co][ci][3][3].
-// One thread per 4 consecutive ci: float4 loads of the partials (the 16 positions x splits reads are independent streams).
+// Four threads per 4 consecutive ci, one per transform row i: each sums its 4 positions over the splits (the 16 positions x splits
+// reads are independent float4 streams; with one thread per quad the big layers ran 256 blocks of 64 dependent-free but serial loads
+// at 1.1 TB/s), applies G along j, and the rows meet through LDS for G along i.  Fixed summation order: deterministic.
 __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits, int dw_vec) {
+  __shared__ f32x4 wl[64][4][3];
   const long long slab = (long long)Cout * Ktot, quads = slab >> 2;
-  for (long long qd = blockIdx.x * (long long)blockDim.x + threadIdx.x; qd < quads; qd += (long long)gridDim.x * blockDim.x) {
-    const long long idx = qd << 2;
-    f32x4 u[4][4];
-#pragma unroll
-    for (int pos = 0; pos < 16; ++pos) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int z = 0; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(ws + ((long long)z * 16 + pos) * slab + idx);
-      const int i = pos >> 2, j = pos & 3;
-      u[i][j] = ((i == 3) != (j == 3)) ? -s : s;
-    }
-    // t[r][j] = sum_i G[i][r] u[i][j],  G = (1 0 0 / .5 .5 .5 / .5 -.5 .5 / 0 0 1)
-    f32x4 t[3][4];
+  const int ql = threadIdx.x >> 2, i = threadIdx.x & 3;
+  for (long long q0 = blockIdx.x * 64ll; q0 < quads; q0 += (long long)gridDim.x * 64) {
+    const long long qd = q0 + ql;
+    const bool live = qd < quads;
+    const long long idx = (live ? qd : 0) << 2;
+    f32x4 u[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
-      t[1][j] = 0.5f * (u[1][j] - u[2][j]);
-      t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+      f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int pos = 4 * i + j;
+      for (int z = 0; z < splits; ++z) sacc += *reinterpret_cast<const f32x4*>(ws + ((long long)z * 16 + pos) * slab + idx);
+      u[j] = ((i == 3) != (j == 3)) ? -sacc : sacc;
     }
-    float o[4][9];
+    // along j:  w[c] = sum_j u[j] G[j][c],  G = (1 0 0 / .5 .5 .5 / .5 -.5 .5 / 0 0 1)
+    wl[ql][i][0] = u[0] + 0.5f * (u[1] + u[2]);
+    wl[ql][i][1] = 0.5f * (u[1] - u[2]);
+    wl[ql][i][2] = 0.5f * (u[1] + u[2]) + u[3];
+    __syncthreads();
+    if (live) {
+      // along i:  o[r][c] = sum_i G[i][r] w_i[c]; the 4 x 9 results are 36 consecutive floats of dw (idx * 9 is a multiple of 4 floats);
+      // thread i stores the float4s i, i + 4 (and 8 for i == 0)
+      float o[4][9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const f32x4 o0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
-      const f32x4 o1 = 0.5f * (t[r][1] - t[r][2]);
-      const f32x4 o2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+      for (int c = 0; c < 3; ++c) {
+        const f32x4 w0 = wl[ql][0][c], w1 = wl[ql][1][c], w2 = wl[ql][2][c], w3 = wl[ql][3][c];
+        const f32x4 o0 = w0 + 0.5f * (w1 + w2), o1 = 0.5f * (w1 - w2), o2 = 0.5f * (w1 + w2) + w3;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e][r * 3 + 0] = o0[e];
-        o[e][r * 3 + 1] = o1[e];
-        o[e][r * 3 + 2] = o2[e];
+        for (int e = 0; e < 4; ++e) {
+          o[e][0 * 3 + c] = o0[e];
+          o[e][1 * 3 + c] = o1[e];
+          o[e][2 * 3 + c] = o2[e];
+        }
+      }
+      float* dst = dw + idx * 9;
+#pragma unroll
+      for (int v = 0; v < 9; ++v) {
+        if ((v & 3) != i) continue;
+        f32x4 w4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w4[e] = o[(v * 4 + e) / 9][(v * 4 + e) % 9];
+        if (dw_vec) *reinterpret_cast<f32x4*>(dst + 4 * v) = w4;
+        else {                               // a gradient slice of the optimizer arena need not be 16-byte aligned
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[4 * v + e] = w4[e];
+        }
       }
     }
-    // the 4 x 9 results are 36 consecutive floats of dw (idx*9 is a multiple of 4 floats: float4 stores)
-    float* dst = dw + idx * 9;
-#pragma unroll
-    for (int v = 0; v < 9; ++v) {
-      f32x4 w4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w4[e] = o[(v * 4 + e) / 9][(v * 4 + e) % 9];
-      if (dw_vec) *reinterpret_cast<f32x4*>(dst + 4 * v) = w4;
-      else {                               // a gradient slice of the optimizer arena need not be 16-byte aligned
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[4 * v + e] = w4[e];
-      }
-    }
+    __syncthreads();
   }
 }
 
@@ -781,8 +788,8 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
     src = folded;
     nsrc = groups;
   }
-  int blocks = (int)(((slab >> 2) + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)(((slab >> 2) + 63) / 64);       // 64 quads (x 4 transform rows) per block
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc,
                      (reinterpret_cast<uintptr_t>(dw) & 15) == 0 ? 1 : 0);
   return check_launch("wino_wgrad_reduce_kernel");
