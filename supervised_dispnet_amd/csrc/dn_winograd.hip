@@ -1,7 +1,13 @@
-// Winograd F(2x2, 3x3) convolution on the CDNA4 fp32 matrix core (gfx950 only): forward and input gradient of the
+// Winograd F(2x2, 3x3) convolution on the CDNA4 matrix cores (gfx950 only): forward and input gradient of the
 // 3x3 / stride 1 / pad 1 layers (the whole VGG16-BN encoder but its first layer, and the channel-aligned decoder iconvs;
-// models/Disp_vgg_BN.py:84,93-105,137-186).  2.25x fewer multiply-accumulates than the direct contraction, all of them
-// exact fp32 FMAs on v_mfma_f32_32x32x2_f32; the transforms are fp32 adds (and multiplications by 1/2 on the weights).
+// models/Disp_vgg_BN.py:84,93-105,137-186).  2.25x fewer multiply-accumulates than the direct contraction; the transforms are
+// fp32 adds (and multiplications by 1/2 on the weights).  Three arithmetic variants of the 16 GEMMs (template parameter PREC,
+// dn_conv_desc.compute):
+//   PREC 3 (DN_COMPUTE_F32X3, the Python layer's default): every fp32 product from three exact bf16 pieces per operand, six partial
+//           products on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- an fp32 result at 2.7x the fp32 instruction's matrix rate;
+//   PREC 0 (DN_COMPUTE_F32): exact fp32 FMAs on v_mfma_f32_32x32x2_f32 (the description below is written for this one; the others
+//           differ in the main loop only);
+//   PREC 1 (DN_COMPUTE_BF16): operands rounded to bf16 (opt-in mixed precision).
 //
 //   Y_tile(2x2) = A^T [ sum_c  U_c (.) V_c ] A      V = B^T d B   (4x4 input patch d, per channel, on the fly)
 //                                                    U = G g G^T   (3x3 filter g, once per optimizer step: wino_pack_kernel)

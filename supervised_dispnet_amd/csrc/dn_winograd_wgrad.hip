@@ -1,4 +1,6 @@
-// Winograd F(2x2, 3x3) weight gradient of the 3x3 / stride 1 / pad 1 layers on the CDNA4 fp32 matrix core (gfx950 only).
+// Winograd F(2x2, 3x3) weight gradient of the 3x3 / stride 1 / pad 1 layers on the CDNA4 matrix cores (gfx950 only):
+// wino_wgrad_kernel (fp32 matrix instruction, DN_COMPUTE_F32 / _BF16) and wino_wgrad_x3_kernel (fp32 products from three exact bf16
+// pieces per operand on v_mfma_f32_32x32x16_bf16, DN_COMPUTE_F32X3 = the Python layer's default; described where it is defined).
 //
 //   dU_p[co][ci] = sum over tiles t of  Gt_p[t][co] * V_p[t][ci]        p = 4i + j, the 16 positions of the transform domain
 //   Gt = A dY A^T  (2x2 output-gradient tile -> 4x4),   V = B^T d B  (4x4 input patch -> 4x4, the forward's input transform)
