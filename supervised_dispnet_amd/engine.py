@@ -48,6 +48,8 @@ BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
 #   "bf16"  operands ROUNDED to bf16, fp32 accumulation: the "mixed precision" mode of BASELINE configs[4]; opt-in only
 # DN_COMPUTE=... or set_compute(...).
 COMPUTE_MODES = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f32x3": _lib.COMPUTE_F32X3}
+if os.environ.get("DN_COMPUTE", "f32x3").lower() not in COMPUTE_MODES:
+    raise ValueError("DN_COMPUTE=%r: expected one of %s" % (os.environ["DN_COMPUTE"], sorted(COMPUTE_MODES)))
 COMPUTE = COMPUTE_MODES[os.environ.get("DN_COMPUTE", "f32x3").lower()]
 
 
