@@ -197,6 +197,26 @@ def test_weight_layout_follows_the_geometry(lib):
         assert lib.dn_conv_wgrad_workspace_bytes(C.byref(dd)) > 0
 
 
+def test_compute_field_selects_the_packed_layout(lib):
+    """dn_conv_desc.compute (host only): the Winograd layers pack their weights per arithmetic -- 1 fp32 fragments (DN_COMPUTE_F32),
+    2 bf16-rounded (DN_COMPUTE_BF16), 3 three exact bf16 pieces (DN_COMPUTE_F32X3, 6 bytes per weight = 1.5 floats); layers on the
+    implicit-GEMM path ignore the field; unknown values mean fp32."""
+    from supervised_dispnet_amd._lib import COMPUTE_BF16, COMPUTE_F32, COMPUTE_F32X3
+    L = lambda d: lib.dn_conv_weight_layout(C.byref(d))
+    n32 = None
+    for mode, layout in ((COMPUTE_F32, 1), (COMPUTE_BF16, 2), (COMPUTE_F32X3, 3), (77, 1)):
+        d = _desc3x3(32, 64, 208, (128,), 128)
+        d.compute = mode
+        assert L(d) == layout
+        n = lib.dn_conv_packed_weight_elems(C.byref(d))
+        if n32 is None:
+            n32 = n
+        assert n == (n32 * 3 // 2 if layout == 3 else n32)
+        first = _desc3x3(32, 128, 416, (3,), 64)
+        first.compute = mode
+        assert L(first) == 0
+
+
 def test_bad_descriptors_are_rejected_not_crashing(lib):
     from supervised_dispnet_amd._lib import CONV_FWD, ConvDesc
     d = ConvDesc()
