@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_kernel(const IgemmParams p)
 //   * one patch in flight per thread (the chunk is ~2.5x shorter, the vector ALUs are what the kernel is bound by, and the registers
 //     are needed for the operands): a wave requests its next chunk's patch + gradient tile at the top of one chunk and transforms +
 //     stores them during the next one; ONE barrier per chunk, placed after the last read of the current buffer / the last store
-//     into the next one (slot 14 of 24), so that the next chunk's first operands are built under the current chunk's tail.
+//     into the next one (slot 12 of 24), so that the next chunk's first operands are built under the current chunk's tail.
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
@@ -600,6 +600,10 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
   } else {
     load_patch(1);
     load_grad(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) affine_piece(i);      // (what the request phase of "chunk -1" would have done)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) row_piece(b);
   }
   __syncthreads();
   {
@@ -636,20 +640,25 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
         if constexpr (part == 2 && grp < 4) issue_reads(grp + 2, cur, nxt);
         if constexpr (part == 2 && grp == 5) issue_reads(7, cur, nxt);
         if constexpr (part == 2 && grp >= 6) issue_reads(grp - 6, nxt, nxt);
-        if constexpr (!REQ && !(DBG & 1)) {
-          if constexpr (m < 8) {
-            affine_piece(2 * m);
-            affine_piece(2 * m + 1);
+        // staging of a wave's next chunk, balanced over its two phases: the request phase clamps + row-transforms the patch it asked
+        // for at the top of this chunk in its last nine slots (after the barrier, when the loads have had ~13 slots), the store phase
+        // column-transforms + stores it (and the gradient tile) in the slots before the barrier
+        if constexpr (REQ && !(DBG & 1)) {
+          if constexpr (m >= 13 && m < 21) {
+            affine_piece(2 * (m - 13));
+            affine_piece(2 * (m - 13) + 1);
           }
-          if constexpr (m == 8 || m == 9) {
-            row_piece(2 * (m - 8));
-            row_piece(2 * (m - 8) + 1);
+          if constexpr (m == 21 || m == 22) {
+            row_piece(2 * (m - 21));
+            row_piece(2 * (m - 21) + 1);
           }
-          if constexpr (m >= 10 && m < 14) col_piece(buf ^ 1, m - 10);
-          if constexpr (m >= 2 && m < 10 && (m % 2) == 0) g_cols(buf ^ 1, (m - 2) / 2);
         }
-        if constexpr (m == 14) __syncthreads();                   // all reads of `cur` are out, all stores into `nxt` are done
-        if constexpr (m == 14) issue_reads(6, cur, nxt);
+        if constexpr (!REQ && !(DBG & 1)) {
+          if constexpr (m < 4) g_cols(buf ^ 1, m);
+          if constexpr (m >= 4 && m < 12 && (m % 2) == 0) col_piece(buf ^ 1, (m - 4) / 2);
+        }
+        if constexpr (m == 12) __syncthreads();                   // all reads of `cur` are out (build 5's at slot 11), all stores into `nxt` are done (slot 10)
+        if constexpr (m == 14) issue_reads(6, cur, nxt);          // (its raw set is build 4's until that build's last part)
         __builtin_amdgcn_sched_barrier(0);
       });
     };
