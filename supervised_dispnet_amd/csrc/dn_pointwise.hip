@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __re
   __shared__ double red[kThreads];
   __shared__ double s_mean;
   double s1 = 0.0;
-  for (int r = threadIdx.x; r < rows; r += kThreads) s1 += (double)partial[((long long)r * C + c) * 2 + 0];
+#pragma unroll 8
+  for (int r = threadIdx.x; r < rows; r += kThreads) s1 += (double)partial[((long long)r * C + c) * 2 + 0];   // (8 strided loads in flight)
   red[threadIdx.x] = s1;
   __syncthreads();
   for (int o = kThreads / 2; o > 0; o >>= 1) {
@@ -134,6 +135,7 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __re
   __syncthreads();
   const double macc = s_mean;
   double m2 = 0.0;
+#pragma unroll 8
   for (int r = threadIdx.x; r < rows; r += kThreads) {
     const double left = count - (double)r * kBnTileRows;
     const double nt = left < (double)kBnTileRows ? left : (double)kBnTileRows;
