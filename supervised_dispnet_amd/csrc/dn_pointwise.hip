@@ -269,9 +269,11 @@ struct PoolBwdOp {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int e = 0; e < V; ++e) out[q].v[e] = 0.f;
+    unsigned codes = 0;                                   // the V routing bytes of this thread in one load when they form a dword
+    if constexpr (V == 4) codes = *reinterpret_cast<const unsigned*>(idx + row * C + c0);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const int code = idx[row * C + c0 + e];
+      const int code = V == 4 ? (int)((codes >> (8 * e)) & 0xffu) : (int)idx[row * C + c0 + e];
       if (code & 4) {
         const int q = code & 3;
         const float g = dp.v[e];
