@@ -8,8 +8,10 @@ KITTI-like data resident in HBM (BASELINE.json metric / configs[1]; SURVEY.md se
 One rank per GPU (RCCL over xGMI); the only exchange is the bucketed gradient all-reduce overlapped with the encoder backward.
 Rank 0 prints ONE JSON line.
 
-  --scaling weak    (default) every rank steps its own batch of --batch images (b32): per-GPU work fixed as N grows.
-  --scaling strong  the literal metric of BASELINE.json ("b32 @1/2/4/8 GPU"): --global-batch 32 split into 32/N per rank.
+  --scaling strong  (default) the literal metric of BASELINE.json ("b32 @1/2/4/8 GPU"): --global-batch 32 split into 32/N images per
+                    rank, total work fixed as N grows; `value` is that rate.  At N = 1 this IS b32 on one GPU.  With N > 1 the line also
+                    carries `weak_scaling` (every rank stepping its own b32, timed after the headline region) as a secondary figure.
+  --scaling weak    every rank steps its own batch of --batch images (b32): per-GPU work fixed as N grows.
   --config          vggbn128 (the headline) | vggbn480 | res50_480 | dorn128 | photo128: BASELINE.json configs[2..4] and the
                     480x640 secondary of SURVEY 8d produce their own lines (never the headline; `metric` says which).
 
@@ -229,7 +231,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="vggbn128", choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): --global-batch images per step over ALL ranks = BASELINE.json's 'b32 @1/2/4/8 GPU'; "
+                         "weak: --batch images per rank")
     ap.add_argument("--global-batch", type=int, default=32, help="--scaling strong: images per step over ALL ranks")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the config's; strong scaling: global/N)")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps (after the timed region) for the roofline")
@@ -244,7 +248,10 @@ def main():
                          "per operand, fp32 accumulation -- error vs fp64 at or below the fp32 instruction's (tests/test_gpu_kernels.py); "
                          "f32: the fp32 matrix instruction (also timed in every default run: field f32_mfma_path); "
                          "bf16: operands ROUNDED to bf16 (BASELINE configs[4]'s mixed precision; never the headline)")
-    ap.add_argument("--alt-steps", type=int, default=10, help="steps of the secondary timing with the fp32 matrix instruction (0: skip)")
+    ap.add_argument("--alt-steps", type=int, default=10, help="steps of the secondary timings (fp32 matrix instruction; weak scaling at N > 1) (0: skip)")
+    ap.add_argument("--rccl-selfcheck", default="auto", choices=["auto", "0", "1"],
+                    help="N > 1: after the timed region, all-reduce one 20 MB bucket through this library's own RCCL communicator AND through "
+                         "torch.distributed and compare bitwise (config.rccl_selfcheck); guarded by a watchdog that prints the line anyway")
     ap.add_argument("--graph", default="0", choices=["0", "1"],
                     help="1: replay the whole step (fwd + loss + bwd + Adam) as ONE captured hipGraph.  Off by default: measured on "
                          "ROCm 7.2 the replay is 1-4 %% SLOWER than the eager launches at every batch size (profiles/r02_strong_1gpu.txt)")
@@ -289,9 +296,12 @@ def main():
     if args.compute == "bf16":
         metric = metric.replace(", fp32)", ", mixed precision: bf16 multiplies / fp32 accumulation in the Winograd kernels)")
     if args.scaling == "strong":
-        if args.global_batch % world:
-            raise SystemExit("--global-batch %d does not divide over %d ranks" % (args.global_batch, world))
-        batch = args.global_batch // world
+        gb = args.global_batch if args.global_batch > 0 else cfg_batch
+        if args.config != "vggbn128" and args.global_batch == 32:
+            gb = cfg_batch                               # the other configs are quoted on their own batch (b16 at 480x640)
+        if gb % world:
+            raise SystemExit("global batch %d does not divide over %d ranks" % (gb, world))
+        batch = args.batch or gb // world
     else:
         batch = args.batch or cfg_batch
     step, opt, state, desc = build_workload(args.config, batch, dev, rank, models, LF, U, reciprocal, FusedAdam)
@@ -365,6 +375,34 @@ def main():
             eager_step()
         torch.cuda.synchronize()
 
+    # ---- secondary timing at N > 1 (not `value`): weak scaling, every rank stepping its own full batch of the config
+    weak = None
+    if world > 1 and args.scaling == "strong" and args.alt_steps > 0 and batch != cfg_batch:
+        engine.GradSink.reducer = None
+        wstep, wopt, wstate, _wdesc = build_workload(args.config, cfg_batch, dev, rank, models, LF, U, reciprocal, FusedAdam)
+        wred = GradReducer(wopt.arena)
+        wstate["reducer"] = wred
+        engine.GradSink.reducer = wred
+        for _ in range(3):
+            wstep()
+        gc.collect()
+        gc.disable()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.alt_steps):
+            wstep()
+        fence()
+        wdt = time.perf_counter() - t0
+        gc.enable()
+        t = torch.tensor([wdt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wdt = float(t.item())
+        weak = {"scaling": "weak", "batch_per_gpu": cfg_batch, "global_batch": cfg_batch * world, "value": cfg_batch * world * args.alt_steps / wdt,
+                "unit": "images/sec", "ms_per_step": wdt / args.alt_steps * 1e3, "steps": args.alt_steps, "comm": wred.path}
+        engine.GradSink.reducer = reducer
+        del wstep, wopt, wstate, wred
+        torch.cuda.synchronize()
+
     # ---- instrumented steps (not part of `value`): HIP events around every conv-family launch and every HBM-bound family
     roofline = roofline_hbm = None
     step_exec_flops = step_credited_flops = None
@@ -401,7 +439,7 @@ def main():
         # multiply-accumulates x 2 the algorithm needs in fp32 terms (Winograd: 16/36 of the direct ones) ...
         execf = lambda k, fl: fl * (WINO_EXEC if "wino_" in k else 1.0)
         # ... and what the matrix pipe the kernel runs on executes for them (f32x3: six bf16 partial products per fp32 multiply)
-        is_x3 = lambda k: "wino_conv_kernel" in k and k.endswith(", 3>")
+        is_x3 = lambda k: ("wino_conv_kernel" in k and k.endswith(", 3>")) or "wino_wgrad_x3_kernel" in k
         is_bf = lambda k: "wino_conv_kernel" in k and k.endswith(", 1>")
         pipef = lambda k, fl: execf(k, fl) * (X3_PRODUCTS if is_x3(k) else 1.0)
         step_credited_flops = sum(v[0] for v in mf.values()) / nps
@@ -417,7 +455,7 @@ def main():
             if is_x3(name):
                 algo += "; each fp32 product = six bf16 partial products (three exact bf16 pieces per operand) on v_mfma_f32_32x32x16_bf16, fp32 accumulation"
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": kpeak, "unit": "TFLOP/s",
-                    "frac": ach / kpeak, "traffic": pmc_traffic(name),
+                    "frac": ach / kpeak, "traffic": pmc_traffic(name), "traffic_source": pmc_traffic_source(name),
                     "pipe": "bf16 matrix cores (dense peak 2500 TFLOP/s)" if on_bf16_pipe else "fp32 matrix instruction (157.3 TFLOP/s)",
                     "fp32_equivalent_achieved": execf(name, fl) / sec / 1e12,
                     "fp32_equivalent_frac_of_fp32_mfma_peak": execf(name, fl) / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -430,12 +468,13 @@ def main():
                     "avg_launch_gflop_credited": fl / n / 1e9,
                     "by_kernel": {k: {"tflops_executed": pipef(k, v[0]) / v[1] / 1e12, "tflops_fp32_equivalent": execf(k, v[0]) / v[1] / 1e12,
                                       "tflops_credited": v[0] / v[1] / 1e12,
+                                      "pipe_frac": pipef(k, v[0]) / v[1] / 1e12 / (PEAK_BF16_MFMA_TFLOPS if (is_x3(k) or is_bf(k)) else PEAK_FP32_MFMA_TFLOPS),
                                       "ms_per_step": v[1] / nps * 1e3, "launches_per_step": v[2] // nps} for k, v in sorted(mf.items())}}
         if hb:
             name, (nb, sec, n) = max(hb.items(), key=lambda kv: kv[1][1])
             gbps = nb / sec / 1e9
             roofline_hbm = {"bound": "hbm", "kernel": name, "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                            "frac": gbps / PEAK_HBM_GBPS, "traffic": pmc_traffic(name), "frac_of_measured_peak": gbps / peaks["copy_GBps"],
+                            "frac": gbps / PEAK_HBM_GBPS, "traffic": pmc_traffic(name), "traffic_source": pmc_traffic_source(name), "frac_of_measured_peak": gbps / peaks["copy_GBps"],
                             "measured_peak": peaks["copy_GBps"], "launches_per_step": n // nps, "avg_launch_ms": sec / n * 1e3,
                             "avg_launch_algorithmic_bytes": nb / n,
                             "by_kernel": {k: {"GBps": v[0] / v[1] / 1e9, "ms_per_step": v[1] / nps * 1e3, "launches_per_step": v[2] // nps}
@@ -460,16 +499,88 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "launch": "one hipGraph replay per step" if graphed else "eager launches", "graph_fallback": graph_note},
+                       "launch": "one hipGraph replay per step" if graphed else "eager launches", "graph_fallback": graph_note,
+                       "comm": reducer.path if reducer is not None else "none (one rank)",
+                       "dist_backend": dist.get_backend() if world > 1 else None},
             "step_tflops_credited_per_gpu": (step_credited_flops / sec_step / 1e12) if step_credited_flops else None,
             "step_credited_frac": (step_credited_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_credited_flops else None,
             "step_executed_frac": (step_exec_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_exec_flops else None,
             "baseline_md_gflop_per_img": gflop_img,
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "f32_mfma_path": alt, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "f32_mfma_path": alt, "weak_scaling": weak, "cpu_baseline": cpu,
         }
+    else:
+        line = None
+    if world > 1 and args.rccl_selfcheck != "0" and os.environ.get("DN_DIST_BACKEND", "nccl") == "nccl":
+        rccl_selfcheck(line, dev, rank, world)
+    if rank == 0:
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def rccl_selfcheck(line, dev, rank, world, timeout_s=90.0):
+    """N > 1 only, AFTER every timed region: one 20 MB gradient-bucket-sized buffer is summed over the ranks through this library's own
+    RCCL communicator (rccl.Communicator: ncclCommInitRank from a unique id passed through torch.distributed's store, ncclAllReduce
+    on a library stream, event fences) and through torch.distributed.all_reduce, and the two results are compared bit for bit; both
+    paths are also timed (10 all-reduces each).  Recorded as config.rccl_selfcheck -- the evidence DN_COMM=rccl's default-off status
+    is waiting for.  A watchdog prints the line (rank 0) and ends the process if the own path blocks, so the headline never depends
+    on it."""
+    import threading
+    import torch.distributed as dist
+    result = {"status": "started", "world": world}
+    if line is not None:
+        line["config"]["rccl_selfcheck"] = result
+
+    def bail():
+        result["status"] = "timeout after %.0f s (own-RCCL path blocked); the line above it is unaffected" % timeout_s
+        if rank == 0:
+            print(json.dumps(line))
+            sys.stdout.flush()
+        os._exit(0)
+
+    dog = threading.Timer(timeout_s, bail)
+    dog.daemon = True
+    dog.start()
+    try:
+        from supervised_dispnet_amd.distributed import open_rccl_communicator
+        comm = open_rccl_communicator(dev)
+        if comm is None:
+            result["status"] = "own communicator not available on every rank"
+            return
+        n = (20 << 20) // 4
+        g = torch.Generator().manual_seed(1234 + rank)
+        src = torch.randn(n, generator=g).to(dev)
+        a, b = src.clone(), src.clone()
+        comm.all_reduce_sum_(a, [torch.cuda.current_stream()])
+        comm.join()
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(a, b))
+        maxdiff = float((a - b).abs().max().item())
+        times = {}
+        for name in ("rccl-own", "torch.distributed"):
+            x = src.clone()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                if name == "rccl-own":
+                    comm.all_reduce_sum_(x, [torch.cuda.current_stream()])
+                    comm.join()
+                else:
+                    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            times[name] = (time.perf_counter() - t0) / 10 * 1e6
+        ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        comm.destroy()
+        result.update({"status": "ok", "bitwise_equal_on_all_ranks": bool(int(ok.item()) == 1), "max_abs_diff_rank0": maxdiff,
+                       "bytes": n * 4, "us_per_allreduce": times})
+    except Exception as e:                                     # noqa: BLE001 -- diagnostic only
+        result["status"] = "error: %s: %s" % (type(e).__name__, str(e)[:200])
+    finally:
+        dog.cancel()
 
 
 def dry_run(args, world, rank):
@@ -523,6 +634,16 @@ def pmc_traffic(kernel):
         return (k["read_bytes"] + k["write_bytes"]) if k else None
     except Exception:
         return None
+
+
+def pmc_traffic_source(kernel):
+    """Which committed profile `traffic` was read from: the PMC passes describe the build that was PROFILED, which may be older than
+    the build this run timed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files or pmc_traffic(kernel) is None:
+        return None
+    return "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the build that was profiled, not measured in this run)" % os.path.basename(files[-1])
 
 
 def _quiet_init(net):

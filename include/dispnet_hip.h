@@ -371,12 +371,17 @@ int dn_ordinal_fwd(const float* pre, int64_t stride_n, int64_t stride_pix, int64
                    int64_t* decode, dn_stream_t stream);
 int dn_ordinal_bwd(const float* pre, int64_t stride_n, int64_t stride_pix, int64_t stride_c, const float* ord, const float* dord, int32_t N,
                    int64_t HW, int32_t K, float* dpre, dn_stream_t stream);
-/* DORN_loss: target = SID labels int32 [N][HW]; stats[2] = (sum, num_valid) kept for the backward. */
+/* DORN_loss: target = SID labels int32 [N][HW]; stats[2] = (sum, num_valid) kept for the backward; loss = sum / -num_valid.
+ * One process per GPU (the reference's DataParallel sees the gathered batch on GPU0 and divides by ITS valid count,
+ * loss_functions.py:69-73): the caller sums `stats` over the ranks between dn_ordinal_loss_fwd and dn_ordinal_loss_finalize
+ * (loss = stats[0] / -stats[1] again, from the exchanged pair) and passes grad_scale = world size to the backward, whose 1/num_valid
+ * is then the whole batch's; grad_scale = 1 otherwise. */
 int32_t dn_ordinal_loss_blocks(int32_t N, int64_t HW);
 int dn_ordinal_loss_fwd(const float* ord, const float* gt, const int32_t* target, int32_t N, int64_t HW, int32_t K, float max_depth,
                         float* partial, float* stats, float* loss, dn_stream_t stream);
+int dn_ordinal_loss_finalize(const float* stats, float* loss, dn_stream_t stream);
 int dn_ordinal_loss_bwd(const float* ord, const float* gt, const int32_t* target, const float* stats, const float* dloss, int32_t N,
-                        int64_t HW, int32_t K, float max_depth, float* dord, dn_stream_t stream);
+                        int64_t HW, int32_t K, float max_depth, float grad_scale, float* dord, dn_stream_t stream);
 /* get_labels_sid / get_depth_sid (beta = 80.999 kitti, 10.999 nyu). */
 /* Fused head (models/Disp_vgg_BN_DORN.py:112-114,191-227): Dropout2d channel mask (mask[N][16] = 0 or 1/(1-p), NULL = none) ->
  * 1x1 convolution 16 -> 2K (w = conv_ord.weight [2K][16], bias [2K]) -> clamp -> pair softmax.  The 2K-channel logits never reach

@@ -80,3 +80,32 @@ def compute_errors_np(gt, pred):
     abs_rel = np.mean(np.abs(gt - pred) / gt)
     sq_rel = np.mean(((gt - pred) ** 2) / gt)
     return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+
+
+def compute_abs_rel_per_pixel(gt, pred, min_depth, max_depth):
+    """test_disp.py:471-477."""
+    valid = (gt > min_depth) & (gt < max_depth)
+    valid_complement = np.logical_not(valid)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        abs_rel = np.abs(gt - pred) / gt
+    abs_rel[valid_complement] = -1
+    return abs_rel
+
+
+def worst_pixels_loop(abs_rel_map, count=300):
+    """test_disp.py:318-338 restated WITHOUT numpy's selection routine: every valid pixel inside the Garg crop in row-major order,
+    then the `count` largest abs_rel values by a full stable sort.  Returns the selected (row, col) pairs as a sorted list of tuples --
+    the SET the reference's np.argpartition(..., -300)[-300:] selects whenever the 300th and 301st largest values differ (the
+    order inside argpartition's output is an implementation detail of numpy's introselect and is compared separately, through the
+    committed golden)."""
+    h, w = abs_rel_map.shape
+    c = garg_crop(h, w)
+    rows = []
+    for y in range(int(c[0]), int(c[1])):
+        for x in range(int(c[2]), int(c[3])):
+            v = abs_rel_map[y, x]
+            if v > 0:
+                rows.append((float(v), y, x))
+    rows.sort(key=lambda r: r[0])
+    return sorted((y, x) for _, y, x in rows[-count:]), (rows[-count][0] if len(rows) >= count else None), \
+        (rows[-count - 1][0] if len(rows) > count else None)

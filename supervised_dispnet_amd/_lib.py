@@ -10,6 +10,11 @@ import pathlib
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip.so"))
 
+# ABI version this binding was written against (include/dispnet_hip.h: dn_version(), bumped on any signature / struct change).
+# load() refuses a library that reports anything else: a stale .so (DISPNET_HIP_LIB, a build that did not re-run) would otherwise
+# read struct fields past the end of what this binding fills in and mis-marshal arguments -- silent memory corruption, not an error.
+EXPECTED_ABI = 6
+
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F32X3 = 0, 1, 2
@@ -124,7 +129,8 @@ SIGNATURES = {
     "dn_ordinal_bwd": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "dn_ordinal_loss_blocks": (_i32, [_i32, _i64]),
     "dn_ordinal_loss_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _f, _vp, _vp, _vp, _vp]),
-    "dn_ordinal_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _vp, _vp]),
+    "dn_ordinal_loss_finalize": (C.c_int, [_vp, _vp, _vp]),
+    "dn_ordinal_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f, _f, _vp, _vp]),
     "dn_ord_head_supported": (_i32, [_i32, _i64, _i32]),
     "dn_ord_head_bwd_blocks": (_i32, [_i32, _i64]),
     "dn_ord_head_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
@@ -168,6 +174,11 @@ def load():
     except ImportError:
         pass
     lib = C.CDLL(str(LIB_PATH))
+    lib.dn_version.restype, lib.dn_version.argtypes = C.c_int, []
+    got = lib.dn_version()
+    if got != EXPECTED_ABI:
+        raise DispnetHipError("%s reports ABI version %d but this binding expects %d: rebuild it (`python supervised_dispnet_amd/csrc/"
+                              "build.py --force`) -- a stale library would mis-marshal descriptors and arguments" % (LIB_PATH, got, EXPECTED_ABI))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -101,12 +101,16 @@ __global__ void ordinal_loss_finalize_kernel(const float* __restrict__ partial, 
   loss[0] = (float)s / (-(float)c);
 }
 
+__global__ void ordinal_loss_refinalize_kernel(const float* __restrict__ stats, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = stats[0] / (-stats[1]);
+}
+
 __global__ void __launch_bounds__(256) ordinal_loss_bwd_kernel(const float* __restrict__ ord, const float* __restrict__ gt,
                                                                const int* __restrict__ target, const float* __restrict__ stats,
                                                                const float* __restrict__ dloss, int N, long long HW, int K, float max_depth,
-                                                               float* __restrict__ dord) {
+                                                               float grad_scale, float* __restrict__ dord) {
   const long long total = (long long)N * HW;
-  const float up = dloss[0] / (-stats[1]);
+  const float up = grad_scale == 1.f ? dloss[0] / (-stats[1]) : (dloss[0] * grad_scale) / (-stats[1]);
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const float g = gt[i];
     const bool valid = g > 0.f && g < max_depth;
@@ -201,11 +205,17 @@ int dn_ordinal_loss_fwd(const float* ord, const float* gt, const int32_t* target
   return check_launch("ordinal_loss_fwd");
 }
 
+int dn_ordinal_loss_finalize(const float* stats, float* loss, dn_stream_t stream) {
+  DN_REQUIRE(stats && loss, DN_ERR_BAD_ARG, "dn_ordinal_loss_finalize: bad argument");
+  hipLaunchKernelGGL(ordinal_loss_refinalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), stats, loss);
+  return check_launch("ordinal_loss_refinalize_kernel");
+}
+
 int dn_ordinal_loss_bwd(const float* ord, const float* gt, const int32_t* target, const float* stats, const float* dloss, int32_t N,
-                        int64_t HW, int32_t K, float max_depth, float* dord, dn_stream_t stream) {
+                        int64_t HW, int32_t K, float max_depth, float grad_scale, float* dord, dn_stream_t stream) {
   DN_REQUIRE(ord && gt && target && stats && dloss && dord && N > 0 && HW > 0 && K > 0, DN_ERR_BAD_ARG, "dn_ordinal_loss_bwd: bad argument");
   hipLaunchKernelGGL(ordinal_loss_bwd_kernel, dim3(ew_blocks_o((long long)N * HW)), dim3(256), 0, as_stream(stream), ord, gt, target, stats,
-                     dloss, N, (long long)HW, K, max_depth, dord);
+                     dloss, N, (long long)HW, K, max_depth, grad_scale, dord);
   return check_launch("ordinal_loss_bwd_kernel");
 }
 

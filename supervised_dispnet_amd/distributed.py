@@ -12,35 +12,85 @@ import torch
 import torch.distributed as dist
 
 
+def agree_all_ranks(ok, process_group=None, device=None):
+    """True iff `ok` is true on EVERY rank (MIN all-reduce of a flag over torch.distributed); with one rank: bool(ok).  Used to take
+    collective decisions -- which data path the gradient exchange uses -- so that no subset of ranks ever ends up on a different
+    communicator than its peers (that would hang the job without an error)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) <= 1:
+        return bool(ok)
+    backend = dist.get_backend(process_group)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if (backend == "nccl" and device is not None) else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+    return bool(int(flag.item()) == 1)
+
+
+def open_rccl_communicator(device, strict=False):
+    """This library's own RCCL communicator on ALL ranks, or None on ALL ranks.  Two agreement rounds: (1) librccl loads everywhere --
+    checked BEFORE rank 0's unique id is broadcast, so a rank that cannot load the library never leaves its peers blocked in the
+    broadcast; (2) ncclCommInitRank succeeded everywhere -- otherwise every rank that did get a communicator destroys it and all of
+    them use torch.distributed.  `strict` (an explicit request for the own path) turns a refusal into an error, also collectively."""
+    import sys
+    from . import rccl
+    err = None
+    try:
+        rccl.load()
+    except Exception as e:                       # noqa: BLE001
+        err = e
+    if not agree_all_ranks(err is None, device=device):
+        if strict:
+            raise RuntimeError("own RCCL communicator requested but librccl does not load on every rank (%s)" % (err,))
+        if err is not None:
+            print("supervised_dispnet_amd: librccl unavailable on this rank (%s); all ranks use torch.distributed" % err, file=sys.stderr)
+        return None
+    comm = None
+    try:
+        comm = rccl.Communicator(device=device)
+    except Exception as e:                       # noqa: BLE001
+        err = e
+    if not agree_all_ranks(comm is not None, device=device):
+        if comm is not None:
+            comm.destroy()
+        if strict:
+            raise RuntimeError("own RCCL communicator requested but ncclCommInitRank did not succeed on every rank (%s)" % (err,))
+        print("supervised_dispnet_amd: own RCCL communicator not available on every rank (%s); all ranks use torch.distributed" % (err,),
+              file=sys.stderr)
+        return None
+    return comm
+
+
 class GradReducer(object):
-    """`comm`: "rccl" = this library's own communicator and HIP stream (rccl.Communicator: ncclAllReduce + event fences, the
-    default for device arenas), "torch" = torch.distributed.all_reduce(async_op=True) (gloo on CPU in the tests; also available on the
-    device for A/B), or a ready rccl.Communicator.  DN_COMM=torch|rccl overrides the default."""
+    """`comm`: "torch" = torch.distributed.all_reduce(async_op=True) on the launcher's process group (backend "nccl" IS RCCL on ROCm;
+    gloo on CPU in the tests) -- the DEFAULT whenever there is more than one rank; "rccl" = this library's own communicator and HIP
+    stream (rccl.Communicator: ncclCommInitRank / ncclAllReduce + event fences) -- the default at world == 1 (where it is exercised
+    bit-for-bit by tests/test_gpu_rccl.py) and opt-in (DN_COMM=rccl) beyond, because no multi-GPU node has been available to this
+    build to validate it against the torch path (bench.py --gpus N records exactly that comparison as config.rccl_selfcheck); or a
+    ready rccl.Communicator.  Whatever is chosen is chosen by ALL ranks together (open_rccl_communicator).  `self.path` names the
+    data path that actually runs ("rccl-own" / "torch.distributed:<backend>" / "none")."""
 
     def __init__(self, arena, bucket_bytes=20 << 20, process_group=None, comm=None):
         self.arena = arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         import os
-        choice = comm if comm is not None else os.environ.get("DN_COMM", "rccl" if arena.flat_g.is_cuda else "torch")
+        env = os.environ.get("DN_COMM")
+        default = "rccl" if (arena.flat_g.is_cuda and self.world == 1) else "torch"
+        choice = comm if comm is not None else (env or default)
         self.comm = None
         if choice == "rccl":
             if not arena.flat_g.is_cuda or process_group is not None:
                 raise ValueError("the RCCL communicator serves device arenas on the default process group")
-            from .rccl import Communicator
-            try:
-                self.comm = Communicator(device=arena.flat_g.device)
+            self.comm = open_rccl_communicator(arena.flat_g.device, strict=(comm == "rccl" or env == "rccl") and self.world > 1)
+            if self.comm is not None:
                 self.world = self.comm.world
-            except Exception as e:               # noqa: BLE001 -- same arithmetic through torch.distributed; say so
-                import sys
-                if comm == "rccl":
-                    raise
-                print("supervised_dispnet_amd: own RCCL communicator unavailable (%s); gradients go through torch.distributed" % e,
-                      file=sys.stderr)
-                self.comm = None
         elif choice != "torch":
             self.comm = choice
             self.world = choice.world
+        if self.comm is not None:
+            self.path = "rccl-own"
+        elif self.world > 1:
+            self.path = "torch.distributed:%s" % dist.get_backend(process_group)
+        else:
+            self.path = "none"
         # contiguous buckets over the arena (arena order == gradient production order)
         self.buckets, start, acc = [], 0, 0
         for i, (p, o) in enumerate(zip(arena.params, arena.offsets)):

@@ -17,6 +17,7 @@ import ctypes as C
 import math
 import os
 import threading
+import weakref
 
 import torch
 
@@ -397,19 +398,23 @@ class ConvLayer:
         _lib.call("dn_conv_pack_weights", C.byref(desc), wc.data_ptr(), buf.data_ptr(), _stream())
         self._packed[(kind, layout)] = (key, buf)
         if table is not None and contiguous:
-            table.register((id(self), kind, layout) + split, desc, w, buf)
+            table.register((id(self), kind, layout) + split, desc, w, buf, self)
+        elif table is not None and table.rows.pop((id(self), kind, layout) + split, None) is not None:
+            table.dirty = True                   # a row of this layer must never outlive the buffer it points at
         return buf
 
 
 class PackTable(object):
     """All weight re-lays of a training step as ONE batched launch (dn_pack_many) instead of ~53 launches of 6-8 us each.
     Rows are collected the first time a (layer, kind, layout) is packed the ordinary way; the table is uploaded when it changed and
-    replayed at the start of the first forward after every optimizer step.  A row is dropped when its weight tensor moved."""
+    replayed at the start of the first forward after every optimizer step.  A row holds only WEAK references (to its ConvLayer, which
+    owns the packed buffer, and to the weight tensor): when a model is deleted its rows die with it -- no leaked HBM, no re-lays of
+    dead weights on later steps -- and a row is also dropped when its weight tensor moved."""
     MAX_ROWS = 512
 
     def __init__(self, device):
         self.device = device
-        self.rows = {}                  # key -> [entry bytes, wino flag, weight tensor, packed buffer, weight ptr]
+        self.rows = {}                  # key -> [entry bytes, wino flag, weakref(weight), weakref(owning ConvLayer), weight ptr, buffer ptr]
         self.dirty = True
         self.dev_table = None
         self.counts = (0, 0, 0, 0)
@@ -417,15 +422,28 @@ class PackTable(object):
         self.covered = set()
         self.esize = int(_lib.load().dn_pack_entry_bytes())
 
-    def register(self, key, desc, w, buf):
+    def register(self, key, desc, w, buf, owner):
+        if len(self.rows) >= self.MAX_ROWS:
+            self._prune()
         if len(self.rows) >= self.MAX_ROWS:
             self.rows.clear()
         entry = (C.c_char * self.esize)()
         wino = _lib.load().dn_pack_entry_fill(C.byref(desc), w.data_ptr(), buf.data_ptr(), entry)
         if wino < 0:
             raise _lib.DispnetHipError("dn_pack_entry_fill: " + _lib.last_error())
-        self.rows[key] = [bytes(entry), int(wino), w, buf, w.data_ptr()]
+        self.rows[key] = [bytes(entry), int(wino), weakref.ref(w), weakref.ref(owner), w.data_ptr(), buf.data_ptr()]
         self.dirty = True
+
+    def _prune(self):
+        """Drop rows whose layer or weight is gone (the packed buffer died with the layer: it must not be written again) or moved."""
+        dead = []
+        for k, r in self.rows.items():
+            w = r[2]()
+            if w is None or r[3]() is None or w.data_ptr() != r[4]:
+                dead.append(k)
+        for k in dead:
+            del self.rows[k]
+            self.dirty = True
 
     def fresh(self, buf, epoch):
         return self.epoch == epoch and buf.data_ptr() in self.covered
@@ -434,10 +452,7 @@ class PackTable(object):
         """Re-lay every registered row from the current weights (called once per optimizer step, before the forward)."""
         if self.epoch == epoch or not self.rows:
             return
-        stale = [k for k, r in self.rows.items() if r[2].data_ptr() != r[4]]
-        for k in stale:
-            del self.rows[k]
-            self.dirty = True
+        self._prune()
         if not self.rows:
             return
         if self.dirty:
@@ -446,7 +461,7 @@ class PackTable(object):
             blob = b"".join(r[0] for r in ordered)
             self.dev_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
             self.counts = tuple(len(k) for k in kinds)
-            self.covered = {r[3].data_ptr() for r in ordered}
+            self.covered = {r[5] for r in ordered}
             self.dirty = False
         _lib.call("dn_pack_many", self.dev_table.data_ptr(), *self.counts, _stream())
         self.epoch = epoch

@@ -110,6 +110,54 @@ def compute_errors(gt, pred):
     return np.mean(np.abs(gt - pred) / gt), np.mean(((gt - pred) ** 2) / gt), rmse, rmse_log, a1, a2, a3
 
 
+def compute_abs_rel_per_pixel(gt, pred, min_depth, max_depth):
+    """test_disp.py:471-477 -> |gt - pred| / gt per pixel, -1 where gt is outside (min_depth, max_depth).  (gt == 0 pixels divide by
+    zero exactly like the reference and are then overwritten with -1.)"""
+    valid = (gt > min_depth) & (gt < max_depth)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        abs_rel = np.abs(gt - pred) / gt
+    abs_rel[np.logical_not(valid)] = -1
+    return abs_rel
+
+
+def worst_pixels(abs_rel_map, count=300, threshold=None):
+    """test_disp.py:318-343: the pixels with abs_rel > 0 inside the Garg crop, as (row, col, abs_rel) rows in np.where order; then
+    either the `count` largest through np.argpartition(values, -count)[-count:] (the reference's `worst = True` branch, count 300)
+    or, with `threshold`, the ones above it (the `else` branch, 0.3).  Returns (graph_index int32 [k, 2], index_result float64 [n, 3]).
+    Index arithmetic -- identical to the reference's for identical inputs (same numpy selection routine on the same array)."""
+    valid = abs_rel_map > 0
+    gt_height, gt_width = valid.shape[:2]
+    c = garg_crop(gt_height, gt_width)
+    crop_mask = np.zeros(valid.shape)
+    crop_mask[c[0]:c[1], c[2]:c[3]] = 1
+    valid = np.logical_and(valid, crop_mask)
+    ind = np.where(valid)
+    index_result = np.zeros((len(ind[0]), 3))
+    index_result[:, 0] = ind[0]
+    index_result[:, 1] = ind[1]
+    index_result[:, 2] = abs_rel_map[valid]
+    if threshold is None:
+        if len(ind[0]) < count:
+            raise ValueError("only %d valid pixels inside the crop, %d requested (np.argpartition would raise too)" % (len(ind[0]), count))
+        pick = np.argpartition(index_result[:, 2], -count)[-count:]
+    else:
+        pick = index_result[:, 2] > threshold
+    return index_result[pick, :2].astype(np.int32), index_result
+
+
+def annotate_pixels(tgt, graph_index, size=5):
+    """test_disp.py:345-350: a size x size patch at every selected pixel is tinted red (R -> R/2 + 127.5, G, B -> /2, truncated),
+    applied sequentially per patch offset on a copy of the uint8-valued image [H, W, 3]."""
+    out = np.copy(tgt)
+    for k in range(size):
+        for l in range(size):
+            y, x = graph_index[:, 0] + k, graph_index[:, 1] + l
+            out[(y, x, 0)] = (out[(y, x, 0)] / 2.0 + 255.0 / 2.0).astype(int)
+            out[(y, x, 1)] = (out[(y, x, 1)] / 2.0).astype(int)
+            out[(y, x, 2)] = (out[(y, x, 2)] / 2.0).astype(int)
+    return out
+
+
 def imresize_bilinear(arr, size):
     """scipy.misc.imresize(arr, (h, w)) as test_disp.py:194 uses it (removed from SciPy): byte-scale the float image by its own
     min/max to uint8, PIL bilinear resize, back to an array."""

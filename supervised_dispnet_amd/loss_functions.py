@@ -419,8 +419,14 @@ def smooth_DORN_loss(pred_map):
 
 # --------------------------------------------------------------------------------------------------------------- DORN
 class _OrdinalLoss(torch.autograd.Function):
+    """DORN_loss as one autograd node.  `sync` (a world size > 1): the loss is a WHOLE-BATCH mean (loss_functions.py:69-73 divide by
+    the valid-pixel count of the batch the reference's DataParallel gathered on GPU0): every rank reduces its own pixels to
+    (sum, count), the pair is summed over the ranks (distributed.exchange_loss_stats) and the division happens afterwards
+    (dn_ordinal_loss_finalize); the backward yields world * d(global loss)/d(local probabilities), which the data-parallel
+    optimizer's 1/world turns back into the sum -- the same scheme as _MaskedLoss."""
+
     @staticmethod
-    def forward(ctx, gt_depth, ord_labels, target, max_depth):
+    def forward(ctx, gt_depth, ord_labels, target, max_depth, sync=0):
         require_cuda(ord_labels, "ordinal probabilities")
         require_cuda(gt_depth, "ground-truth depth")
         require_cuda(target, "SID target labels")
@@ -437,24 +443,30 @@ class _OrdinalLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         _lib.call("dn_ordinal_loss_fwd", oc.data_ptr(), gtc.data_ptr(), tc.data_ptr(), n, h * w, k, max_depth, partial.data_ptr(),
                   stats.data_ptr(), loss.data_ptr(), _stream())
+        if sync > 1:
+            from .distributed import exchange_loss_stats
+            exchange_loss_stats(stats.view(1, 2), sum_cols=(0, 1))
+            _lib.call("dn_ordinal_loss_finalize", stats.data_ptr(), loss.data_ptr(), _stream())
         ctx.save_for_backward(oc, gtc, tc, stats)
-        ctx.cfg = (n, k, h, w, max_depth)
+        ctx.cfg = (n, k, h, w, max_depth, float(max(sync, 1)))
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         oc, gtc, tc, stats = ctx.saved_tensors
-        n, k, h, w, max_depth = ctx.cfg
+        n, k, h, w, max_depth, up = ctx.cfg
         dl = dloss.contiguous().float()
         dord = torch.empty_like(oc)
         _lib.call("dn_ordinal_loss_bwd", oc.data_ptr(), gtc.data_ptr(), tc.data_ptr(), stats.data_ptr(), dl.data_ptr(), n, h * w, k,
-                  max_depth, dord.data_ptr(), _stream())
-        return None, dord, None, None
+                  max_depth, up, dord.data_ptr(), _stream())
+        return None, dord, None, None, None
 
 
 def DORN_loss(gt_depth, ord_labels, target, datasets):
-    """reference loss_functions.py:16-74."""
-    return _OrdinalLoss.apply(gt_depth, ord_labels, target, _max_depth(datasets))
+    """reference loss_functions.py:16-74.  Under one process per GPU the (sum, num_valid) pair is exchanged before the division, so the
+    value and the gradients are the reference's whole-batch ones."""
+    from .distributed import data_parallel_world
+    return _OrdinalLoss.apply(gt_depth, ord_labels, target, _max_depth(datasets), data_parallel_world())
 
 
 # ------------------------------------------------------------------------------------------------------------ metrics

@@ -10,8 +10,10 @@ ship 12 B per pixel over PCIe.  At ~1 400 img/s per GPU that path starves the de
     3 B per pixel to the device on a side stream, and ONE kernel (`dn_u8_normalize_flip`) produces the normalised fp32 NCHW batch with
     the per-sample RandomHorizontalFlip folded in (`dn_flip_w` mirrors the ground truth; the intrinsics' cx flips on the host).
 
-The values are bit-identical to the host chain (`data.Transform`): ((float)u8 / 255 - mean) / std in IEEE fp32, same flip draw
-(`random.random() < 0.5` per sample).
+The values are bit-identical to the host chain (`data.Transform`): ((float)u8 / 255 - mean) / std in IEEE fp32, same flip rule
+(`rng.random() < 0.5`, one draw per sample).  The draws come from a PRIVATE `random.Random(seed + rank)` that `set_epoch` re-seeds
+(seed, rank, epoch), so the flips are reproducible from --seed whatever else the process does with the global `random` module; a
+caller that wants the JPEG loader's exact draws passes its own generator as `flip_rng` (tests do).
 """
 import json
 import os
@@ -72,12 +74,22 @@ def write_shards(root, out_dir, train=True, sequence_length=3, with_gt=False):
 
 
 class ShardSet(object):
-    def __init__(self, shard_dir):
+    def __init__(self, shard_dir, percentage=1, seed=None):
+        """`percentage` < 1 keeps that share of the samples after a seeded shuffle -- the reference's --data-amount
+        (datasets/sequence_folders.py:40-41: random.shuffle(sequence_set); sequence_set[:int(percentage * len)])."""
         with open(os.path.join(shard_dir, "meta.json")) as f:
             self.meta = json.load(f)
         self.frames = np.load(os.path.join(shard_dir, "frames.u8.npy"), mmap_mode="r")
         self.depth = np.load(os.path.join(shard_dir, "depth.f32.npy"), mmap_mode="r")
         self.samples = self.meta["samples"]
+        if percentage != 1:
+            if not 0 < percentage <= 1:
+                raise ValueError("--data-amount must lie in (0, 1], got %r" % (percentage,))
+            order = list(self.samples)
+            random.Random(seed).shuffle(order)
+            self.samples = order[:int(percentage * len(order))]
+            if not self.samples:
+                raise ValueError("--data-amount %r keeps no sample of %d" % (percentage, len(order)))
         self.intrinsics = np.asarray(self.meta["intrinsics"], dtype=np.float32)
         self.H, self.W = self.meta["H"], self.meta["W"]
         self.scenes = self.meta.get("scenes", [])
@@ -93,9 +105,9 @@ class ShardLoader(object):
     (data.RankSampler)."""
 
     def __init__(self, shards, batch_size, device, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), flip=True, shuffle=True, seed=0,
-                 rank=0, world=1, with_refs=False, drop_last=True, prefetch=2, flip_rng=None):
+                 rank=0, world=1, with_refs=False, drop_last=True, prefetch=2, flip_rng=None, percentage=1):
         from .data import RankSampler
-        self.set = shards if isinstance(shards, ShardSet) else ShardSet(shards)
+        self.set = shards if isinstance(shards, ShardSet) else ShardSet(shards, percentage=percentage, seed=seed)
         self.device = torch.device(device)
         engine.require_cuda(torch.empty(0, device=self.device), "ShardLoader device")
         self.B = batch_size
@@ -106,7 +118,9 @@ class ShardLoader(object):
         self.mean_d = torch.tensor(mean, dtype=torch.float32, device=self.device)
         self.std_d = torch.tensor(std, dtype=torch.float32, device=self.device)
         self.prefetch = max(1, prefetch)
-        self.rng = flip_rng or random
+        self._own_rng = flip_rng is None
+        self._seed, self._rank = int(seed or 0), int(rank)
+        self.rng = flip_rng if flip_rng is not None else random.Random(self._flip_seed(0))
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.nimg = 1 + (len(self.set.samples[0][1]) if with_refs else 0)
         self._ring, self._slot = [], 0           # pinned staging buffers, reused round-robin once their copy has completed
@@ -125,8 +139,13 @@ class ShardLoader(object):
             slot["ev"].synchronize()             # the copy that last read this slot (prefetch + 2 batches ago) is done
         return slot
 
+    def _flip_seed(self, epoch):
+        return (self._seed * 1000003 + self._rank) * 1000003 + int(epoch)
+
     def set_epoch(self, epoch):
         self.sampler.set_epoch(epoch)
+        if self._own_rng:
+            self.rng = random.Random(self._flip_seed(epoch))
 
     def __len__(self):
         return len(self.sampler)

@@ -8,7 +8,9 @@ network on the MI355X HIP path:
 Per image (test_disp.py:184-450): resize to --img-height x --img-width (scipy.misc.imresize semantics), /255 and normalise,
 forward in eval mode, depth = 1/disp, cubic-spline zoom to the ground-truth size clipped to [min_depth, max_depth], mask
 (valid range AND Garg crop), optional median scaling (--unsupervised / --mono) or x5.4 (--stereo), 7 error metrics.
-The PoseNet-scaled evaluation (--pretrained-posenet) and the --pic / --error picture dumps are outside this path.
+--error: the per-pixel abs-rel map and the 300 worst pixels inside the Garg crop (test_disp.py:309-373: compute_abs_rel_per_pixel,
+np.argpartition(..., -300)), annotated input written under output/[stereo|mono/]bad_300pixel/ like the reference.
+The PoseNet-scaled evaluation (--pretrained-posenet) and the --pic comparison plots are outside this path.
 """
 import argparse
 import os
@@ -98,6 +100,8 @@ def evaluate_sample(args, disp_net, sample, device, min_depth, max_depth, KE, U)
     zoomed = zoom(pred_depth, (gt.shape[0] / pred_depth.shape[0], gt.shape[1] / pred_depth.shape[1])).clip(min_depth, max_depth)
     mask = sample["mask"] if args.gt_type == "KITTI" else (gt > min_depth) & (gt < max_depth)
     pz, g = zoomed[mask], gt[mask]
+    if args.error and args.gt_type == "KITTI":
+        worst_pixel_report(args, sample, gt, zoomed, g, pz, min_depth, max_depth, KE)
     if args.unsupervised or args.mono:
         scale = np.median(g) / np.median(pz)
     elif args.stereo:
@@ -105,6 +109,29 @@ def evaluate_sample(args, disp_net, sample, device, min_depth, max_depth, KE, U)
     else:
         scale = 1
     return KE.compute_errors(g, pz * scale), pred_depth
+
+
+def worst_pixel_report(args, sample, gt, zoomed, g, pz, min_depth, max_depth, KE, out_root="output"):
+    """test_disp.py:309-373 (--error): abs-rel per pixel of the zoomed, clipped prediction (x5.4 with --stereo, x median ratio with
+    --mono; the reference leaves the map undefined -- NameError -- without either flag, here the unscaled prediction is used), the 300
+    worst pixels inside the Garg crop, input + annotated input saved as PNGs.  Returns (abs_rel map, graph_index)."""
+    if args.stereo:
+        scale = 5.4
+    elif args.mono:
+        scale = np.median(g) / np.median(pz)
+    else:
+        scale = 1.0
+    m = KE.compute_abs_rel_per_pixel(gt, zoomed * scale, min_depth=min_depth, max_depth=max_depth)
+    graph_index, _ = KE.worst_pixels(m, 300)
+    annotated = KE.annotate_pixels(sample["tgt"], graph_index)
+    sub = "stereo" if args.stereo else ("mono" if args.mono else "")
+    d = os.path.join(out_root, sub, "bad_300pixel")
+    os.makedirs(d, exist_ok=True)
+    j = sample.get("index", 0)
+    from PIL import Image
+    for name, arr in (("input", sample["tgt"]), ("annotate", annotated)):
+        Image.fromarray(np.clip(arr, 0, 255).astype(np.uint8)).save(os.path.join(d, "{}_{}.png".format(j, name)))
+    return m, graph_index
 
 
 @torch.no_grad()
@@ -145,7 +172,10 @@ def main(argv=None):
     errors = np.zeros((7, n), np.float32)
     predictions = None
     for j in range(n):
-        errs, pred_depth = evaluate_sample(args, disp_net, framework[j], device, min_depth, max_depth, KE, U)
+        sample = framework[j]
+        if isinstance(sample, dict):
+            sample.setdefault("index", j)
+        errs, pred_depth = evaluate_sample(args, disp_net, sample, device, min_depth, max_depth, KE, U)
         errors[:, j] = errs
         if args.output_dir is not None:
             if predictions is None:

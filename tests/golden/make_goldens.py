@@ -697,6 +697,69 @@ def gold_zoo(ref_loss):
     save("zoo", **arrays)
 
 
+def _reference_slice(rel, first, last, must_contain):
+    """Source lines first..last (1-based, inclusive) of a reference file, dedented, for exec: the worst-pixel selection lives INLINE
+    in test_disp.py's main() (it is not a function that could be imported), so the generator runs the reference's own statements on
+    its inputs.  Nothing of it is stored: only the resulting numbers."""
+    import textwrap
+    lines = (REF / rel).read_text().splitlines()[first - 1:last]
+    text = textwrap.dedent("\n".join(lines))
+    for m in must_contain:
+        assert m in text, "reference %s:%d-%d no longer holds %r" % (rel, first, last, m)
+    return text
+
+
+def abs_rel_inputs(shape, variant=0):
+    """gt: the synthetic KITTI depth map of gold_kitti (sparse, from the reference's own generate_depth_map, passed in); pred: a smooth
+    closed-form depth map both sides can evaluate (two variants)."""
+    h, w = shape
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    if variant == 0:
+        return 4.0 + 60.0 * (1.0 - yy / h) ** 2 + 3.0 * np.sin(xx * 0.05) + 2.0 * np.cos(yy * 0.11 + xx * 0.013)
+    return 25.0 + 20.0 * np.sin(yy * 0.031 + 0.4) * np.cos(xx * 0.0071) + 0.01 * xx
+
+
+def gold_worst_pixels(ref_kitti):
+    """test_disp.py:471-477 (compute_abs_rel_per_pixel) and :318-338 (crop, np.where, argpartition(-300)) executed from the
+    reference's source on the synthetic scene's ground truth."""
+    ns = {"np": np}
+    exec(_reference_slice("test_disp.py", 471, 477, ["def compute_abs_rel_per_pixel", "abs_rel[valid_complement] = -1"]), ns)
+    block = _reference_slice("test_disp.py", 318, 338, ["valid = current_abs_rel_per_pixel>0", "np.argpartition(index_result[:,2], -300)[-300:]",
+                                                        "graph_index = index_result[max_100_error_index,:2].astype(np.int32)"])
+    tint = _reference_slice("test_disp.py", 345, 350, ["annotate_input = np.copy(sample['tgt'])", "255.0/2.0"])
+    p_rect, r_rect, r, t, velo = synthetic_kitti_scene()
+    arrays = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = pathlib.Path(tmp)
+        fmt = lambda a: " ".join("%.6e" % v for v in a)
+        (tmp / "calib_cam_to_cam.txt").write_text(
+            "calib_time: 09-Jan-2012 13:57:47\nR_rect_00: %s\nP_rect_02: %s\n" % (fmt(r_rect), fmt(p_rect)))
+        (tmp / "calib_velo_to_cam.txt").write_text(
+            "calib_time: 15-Mar-2012 11:37:16\nR: %s\nT: %s\n" % (fmt(r), fmt(t)))
+        velo.tofile(str(tmp / "scan.bin"))
+        for variant in (0, 1):
+            shape = (375, 1242)
+            gt = ref_kitti.generate_depth_map(tmp, tmp / "scan.bin", shape, cam=2)
+            pred = abs_rel_inputs(shape, variant)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                m = ns["compute_abs_rel_per_pixel"](gt, pred, min_depth=1e-3, max_depth=80)
+            tgt = (np.arange(shape[0] * shape[1] * 3, dtype=np.int64) * 7919 % 256).reshape(shape + (3,)).astype(np.float32)
+            loc = {"np": np, "current_abs_rel_per_pixel": m, "sample": {"tgt": tgt}}
+            exec(block, loc)
+            exec(tint, loc)
+            tag = "%dx%d:v%d" % (shape + (variant,))
+            yy, xx = np.nonzero(m > 0)
+            arrays["abs_rel:%s:yx" % tag] = np.stack([yy, xx], 1).astype(np.int32)
+            arrays["abs_rel:%s:val" % tag] = m[yy, xx]
+            arrays["abs_rel:%s:neg_count" % tag] = np.int64((m == -1).sum())
+            arrays["worst:%s:graph_index" % tag] = loc["graph_index"]                 # numpy's own output order
+            arrays["worst:%s:n_valid" % tag] = np.int64(loc["index_result"].shape[0])
+            arrays["annotate:%s:sum" % tag] = loc["annotate_input"].astype(np.float64).sum(axis=(0, 1))
+            ys, xs = loc["graph_index"][:8, 0], loc["graph_index"][:8, 1]
+            arrays["annotate:%s:patch" % tag] = np.stack([loc["annotate_input"][y:y + 5, x:x + 5] for y, x in zip(ys, xs)])
+    save("worst_pixels", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -731,6 +794,7 @@ def main():
         "config3": lambda: gold_config3(ref_vgg, ref_pose, ref_loss, ref_warp),
         "dorn80": lambda: gold_dorn80(ref_dorn, ref_utils, ref_loss),
         "zoo": lambda: gold_zoo(ref_loss),
+        "worst": lambda: gold_worst_pixels(ref_kitti),
     }
     for name, fn in sections.items():
         if not want or name in want:

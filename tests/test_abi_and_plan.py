@@ -30,8 +30,26 @@ def test_every_declared_symbol_is_exported(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), "libdispnet_hip.so does not export %s" % name
         assert name in _lib.SIGNATURES, "ctypes binding missing for %s" % name
-    assert lib.dn_version() >= 1
+    assert lib.dn_version() == _lib.EXPECTED_ABI
     assert isinstance(lib.dn_last_error(), bytes)
+
+
+def test_integration_md_stub_matches_the_binding():
+    """The reference-side ctypes stub printed in INTEGRATION.md section 1(b) must declare the argument lists the header has
+    (round 2 shipped a 9-argument dn_masked_loss_fwd there against the header's 13)."""
+    import ctypes as C  # noqa: F401 -- evaluated below
+    from supervised_dispnet_amd import _lib
+    text = (ROOT / "INTEGRATION.md").read_text()
+    found = re.findall(r"lib\.(dn_[a-z0-9_]+)\.argtypes\s*=\s*(\[[^\]]*\])", text)
+    assert found, "no argtypes lines in INTEGRATION.md"
+    for name, lst in found:
+        got = eval(lst, {"C": C})
+        want = list(_lib.SIGNATURES[name][1])
+        assert got == want, "%s: INTEGRATION.md declares %d arguments, the binding %d" % (name, len(got), len(want))
+    m = re.search(r"lib\.dn_version\(\) == (\d+)", text)
+    assert m and int(m.group(1)) == _lib.EXPECTED_ABI
+    call = re.search(r"lib\.dn_masked_loss_fwd\((.*?)\),\s*\n\s*\"dn_masked_loss_fwd\"", text, re.S)
+    assert call and call.group(1).count(",") + 1 == len(_lib.SIGNATURES["dn_masked_loss_fwd"][1])
 
 
 def test_struct_layout_matches_header(lib):

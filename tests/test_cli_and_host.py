@@ -122,6 +122,54 @@ def test_kitti_ground_truth_matches_reference_golden(golden, tmp_path):
     assert tuple(KE.garg_crop(128, 416)) == (52, 126, 14, 401)
 
 
+def test_abs_rel_per_pixel_and_worst_300_match_reference_golden(golden, tmp_path):
+    """test_disp.py:471-477 + :318-350 (--error): the per-pixel abs-rel map, the np.where / argpartition(-300) selection and the
+    annotation, against vectors produced by executing the reference's own statements (tests/golden/make_goldens.py::gold_worst_pixels)
+    and against the oracle's sort-based restatement.  Index work: exact."""
+    import importlib.util
+    import pathlib
+    from oracle import kitti_gt as OK
+    from supervised_dispnet_amd import kitti_eval as KE
+    g = golden("worst_pixels")
+    spec = importlib.util.spec_from_file_location("mk", pathlib.Path(__file__).parent / "golden" / "make_goldens.py")
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    p_rect, r_rect, r, t, velo = mk.synthetic_kitti_scene()
+    fmt = lambda a: " ".join("%.6e" % v for v in a)
+    (tmp_path / "calib_cam_to_cam.txt").write_text("calib_time: 09-Jan-2012 13:57:47\nR_rect_00: %s\nP_rect_02: %s\n" % (fmt(r_rect), fmt(p_rect)))
+    (tmp_path / "calib_velo_to_cam.txt").write_text("calib_time: 15-Mar-2012 11:37:16\nR: %s\nT: %s\n" % (fmt(r), fmt(t)))
+    velo.astype(np.float32).tofile(tmp_path / "0000000000.bin")
+    shape = (375, 1242)
+    gt = KE.generate_depth_map(str(tmp_path), str(tmp_path / "0000000000.bin"), shape, cam=2)
+    for variant in (0, 1):
+        tag = "%dx%d:v%d" % (shape + (variant,))
+        pred = mk.abs_rel_inputs(shape, variant)
+        m = KE.compute_abs_rel_per_pixel(gt, pred, 1e-3, 80)
+        om = OK.compute_abs_rel_per_pixel(gt, pred, 1e-3, 80)
+        np.testing.assert_array_equal(m, om)
+        yy, xx = np.nonzero(m > 0)
+        np.testing.assert_array_equal(np.stack([yy, xx], 1).astype(np.int32), g["abs_rel:%s:yx" % tag])
+        np.testing.assert_array_equal(m[yy, xx], g["abs_rel:%s:val" % tag])                     # bit-exact float64
+        assert int((m == -1).sum()) == int(g["abs_rel:%s:neg_count" % tag])
+        gi, index_result = KE.worst_pixels(m, 300)
+        assert gi.dtype == np.int32 and gi.shape == (300, 2)
+        assert index_result.shape[0] == int(g["worst:%s:n_valid" % tag])
+        np.testing.assert_array_equal(gi, g["worst:%s:graph_index" % tag])                      # same numpy routine, same order
+        want_set, v300, v301 = OK.worst_pixels_loop(om, 300)
+        assert v300 > v301, "the synthetic case must not tie at the selection boundary"
+        assert sorted(map(tuple, gi.tolist())) == want_set                                       # order-free check vs the sort-based oracle
+        tgt = (np.arange(shape[0] * shape[1] * 3, dtype=np.int64) * 7919 % 256).reshape(shape + (3,)).astype(np.float32)
+        ann = KE.annotate_pixels(tgt, gi)
+        np.testing.assert_array_equal(ann.astype(np.float64).sum(axis=(0, 1)), g["annotate:%s:sum" % tag])
+        got = np.stack([ann[y:y + 5, x:x + 5] for y, x in zip(gi[:8, 0], gi[:8, 1])])
+        np.testing.assert_array_equal(got, g["annotate:%s:patch" % tag])
+    # the threshold branch (test_disp.py:339-342) and the too-few-pixels error
+    gi03, _ = KE.worst_pixels(m, threshold=0.3)
+    assert gi03.shape[0] == int((m[153:371, 44:1197] > 0.3).sum())
+    with pytest.raises(ValueError):
+        KE.worst_pixels(np.full((20, 30), -1.0), 300)
+
+
 def test_scene_folder_readers_and_rank_sampler(tmp_path):
     from PIL import Image
     from supervised_dispnet_amd import data as D

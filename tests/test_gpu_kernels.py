@@ -50,7 +50,7 @@ def rnd(*shape, lo=-1.0, hi=1.0, seed=0):
 
 def test_library_loads_on_gfx950():
     lib = _lib.load()
-    assert lib.dn_version() >= 1
+    assert lib.dn_version() == _lib.EXPECTED_ABI
     assert lib.dn_device_arch_ok() == 1, "the HIP kernels are built for gfx950 only"
 
 

@@ -234,8 +234,11 @@ def main(argv=None):
             raise ValueError("only the sequential folder format is supported on this path")
         mean, std = D.normalization(args.imagenet_normalization, args.monodepth2)
         print("=> fetching scenes in '{}'".format(args.data))
-        train_set = D.SequenceFolder(args.data, transform=D.Transform(mean, std, flip=True), seed=args.seed, train=True,
-                                     sequence_length=args.sequence_length, percentage=args.data_amount, with_refs=with_refs)
+        if args.shards:
+            train_set = None                         # --shards replaces the JPEG train set: do not crawl the scene folders for it
+        else:
+            train_set = D.SequenceFolder(args.data, transform=D.Transform(mean, std, flip=True), seed=args.seed, train=True,
+                                         sequence_length=args.sequence_length, percentage=args.data_amount, with_refs=with_refs)
         if args.with_gt:
             val_set = D.ValidationSet(args.data, transform=D.Transform(mean, std, flip=False))
         else:
@@ -243,21 +246,25 @@ def main(argv=None):
                                        sequence_length=args.sequence_length, with_refs=True)
     else:
         raise ValueError("dataset '{}' needs the reference's NYU h5 loader, which is outside this path; use --synthetic".format(args.dataset))
-    if rank == 0:
-        print("{} samples found in {} train scenes".format(len(train_set), len(train_set.scenes)))
-        print("{} samples found in {} valid scenes".format(len(val_set), len(val_set.scenes)))
     per_rank = args.batch_size // world
-    train_sampler = D.RankSampler(len(train_set), args.batch_size, rank, world, shuffle=True, seed=args.seed)
-    val_sampler = D.RankSampler(len(val_set), args.batch_size, rank, world, shuffle=False, drop_last=False)
     workers = min(per_rank, os.cpu_count() or 1)     # the reference uses num_workers = batch_size and ignores -j (train.py:201-206)
-    train_loader = torch.utils.data.DataLoader(train_set, batch_sampler=train_sampler, num_workers=workers, pin_memory=True)
-    val_loader = torch.utils.data.DataLoader(val_set, batch_sampler=val_sampler, num_workers=workers, pin_memory=True)
     if args.shards:
         from supervised_dispnet_amd.shards import ShardLoader
         mean, std = D.normalization(args.imagenet_normalization, args.monodepth2)
         train_loader = ShardLoader(args.shards, per_rank, device, mean=mean, std=std, flip=True, shuffle=True, seed=args.seed, rank=rank,
-                                   world=world, with_refs=with_refs)
-        train_sampler = train_loader                 # set_epoch() reshuffles
+                                   world=world, with_refs=with_refs, percentage=args.data_amount)
+        train_sampler = train_loader                 # set_epoch() reshuffles (and re-seeds the flip draws)
+        if rank == 0:
+            print("{} samples found in {} train scenes (shards)".format(len(train_loader.set), len(train_loader.set.scenes)))
+    else:
+        if rank == 0:
+            print("{} samples found in {} train scenes".format(len(train_set), len(train_set.scenes)))
+        train_sampler = D.RankSampler(len(train_set), args.batch_size, rank, world, shuffle=True, seed=args.seed)
+        train_loader = torch.utils.data.DataLoader(train_set, batch_sampler=train_sampler, num_workers=workers, pin_memory=True)
+    if rank == 0:
+        print("{} samples found in {} valid scenes".format(len(val_set), len(val_set.scenes)))
+    val_sampler = D.RankSampler(len(val_set), args.batch_size, rank, world, shuffle=False, drop_last=False)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_sampler=val_sampler, num_workers=workers, pin_memory=True)
     if args.epoch_size == 0:
         args.epoch_size = len(train_loader)
 
