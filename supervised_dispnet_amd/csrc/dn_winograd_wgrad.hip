@@ -75,6 +75,12 @@ static int wg_ktot(const IgemmParams& p) {
 }
 
 // pixel (tile) splits: whole rounds of 256 resident blocks, at least 16 chunks per split
+// Three-piece kernel on the longest reductions (>= 2^18 tiles = 1 M pixels: the 64 -> 64 layer of a 32 x 128 x 416 batch): start at THREE
+// rounds.  v_mfma_f32_32x32x16_bf16 rounds its running fp32 sum more often per 8-tile chunk (three instructions, six partial products per
+// tile) than the fp32 instruction does (8 FMAs); over 208 chunks per split the accumulated rounding measured 2.1x the fp32-instruction
+// kernel's against fp64 (2.0e-6 vs 9.6e-7 relative L2; PyTorch-CPU fp32: 2.2e-6).  A third of the chain (the slab sum that follows is a
+// short fixed-order tree) brings it to 1.3x for +0.07 ms on that one layer (tests/test_gpu_f32x3_fp64.py, profiles/r03_wg_rounds.txt).
+// A mid-split flush of the accumulators inside one block (same arithmetic, no extra blocks) was measured 26 % SLOWER: dropped.
 static void wg_choose_splits(const IgemmParams& p, int* splits, int* tiles_per_split) {
   const int T = p.M / 4, chunks = (T + GTC - 1) / GTC;
   const int tb = (p.Ntot / 64) * (wg_ktot(p) / 64);
@@ -82,7 +88,8 @@ static void wg_choose_splits(const IgemmParams& p, int* splits, int* tiles_per_s
   if (max_by_work < 1) max_by_work = 1;
   int best = 1;
   double best_util = 0.0;
-  for (int R = 1; R <= 4; ++R) {
+  const int r0 = (p.compute == DN_COMPUTE_F32X3 && T >= (1 << 18)) ? 3 : 1;
+  for (int R = r0; R <= 4; ++R) {
     int sp = (R * 256) / tb;
     if (sp < 1) continue;
     if (sp > max_by_work) sp = max_by_work;

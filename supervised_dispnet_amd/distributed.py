@@ -11,6 +11,17 @@ reference's DataParallel (no SyncBN).  Device-agnostic on purpose: the same code
 import torch
 import torch.distributed as dist
 
+# Optional record of every collective this module issues, in issue order: ("bucket", lo, hi) for a gradient bucket, ("stats", rows,
+# cols, "sum" | "max") for a loss-statistics exchange.  The gradient buckets and the whole-batch loss statistics may travel on two
+# different communicators (the own RCCL one and torch.distributed's); that is only safe when every rank issues them in the same order,
+# which tests/test_distributed_cpu.py checks by comparing the ranks' logs.  None = off.
+ISSUE_LOG = None
+
+
+def _log(*what):
+    if ISSUE_LOG is not None:
+        ISSUE_LOG.append(tuple(what))
+
 
 def agree_all_ranks(ok, process_group=None, device=None):
     """True iff `ok` is true on EVERY rank (MIN all-reduce of a flag over torch.distributed); with one rank: bool(ok).  Used to take
@@ -114,6 +125,7 @@ class GradReducer(object):
 
     def _launch(self, bi):
         b = self.buckets[bi]
+        _log("bucket", b["lo"], b["hi"])
         if self.comm is not None:
             from . import engine                 # gradients of one bucket come from two HIP streams (engine.WGRAD_STREAM)
             self.comm.all_reduce_sum_(self.arena.flat_g[b["lo"]:b["hi"]], engine.compute_streams())
@@ -175,11 +187,13 @@ def exchange_loss_stats(stats, sum_cols, max_cols=(), process_group=None):
     if sum_cols:
         idx = list(sum_cols)
         part = stats[:, idx].contiguous()
+        _log("stats", part.shape[0], part.shape[1], "sum")
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=process_group)
         stats[:, idx] = part
     if max_cols:
         idx = list(max_cols)
         part = stats[:, idx].contiguous()
+        _log("stats", part.shape[0], part.shape[1], "max")
         dist.all_reduce(part, op=dist.ReduceOp.MAX, group=process_group)
         stats[:, idx] = part
     return stats

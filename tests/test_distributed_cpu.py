@@ -236,3 +236,91 @@ def test_bench_dry_run_two_ranks_constructs_buckets_and_tears_down():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["ok"] and d["world"] == 2 and d["buckets"] >= 3 and d["shard"] == [0, 16] and d["arena_params"] == 80
+
+
+def _worker_two_communicators(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from supervised_dispnet_amd import distributed as DD
+        from supervised_dispnet_amd.optim import ParamArena
+        # The gradient buckets travel on ONE communicator (here: a second process group standing in for the library's own RCCL
+        # communicator), the whole-batch loss statistics on ANOTHER (the default group), interleaved every step: forward statistics,
+        # then the backward's buckets as their gradients land.  Safe only if every rank issues them in the same order -- the ranks
+        # run at different speeds on purpose.
+        grads_group = dist.new_group(ranks=list(range(world)), backend="gloo")
+        arena = ParamArena(_make_params(), production_order=None)
+        red = DD.GradReducer(arena, bucket_bytes=1 << 10, process_group=grads_group, comm="torch")
+        DD.ISSUE_LOG = []
+        for step in range(3):
+            time.sleep(0.05 * rank * (step + 1))                       # rank skew
+            st = torch.full((4, 8), float(rank + 1 + step))
+            DD.exchange_loss_stats(st, sum_cols=(0, 1, 2), max_cols=(3,))             # "forward": default group
+            assert torch.all(st[:, 0] == sum(r + 1 + step for r in range(world))) and torch.all(st[:, 3] == world + step)
+            for i, p in enumerate(arena.params):                       # "backward": buckets launch as gradients land
+                p._dn_grad_view.fill_(float((rank + 1) * (i + 1)))
+                if (i + rank) % 3 == 0:
+                    time.sleep(0.01)
+                red.grad_ready(p)
+            red.finish()
+            for i, p in enumerate(arena.params):
+                assert torch.all(p._dn_grad_view == sum((r + 1) * (i + 1) for r in range(world)))
+        logs = [None] * world
+        dist.all_gather_object(logs, DD.ISSUE_LOG)
+        assert all(l == logs[0] for l in logs), "ranks issued their collectives in different orders"
+        kinds = [e[0] for e in logs[0]]
+        per_step = len(kinds) // 3
+        assert kinds[:2] == ["stats", "stats"] and set(kinds[2:per_step]) == {"bucket"} and per_step >= 5
+        out.put((rank, "ok"))
+    except Exception as e:
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_interleaved_communicators_keep_one_issue_order_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_communicators, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _worker_comm_agreement(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from supervised_dispnet_amd import distributed as DD
+        # a decision every rank must take together: one dissenting rank turns it down for all
+        assert DD.agree_all_ranks(True) is True
+        assert DD.agree_all_ranks(rank != 1) is False
+        # CPU arenas never take the own-RCCL path; the reducer names the path that runs
+        from supervised_dispnet_amd.optim import ParamArena
+        red = DD.GradReducer(ParamArena(_make_params()))
+        assert red.comm is None and red.path == "torch.distributed:gloo" and red.world == world
+        out.put((rank, "ok"))
+    except Exception as e:
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_choice_is_collective_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_comm_agreement, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
