@@ -13,7 +13,7 @@ import sys
 HERE = pathlib.Path(__file__).resolve().parent
 PKG = HERE.parent
 ROOT = PKG.parent
-SOURCES = ["dn_plan.hip", "dn_conv.hip", "dn_pointwise.hip", "dn_loss.hip", "dn_warp.hip", "dn_ordinal.hip", "dn_ordhead.hip", "dn_direct.hip", "dn_winograd.hip", "dn_winograd_wgrad.hip", "dn_thin.hip", "dn_input.hip", "dn_ubench.hip"]
+SOURCES = ["dn_plan.hip", "dn_conv.hip", "dn_pointwise.hip", "dn_loss.hip", "dn_warp.hip", "dn_ordinal.hip", "dn_ordhead.hip", "dn_direct.hip", "dn_winograd.hip", "dn_winograd8.hip", "dn_winograd_wgrad.hip", "dn_thin.hip", "dn_input.hip", "dn_ubench.hip"]
 OUT = PKG / "libdispnet_hip.so"
 ARCH = "gfx950"
 
@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     obj_dir.mkdir(exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", str(ROOT / "include"), "-I", str(HERE),
              "-Wall", "-Wno-unused-function"]
-    deps = [HERE / "dn_internal.h", ROOT / "include" / "dispnet_hip.h", pathlib.Path(__file__)]
+    deps = [HERE / "dn_internal.h", HERE / "dn_wino_common.h", ROOT / "include" / "dispnet_hip.h", pathlib.Path(__file__)]
     newest_dep = max(p.stat().st_mtime for p in deps)
     objs, procs = [], []
     for src in SOURCES:

@@ -32,35 +32,9 @@
 #include <utility>
 
 #include "dn_internal.h"
+#include "dn_wino_common.h"
 
 namespace dn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <class F, int... I>
-__device__ __forceinline__ void wino_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  wino_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-constexpr int WBT = 64;            // tiles per block
-constexpr int WBN = 64;            // output channels per block
-constexpr int WKC = 16;            // channels per staged chunk (two 8-k MFMA groups)
-constexpr int WZLD = 72;           // padded row (floats) of the cross-wave exchange tile: rows 4 apart land 32 banks apart
-
-__device__ __forceinline__ float wino_act(float v, int act, float p0, float p1) {
-  switch (act) {
-    case DN_ACT_RELU: return v > 0.f ? v : 0.f;
-    case DN_ACT_LEAKY: return v > 0.f ? v : v * p0;
-    case DN_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.f);
-    case DN_ACT_SIGMOID_AFFINE: return p0 / (1.f + expf(-v)) + p1;
-    default: return v;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------ eligibility
 bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
@@ -328,19 +302,6 @@ int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_
 //   MTW = 2 : 64 tiles per block, 256 accumulator registers, one block per CU (least L2 traffic per MFMA),
 //   MTW = 1 : 32 tiles per block, 128 accumulator registers, two blocks per CU (a partner wave covers the stalls and one
 //             block's epilogue runs under the other's main loop).
-template <int MTW>
-struct WinoCfg {
-  static constexpr int BT = 32 * MTW;                 // tiles per block
-  static constexpr int HALFB = BT * 16 + 32;          // bytes of one [tile][4 k] plane (+8 banks)
-  static constexpr int POSB = 2 * HALFB;              // one position: k 0-3 plane, k 4-7 plane
-  static constexpr int SUBB = 16 * POSB + 64;         // one 8-k group: 16 positions (+16 banks)
-  static constexpr int BUFB = 2 * SUBB;               // one 16-channel chunk
-  static constexpr size_t LDS = (size_t)2 * BUFB;     // double-buffered ring
-};
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // bf16-multiply / fp32-accumulate variant (descriptor compute = DN_COMPUTE_BF16, BF = true below): the transformed input tiles are
 // rounded to bf16 on their way into LDS ([position][tile][16 k], 48-byte tile rows: the 16-byte fragment reads of a 16-lane group
 // and the dword staging stores land on distinct banks), the transformed weights are packed as bf16 in fragment order, and one
@@ -354,24 +315,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // LDS nor 48 registers of pending pieces); the weights are packed as three pieces; SIX matrix instructions per (position, 32 couts):
 // x0y2, x2y0, x1y1, x1y0, x0y1, x0y0 -- 48 per chunk = 1536 cycles against the 4096 of the fp32 instruction, and unlike that one they
 // leave the vector ALUs to the wave: ~6 vector instructions issue under each of them (tools/ubench/agpr_issue.hip).
-constexpr int W16_ROWB = 48;                          // bytes of one tile's 16 bf16 (+16 padding)
-template <int VW> struct VecOf;
-template <> struct VecOf<4> { typedef f32x4 type; };
-template <> struct VecOf<2> { typedef f32x2 type; };
-
-template <int VW>
-__device__ __forceinline__ typename VecOf<VW>::type buffer_load_vec(__amdgpu_buffer_rsrc_t r, int voffset) {
-  if constexpr (VW == 4) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, 0, 0);
-    return __builtin_bit_cast(f32x4, v);
-  } else {
-    typedef int i32x2 __attribute__((ext_vector_type(2)));
-    const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voffset, 0, 0);
-    return __builtin_bit_cast(f32x2, v);
-  }
-}
-
 template <int MTW, bool HA, int DBG, int PREC = 0>     // PREC 0: fp32 matrix instruction, 1: bf16 operands, 3: three bf16 pieces per operand
 __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const IgemmParams p) {
   constexpr bool BF = PREC != 0;
@@ -1048,6 +991,7 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variants may be used)
     return p.any_affine ? launch_wino_variant<1, true, 0, 1>(p, stream) : launch_wino_variant<1, false, 0, 1>(p, stream);
   if (p.compute == DN_COMPUTE_F32X3) {
+    if ((knobs().wino_dbg == 0 || (knobs().wino_dbg & 4)) && mtw == 1 && wino8_wanted(p)) return launch_wino_conv8(p, stream);
     // (the 64-tile / one-block-per-CU form of this variant -- the loop below is written for either tile height -- moves 37 % fewer bytes
     //  through the texture addresser, the weight pieces being fetched once per 64 tiles, and was measured 5-10 % SLOWER on every layer
     //  but one: a single wave per SIMD stalls on every wait; DN_WINO_MTW=3 selects it for such measurements)
