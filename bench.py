@@ -54,6 +54,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 matrix peak (the p
 X3_PRODUCTS = 6                      # f32x3: six bf16 partial products per fp32 multiply
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E spec (6.29 TB/s measured float4 copy there)
+THIN_KERNELS = ("stem_conv_kernel", "thin_conv_kernel", "thin_wgrad_kernel", "head_fwd", "head_dgrad", "head_wgrad", "igemm_conv_u32_kernel<128, 32, 32, 32>",
+                "igemm_wgrad_kernel<32, 32, 32, true>", "igemm_wgrad_u32_kernel<32, 32, 32, false>")
 WINO_EXEC = 16.0 / 36.0              # F(2x2,3x3): 16 element-wise products per 2x2 tile instead of 36 MACs
 
 # name -> (metric text, network, H, W, default batch per GPU, dataset tag, BASELINE.md section 2 train GFLOP/img or None)
@@ -421,15 +423,18 @@ def main():
         nps = args.profile_steps
         if args.per_layer:
             seen = {}
-            for name, flops, e0, e1, tag, nbytes in prof:
+            for name, flops, e0, e1, tag, nbytes, _ab in prof:
                 r = seen.setdefault((name, tag), [0.0, 0.0, 0, 0])
                 r[0] += flops; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += 1; r[3] += nbytes
             print("%-46s %-58s %9s %9s %8s %8s" % ("kernel", "layer / entry", "ms/launch", "GFLOP", "TFLOP/s", "GB/s"), file=sys.stderr)
             for (name, tag), (fl, sec, n, nb) in seen.items():
                 print("%-46s %-58s %9.3f %9.2f %8.1f %8.0f" % (name, tag, sec / n * 1e3, fl / n / 1e9, fl / sec / 1e12, nb / sec / 1e9), file=sys.stderr)
-        mf, hb = {}, {}
-        for name, flops, e0, e1, _tag, nbytes in prof:
+        mf, hb, thin = {}, {}, {}
+        for name, flops, e0, e1, _tag, nbytes, abytes in prof:
             sec = e0.elapsed_time(e1) * 1e-3
+            if any(t in name for t in THIN_KERNELS):      # the full-resolution thin layers: both rooflines, per kernel
+                a = thin.setdefault(name, [0.0, 0.0, 0, 0])
+                a[0] += flops; a[1] += sec; a[2] += 1; a[3] += abytes
             if nbytes:
                 a = hb.setdefault(name, [0, 0.0, 0])
                 a[0] += nbytes; a[1] += sec; a[2] += 1
@@ -478,7 +483,18 @@ def main():
                             "measured_peak": peaks["copy_GBps"], "launches_per_step": n // nps, "avg_launch_ms": sec / n * 1e3,
                             "avg_launch_algorithmic_bytes": nb / n,
                             "by_kernel": {k: {"GBps": v[0] / v[1] / 1e9, "ms_per_step": v[1] / nps * 1e3, "launches_per_step": v[2] // nps}
-                                          for k, v in sorted(hb.items())}}
+                                          for k, v in sorted(hb.items())},
+                            # the thin full-resolution convolutions (3 / 16 / 17 / 32 channels at 128x416 and 64x208, one-channel heads):
+                            # algorithmic bytes AND multiply-accumulates of each against BOTH ceilings -- at 16 channels x 9 taps their
+                            # arithmetic intensity (~38 flop/B) is above the fp32 matrix instruction's balance point (157.3 TFLOP/s /
+                            # 8 TB/s = 20 flop/B), so that instruction, not HBM, is what bounds them on this path
+                            "thin_layers": {k: {"GBps": v[3] / v[1] / 1e9, "frac_of_hbm_peak": v[3] / v[1] / 1e9 / PEAK_HBM_GBPS,
+                                                "tflops": v[0] / v[1] / 1e12, "frac_of_fp32_mfma_peak": v[0] / v[1] / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                                "ms_per_step": v[1] / nps * 1e3, "launches_per_step": v[2] // nps,
+                                                "hbm_bound_ms_per_step": v[3] / nps / (PEAK_HBM_GBPS * 1e9) * 1e3,
+                                                "mfma_bound_ms_per_step": v[0] / nps / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3,
+                                                "frac_of_binding_roofline": max(v[3] / (PEAK_HBM_GBPS * 1e9), v[0] / (PEAK_FP32_MFMA_TFLOPS * 1e12)) / v[1]}
+                                            for k, v in sorted(thin.items())}}
 
     if world > 1:
         dist.barrier()

@@ -296,6 +296,10 @@ bool thin_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (knobs().no_thin || knobs().no_thin_conv) return false;
   // measured: with 32 output channels / 256-long contractions the tiled kernel wins (0.096 vs 0.132 ms, 0.094 vs 0.164); the
   // 16-channel layers are where padding to a 32-wide tile hurts (0.31 -> 0.15 ms, 0.23 -> 0.16)
+  // (measured in round 3: the input gradient of iconv0 -- 16 -> 16 + 1 channels, i.e. 17 columns of a 32-wide tile and two results --
+  //  takes 0.321 ms here against 0.268 ms on the tiled kernel: at 16 channels x 9 taps these layers are bound by the fp32 matrix
+  //  instruction (8.3 GFLOP = 53 us at its 157 TFLOP/s peak) rather than by their 220 MB of HBM traffic (27 us), and a second column
+  //  tile doubles the matrix work; it stays on the tiled kernel)
   if (p.reflect || p.bn_partial != nullptr || p.Ntot > 16) return false;
   for (int z = 0; z < p.nphases; ++z)
     if (p.ph[z].ntaps > 16 || p.ph[z].ntaps < 1) return false;

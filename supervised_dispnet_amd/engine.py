@@ -144,8 +144,8 @@ def _pick_bn(ntot):
 class _Timed(object):
     """Context manager bracketing one C-ABI launch with HIP events when PROFILE is on."""
 
-    def __init__(self, name, flops, tag=""):
-        self.name, self.flops, self.tag = name, flops, tag
+    def __init__(self, name, flops, tag="", abytes=0):
+        self.name, self.flops, self.tag, self.abytes = name, flops, tag, abytes      # abytes: operands read once + results written once
 
     def __enter__(self):
         if PROFILE is not None:
@@ -158,7 +158,7 @@ class _Timed(object):
         if PROFILE is not None:
             self.e1.record()
             launched = _lib.load().dn_last_kernel().decode(errors="replace")     # what the library actually ran (rocprofv3 name)
-            PROFILE.append((launched or self.name, self.flops, self.e0, self.e1, self.tag, 0))
+            PROFILE.append((launched or self.name, self.flops, self.e0, self.e1, self.tag, 0, int(self.abytes)))
         return False
 
 
@@ -173,7 +173,7 @@ def hbm_call(kernel, nbytes, entry, *args):
     e0.record()
     _lib.call(entry, *args)
     e1.record()
-    PROFILE.append((kernel, 0, e0, e1, entry, int(nbytes)))
+    PROFILE.append((kernel, 0, e0, e1, entry, int(nbytes), int(nbytes)))
 
 
 def bump_param_epoch():
@@ -513,7 +513,8 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
         d.bn_partial = partial.data_ptr()
     with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cout), 2 * layer.macs(N, IH, IW, OH, OW),
                 "%s %dx%d k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_fwd" if layer.transposed else "conv_fwd", layer.R, layer.S,
-                                                               layer.R, layer.stride, layer.Cin, layer.Cout, N, IH, IW)):
+                                                               layer.R, layer.stride, layer.Cin, layer.Cout, N, IH, IW),
+                4 * (sum(p.act.rows * p.act.C for p in pieces) + y.numel())):
         _lib.call("dn_convT2d_fwd" if layer.transposed else "dn_conv2d_fwd", C.byref(d), _stream())
     return y, partial, rows
 
@@ -544,7 +545,8 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None):
         with _Timed("igemm_wgrad_kernel<%d>" % _pick_bn(layer.Cin if layer.transposed else layer.Cout),
                     2 * layer.macs(a0.N, IH, IW, OH, OW),
                     "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_wgrad" if layer.transposed else "conv_wgrad", layer.R, layer.stride,
-                                                             layer.Cin, layer.Cout, a0.N, IH, IW)):
+                                                             layer.Cin, layer.Cout, a0.N, IH, IW),
+                    4 * (sum(p.act.rows * p.act.C for p in pieces) + dy.numel())):
             _lib.call("dn_conv2d_wgrad", C.byref(d), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, _stream())
         if sink is not None:
             sink.put(layer.m.weight, dw)
@@ -612,7 +614,8 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
     d.act = ACT_NONE
     with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cin), 2 * layer.macs(N, IH, IW, OH, OW),
                 "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_dgrad" if layer.transposed else "conv_dgrad", layer.R, layer.stride,
-                                                         layer.Cin, layer.Cout, N, IH, IW)):
+                                                         layer.Cin, layer.Cout, N, IH, IW),
+                4 * (dy.numel() + sum(p.act.rows * p.act.C for p in targets))):
         _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
     for p, tmp in post:
         a = p.act

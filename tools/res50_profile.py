@@ -26,7 +26,7 @@ engine.PROFILE = []
 step()
 torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
-for name, flops, e0, e1, tag, _nbytes in engine.PROFILE:
+for name, flops, e0, e1, tag, _nbytes, _ab in engine.PROFILE:
     a = agg[name]; a[0] += flops; a[1] += e0.elapsed_time(e1); a[2] += 1
 tot = sum(v[1] for v in agg.values())
 print("conv-family total %.2f ms" % tot)
