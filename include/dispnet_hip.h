@@ -123,6 +123,9 @@ typedef struct dn_conv_desc {
                                         (x0y0, x0y1, x1y0, x0y2, x1y1, x2y0) are accumulated in fp32; what is dropped is below
                                         2^-24 of |x||y|, the rounding an fp32 FMA chain commits itself (measured against fp64: the
                                         same error as DN_COMPUTE_F32 or less, tools/ubench/bf16x3.hip, tests/test_gpu_kernels.py). */
+  int32_t dilation;                /* 0 / 1: none.  d > 1: nn.Conv2d(dilation = d) -- kernel tap (r, s) reads input offset
+                                      (r*d - pad, s*d - pad) (models/ASPP.py:62-72,107-113: the dilated bottlenecks and the ASPP
+                                      classifier).  Stride-1 DN_CONV_FWD / DN_CONV_DGRAD and their weight gradient, zero padding. */
 } dn_conv_desc;
 
 enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2 };
@@ -245,9 +248,12 @@ int dn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, cons
                        float* partial, dn_stream_t stream);
 /* MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (models/Disp_res_50.py:73); idx (uint8 per output element) = window
  * position 0..8 of the first maximum in row-major order.  Backward gathers (deterministic), dx overwrite / accumulate. */
-int dn_maxpool3s2_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* out, uint8_t* idx, dn_stream_t stream);
-int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, int32_t accumulate,
-                      dn_stream_t stream);
+/* ceil_mode != 0: nn.MaxPool2d(..., ceil_mode=True) (models/ASPP.py:138): OH = ceil((H - 1) / 2) + 1 unless that window starts past the
+ * input; the caller sizes out / idx with dn_maxpool3s2_out(H, ceil_mode). */
+int32_t dn_maxpool3s2_out(int32_t H, int32_t ceil_mode);
+int dn_maxpool3s2_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ceil_mode, float* out, uint8_t* idx, dn_stream_t stream);
+int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ceil_mode, float* dx,
+                      int32_t accumulate, dn_stream_t stream);
 /* out = (x - sub) / div  element-wise (the input normalisation of networks/vgg_encoder.py:80, resnet_encoder.py:89) */
 int dn_sub_div(const float* x, int64_t n, float sub, float div, float* out, dn_stream_t stream);
 /* bilinear x2, align_corners = False, 1 channel (models/DispNetS.py:120,126,132), cropped to (OH,OW). */
@@ -255,6 +261,31 @@ int dn_upsample2x_bilinear_fwd(const float* low, int32_t N, int32_t h, int32_t w
                                dn_stream_t stream);
 int dn_upsample2x_bilinear_bwd(const float* dout, int32_t N, int32_t h, int32_t w, int32_t OH, int32_t OW, float* dlow,
                                int32_t accumulate, dn_stream_t stream);
+/* ---- pieces of the FCRN / ASPP nets (reference models/FCRN.py, models/ASPP.py, models/res_aspp.py) ----
+ * Batch statistics of a MATERIALISED NHWC tensor in the layout the conv epilogues write and dn_bn_finalize merges:
+ * partial[dn_bn_stats_rows(rows)][C][2] = (sum, sum of squared deviations from the tile mean) per 128-row tile.  FCRN's up-projection
+ * normalises a map interleaved from four convolutions (models/FCRN.py:97-113), so no single conv epilogue sees its statistics. */
+int32_t dn_bn_stats_rows(int64_t rows);
+int dn_bn_stats_partial(const float* x, int64_t rows, int32_t C, float* partial, dn_stream_t stream);
+/* out = y*scale[c] + shift[c]: a BatchNorm output WITHOUT ReLU that leaves as a tensor (FCRN bn2, models/FCRN.py:236-237). */
+int dn_bn_apply_fwd(const float* y, const float* scale, const float* shift, int64_t rows, int32_t C, float* out, dn_stream_t stream);
+/* FCRN's up-projection (models/FCRN.py:74-113) interleaves four convolutions -- 3x3, 2x3, 3x2, 2x2, each with one zero row above and one
+ * zero column to the left -- into a 2H x 2W map: phase (a, b) = (row parity, column parity).  That is exactly a ConvTranspose2d(6x6,
+ * stride 2, padding 2) whose weight is assembled from the four (wt[ci][co][a + 4 - 2 kr][b + 4 - 2 ks] = w_ab[co][ci][kr][ks], zero
+ * elsewhere), so the engine runs DN_CONVT_* on that composite weight; what the transposed convolution cannot carry are the four
+ * separate biases:  x[n][2y+a][2x+b][c] += bias4[a][b][c]  and, backwards,  out4[a][b][c] = sum of g over phase (a, b) (fixed-order sums;
+ * workspace of dn_phase_colsum_workspace_bytes(C)). */
+int dn_phase_bias_add(float* x, int32_t N, int32_t H2, int32_t W2, int32_t C, const float* bias4, dn_stream_t stream);
+size_t dn_phase_colsum_workspace_bytes(int32_t C);
+int dn_phase_colsum(const float* g, int32_t N, int32_t H, int32_t W, int32_t C, float* workspace, float* out4, dn_stream_t stream);
+/* out = act(x) element-wise (the ASPP classifier sums four dilated convolutions BEFORE its sigmoid, models/ASPP.py:117-123). */
+int dn_act_fwd(const float* x, int64_t n, int32_t act, float p0, float p1, float* out, dn_stream_t stream);
+/* F.interpolate(x, size=(OH, OW), mode='bilinear', align_corners=...) of a one-channel map [N][IH][IW] (models/FCRN.py:253,
+ * models/ASPP.py:192); source index and weights computed in fp32 exactly as ATen does.  Backward gathers (deterministic). */
+int dn_resize_bilinear_fwd(const float* in, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t align_corners, float* out,
+                           dn_stream_t stream);
+int dn_resize_bilinear_bwd(const float* dout, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t align_corners, float* din,
+                           int32_t accumulate, dn_stream_t stream);
 /* out[n][c] = scale * mean over pixels of x[n][p][c] (NHWC): pose = 0.01 * pose_pred(...).mean(3).mean(2), models/PoseExpNet.py:73-75 */
 int dn_spatial_mean_fwd(const float* x, int32_t N, int64_t HW, int32_t C, float scale, float* out, dn_stream_t stream);
 int dn_spatial_mean_bwd(const float* dout, int32_t N, int64_t HW, int32_t C, float scale, float* dx, dn_stream_t stream);

@@ -13,7 +13,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 # ABI version this binding was written against (include/dispnet_hip.h: dn_version(), bumped on any signature / struct change).
 # load() refuses a library that reports anything else: a stale .so (DISPNET_HIP_LIB, a build that did not re-run) would otherwise
 # read struct fields past the end of what this binding fills in and mis-marshal arguments -- silent memory corruption, not an error.
-EXPECTED_ABI = 6
+EXPECTED_ABI = 7
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
                 ("n_in", C.c_int32), ("in_", Operand * DN_MAX_OPERANDS),
                 ("n_out", C.c_int32), ("out", Result * DN_MAX_OPERANDS),
                 ("w_packed", _f32p), ("bias", _f32p), ("act", C.c_int32), ("act_p0", C.c_float), ("act_p1", C.c_float),
-                ("bn_partial", _f32p), ("pad_mode", C.c_int32), ("compute", C.c_int32)]
+                ("bn_partial", _f32p), ("pad_mode", C.c_int32), ("compute", C.c_int32), ("dilation", C.c_int32)]
 
 
 _P = C.POINTER
@@ -87,8 +87,18 @@ SIGNATURES = {
     "dn_reflect_fold": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "dn_bn_add_relu_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "dn_bn_add_relu_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
-    "dn_maxpool3s2_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "dn_maxpool3s2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_maxpool3s2_out": (_i32, [_i32, _i32]),
+    "dn_maxpool3s2_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_maxpool3s2_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "dn_bn_stats_rows": (_i32, [_i64]),
+    "dn_bn_stats_partial": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "dn_bn_apply_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "dn_act_fwd": (C.c_int, [_vp, _i64, _i32, _f, _f, _vp, _vp]),
+    "dn_phase_bias_add": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_phase_colsum_workspace_bytes": (_sz, [_i32]),
+    "dn_phase_colsum": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dn_resize_bilinear_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dn_resize_bilinear_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "dn_sub_div": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
     "dn_spatial_mean_fwd": (C.c_int, [_vp, _i32, _i64, _i32, _f, _vp, _vp]),
     "dn_spatial_mean_bwd": (C.c_int, [_vp, _i32, _i64, _i32, _f, _vp, _vp]),

@@ -928,7 +928,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
 
 static bool stem_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (knobs().no_stem) return false;
-  if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
+  if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (p.n_in != 1 || p.n_out != 1 || p.Ntot != 64 || p.nphases != 1) return false;
   const KOperand& o = p.in[0];
   const KResult& r = p.out[0];

@@ -136,7 +136,13 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   p->w = d->w_packed;
   p->bn_partial = d->bn_partial;
   const int st = d->stride, pad = d->pad;
+  const int dil = d->dilation > 1 ? d->dilation : 1;
   DN_REQUIRE(d->pad_mode == 0 || d->pad_mode == 1, DN_ERR_BAD_ARG, "bad pad_mode %d", d->pad_mode);
+  if (dil > 1) {
+    DN_REQUIRE(st == 1 && d->pad_mode == 0 && (d->kind == DN_CONV_FWD || d->kind == DN_CONV_DGRAD), DN_ERR_UNSUPPORTED,
+               "dilation %d: stride-1 zero-padded conv forward / input gradient / weight gradient only", dil);
+    DN_REQUIRE((d->R - 1) * dil - pad <= 127 && (d->S - 1) * dil - pad <= 127 && pad <= 127, DN_ERR_UNSUPPORTED, "dilation %d: tap offsets beyond +-127", dil);
+  }
   if (d->pad_mode == 1) {
     DN_REQUIRE(for_wgrad ? d->kind == DN_CONV_FWD : d->kind == DN_CONV_FWD, DN_ERR_UNSUPPORTED,
                "reflection padding is supported by the conv forward and its weight gradient only");
@@ -153,8 +159,8 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     int nt = 0;
     for (int r = 0; r < d->R; ++r)
       for (int s = 0; s < d->S; ++s) {
-        p->tdy[nt] = (int8_t)(r - pad);
-        p->tdx[nt] = (int8_t)(s - pad);
+        p->tdy[nt] = (int8_t)(r * dil - pad);
+        p->tdx[nt] = (int8_t)(s * dil - pad);
         p->tr[nt] = (int8_t)r;
         p->ts[nt] = (int8_t)s;
         ++nt;
@@ -227,8 +233,8 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
       int nt = 0;
       for (int r = 0; r < d->R; ++r)
         for (int s = 0; s < d->S; ++s) {
-          p->tdy[nt] = (int8_t)(r - pad);
-          p->tdx[nt] = (int8_t)(s - pad);
+          p->tdy[nt] = (int8_t)(r * dil - pad);
+          p->tdx[nt] = (int8_t)(s * dil - pad);
           p->tr[nt] = (int8_t)r;
           p->ts[nt] = (int8_t)s;
           ++nt;
@@ -252,12 +258,12 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
           ph.ooy = py;
           ph.oox = px;
           for (int r = 0; r < d->R; ++r) {
-            if (((py + pad - r) % st + st) % st != 0) continue;
+            if (((py + pad - r * dil) % st + st) % st != 0) continue;
             for (int s = 0; s < d->S; ++s) {
-              if (((px + pad - s) % st + st) % st != 0) continue;
+              if (((px + pad - s * dil) % st + st) % st != 0) continue;
               DN_REQUIRE(nt < kMaxTaps, DN_ERR_UNSUPPORTED, "too many taps");
-              p->tdy[nt] = (int8_t)floor_div(py + pad - r, st);
-              p->tdx[nt] = (int8_t)floor_div(px + pad - s, st);
+              p->tdy[nt] = (int8_t)floor_div(py + pad - r * dil, st);
+              p->tdx[nt] = (int8_t)floor_div(px + pad - s * dil, st);
               p->tr[nt] = (int8_t)r;
               p->ts[nt] = (int8_t)s;
               ++nt;
@@ -331,7 +337,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 6; }
+int dn_version(void) { return 7; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);

@@ -1027,20 +1027,27 @@ int dn_bn_add_relu_bwd(const float* gout, const float* out, const float* y, cons
   return launch_colreduce(op, rows, C, partial, as_stream(stream), "bn_add_relu_bwd");
 }
 
-int dn_maxpool3s2_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* out, uint8_t* idx, dn_stream_t stream) {
+int32_t dn_maxpool3s2_out(int32_t H, int32_t ceil_mode) {
+  if (!ceil_mode) return (H - 1) / 2 + 1;                  // floor((H + 2 - 3) / 2) + 1
+  int o = H / 2 + 1;                                        // ceil((H - 1) / 2) + 1
+  if ((o - 1) * 2 >= H + 1) --o;                            // (ATen: the last window must start inside the input or its left padding)
+  return o;
+}
+
+int dn_maxpool3s2_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ceil_mode, float* out, uint8_t* idx, dn_stream_t stream) {
   DN_REQUIRE(x && out && idx && N > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_maxpool3s2_fwd: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool3s2_fwd: need C%%4==0");
-  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int OH = dn_maxpool3s2_out(H, ceil_mode), OW = dn_maxpool3s2_out(W, ceil_mode);
   hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * (C / 4))), dim3(kThreads), 0, as_stream(stream), x, N, H, W,
                      C, OH, OW, out, idx);
   return check_launch("maxpool3s2_fwd_kernel");
 }
 
-int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, int32_t accumulate,
-                      dn_stream_t stream) {
+int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ceil_mode, float* dx,
+                      int32_t accumulate, dn_stream_t stream) {
   DN_REQUIRE(dout && idx && dx && N > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_maxpool3s2_bwd: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool3s2_bwd: need C%%4==0");
-  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int OH = dn_maxpool3s2_out(H, ceil_mode), OW = dn_maxpool3s2_out(W, ceil_mode);
   hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(kThreads), 0, as_stream(stream), dout, idx, N, H,
                      W, C, OH, OW, dx, accumulate);
   return check_launch("maxpool3s2_bwd_kernel");

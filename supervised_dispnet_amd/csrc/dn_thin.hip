@@ -74,7 +74,7 @@ static bool thin_shape(const IgemmParams& p, int* ntc, int* nkt) {
 bool thin_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (knobs().no_thin) return false;
   if (d->kind != DN_CONV_FWD) return false;
-  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OW & 3)) return false;
   if (p.Ntot % 16 != 0 || p.Ntot > 64) return false;
   if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) return false;

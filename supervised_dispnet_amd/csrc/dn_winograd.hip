@@ -43,7 +43,7 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   // the one-channel disparity heads have their own kernels, dispatched before this one (dn_conv.hip::run_conv); the packed
   // weight layout must follow the same decision (a head's input gradient has a 1-channel operand and would qualify below)
   if (!knobs().no_direct && (head_fwd_eligible(d, p) || head_dgrad_eligible(d, p))) return false;
-  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
   if (p.nphases != 1 || p.ph[0].ntaps != 9) return false;
   if (p.Ntot < 64) return false;

@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x4 wg_buffer_load(__amdgpu_buffer_rsrc_t r, int vo
 bool wino_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (knobs().no_winograd || knobs().no_winograd_wgrad) return false;
   if (d->kind != DN_CONV_FWD) return false;
-  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0) return false;
+  if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
   if (p.ph[0].ntaps != 9) return false;
   if (p.Ntot % 64 != 0) return false;

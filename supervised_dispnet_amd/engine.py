@@ -339,6 +339,7 @@ class ConvLayer:
         self.R, self.S = module.kernel_size
         self.stride = module.stride[0]
         self.pad = module.padding[0]
+        self.dil = module.dilation[0] if not transposed else 1
         self.reflect = reflect_pad > 0          # nn.ReflectionPad2d(reflect_pad) in front of a pad-0 conv (layers.py:124-136)
         if self.reflect:
             if transposed or self.pad != 0:
@@ -359,7 +360,7 @@ class ConvLayer:
         if self.transposed:
             return ((H - 1) * self.stride - 2 * self.pad + self.R + self.out_pad,
                     (W - 1) * self.stride - 2 * self.pad + self.S + self.out_pad)
-        return ((H + 2 * self.pad - self.R) // self.stride + 1, (W + 2 * self.pad - self.S) // self.stride + 1)
+        return ((H + 2 * self.pad - self.dil * (self.R - 1) - 1) // self.stride + 1, (W + 2 * self.pad - self.dil * (self.S - 1) - 1) // self.stride + 1)
 
     def _desc(self, kind, N, IH, IW, OH, OW):
         d = ConvDesc()
@@ -368,6 +369,7 @@ class ConvLayer:
         d.R, d.S, d.stride, d.pad = self.R, self.S, self.stride, self.pad
         d.pad_mode = 1 if (self.reflect and kind == CONV_FWD) else 0
         d.compute = COMPUTE
+        d.dilation = self.dil
         return d
 
     def packed(self, kind, desc):
@@ -487,8 +489,10 @@ def prepack_all(device):
         t.run(PARAM_EPOCH)
 
 
-def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None):
-    """Forward of conv / conv-transpose over virtually concatenated `pieces`.  Returns (y tensor NHWC, partial, rows)."""
+def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None, out_view=None):
+    """Forward of conv / conv-transpose over virtually concatenated `pieces`.  Returns (y tensor NHWC, partial, rows).
+    `out_view` = (tensor, element offset, (stride_n, stride_h, stride_w), accumulate): write the result into a strided view of an
+    existing tensor instead of a fresh one (FCRN's interleaved up-projection maps; the ASPP classifier's sum of four convolutions)."""
     a0 = pieces[0].act
     N = a0.N
     IH = a0.H * (2 if pieces[0].up else 1)
@@ -499,9 +503,17 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
     d.n_in = len(pieces)
     for i, p in enumerate(pieces):
         _fill_operand(d.in_[i], p)
-    y = torch.empty((N, OH, OW, layer.Cout), dtype=torch.float32, device=a0.t.device)
     d.n_out = 1
-    _fill_result(d.out[0], y, layer.Cout, OH, OW, False)
+    if out_view is None:
+        y = torch.empty((N, OH, OW, layer.Cout), dtype=torch.float32, device=a0.t.device)
+        _fill_result(d.out[0], y, layer.Cout, OH, OW, False)
+    else:
+        y, off, (vsn, vsh, vsw), vacc = out_view
+        r = d.out[0]
+        r.data = y.data_ptr() + 4 * off
+        r.C = layer.Cout
+        r.accumulate = 1 if vacc else 0
+        r.stride_n, r.stride_h, r.stride_w = vsn, vsh, vsw
     d.w_packed = layer.packed(kind, d).data_ptr()
     b = layer.m.bias
     d.bias = _ptr(b.detach()) if b is not None else None
@@ -514,7 +526,7 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
     with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cout), 2 * layer.macs(N, IH, IW, OH, OW),
                 "%s %dx%d k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_fwd" if layer.transposed else "conv_fwd", layer.R, layer.S,
                                                                layer.R, layer.stride, layer.Cin, layer.Cout, N, IH, IW),
-                4 * (sum(p.act.rows * p.act.C for p in pieces) + y.numel())):
+                4 * (sum(p.act.rows * p.act.C for p in pieces) + N * OH * OW * layer.Cout)):
         _lib.call("dn_convT2d_fwd" if layer.transposed else "dn_conv2d_fwd", C.byref(d), _stream())
     return y, partial, rows
 
@@ -698,6 +710,74 @@ class GradSink:
         return self.grads.get(id(param))
 
 
+def bn_backward(y, bn, sink, training):
+    """BatchNorm backward of an activation stored pre-BN with the affine pending (block_conv_bn, block_upproject): y.grad holds
+    dL/d(relu(bn(y))) -- or dz with its column sums in y.partial when y.grad_is_dz -- and becomes dL/dy in place; d(gamma), d(beta) go
+    to the sink.  Returns the gradient tensor."""
+    g, y_t, Cn, dev = y.grad, y.t, y.C, y.t.device
+    if not training:
+        raise NotImplementedError("backward through eval-mode BatchNorm (frozen statistics) is not implemented")
+    relu_pending = not y.grad_is_dz           # g is dL/d(relu output): the mask is applied by the kernels below
+    if relu_pending:
+        if y.no_relu:
+            raise RuntimeError("a ReLU-less BatchNorm output must be consumed by block_bn_add_relu / block_bn_plain")
+        nblk = _lib.load().dn_reduce_blocks(y.rows, Cn)
+        y.partial = torch.empty((nblk, Cn, 2), dtype=torch.float32, device=dev)
+        y.partial_rows = nblk
+        if BN_MATERIALIZE_DZ:
+            hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 12, "dn_bn_relu_bwd_reduce", g.data_ptr(),
+                     y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
+                     y.partial.data_ptr(), _stream())
+        else:                                 # sums only: the apply pass re-derives the mask from y (one full-size write less)
+            hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 8, "dn_bn_relu_bwd_sums", g.data_ptr(),
+                     y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
+                     y.partial.data_ptr(), _stream())
+    # written straight into the optimizer arena's gradient slices when there is one (no copy launches)
+    dgamma = sink.dest(bn.weight)
+    dbeta = sink.dest(bn.bias)
+    if dgamma is None:
+        dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
+    if dbeta is None:
+        dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
+    if y.pool_src is not None:                # gradient through the 2x2 max-pool: expanded here, never materialised as dz
+        dpooled, pidx = y.pool_src
+        hbm_call("dn::bn_bwd_apply_pool_kernel", y.rows * Cn * 8 + y.rows * Cn * 5 // 4, "dn_bn_bwd_apply_pool", dpooled.data_ptr(),
+                 pidx.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(),
+                 y.partial_rows, y.partial_stride, y.partial_offset, y.N, y.H, y.W, Cn, g.data_ptr(), dgamma.data_ptr(),
+                 dbeta.data_ptr(), _stream())
+        y.pool_src = None
+    elif relu_pending and not BN_MATERIALIZE_DZ:
+        hbm_call("dn::bn_bwd_apply_relu_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply_relu", g.data_ptr(), y_t.data_ptr(),
+                 y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(),
+                 y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn, dgamma.data_ptr(),
+                 dbeta.data_ptr(), _stream())
+    else:
+        hbm_call("dn::bn_bwd_apply_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
+                 y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride,
+                 y.partial_offset, y.rows, Cn, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
+    sink.put(bn.weight, dgamma)
+    sink.put(bn.bias, dbeta)
+    return g
+
+
+def _bn_pending(y, bn, partial, prow, training, conv_bias=None):
+    """Fold batch statistics (training: from `partial`, also updating the running buffers) or running statistics (eval) of `bn` into the
+    per-channel (scale, shift) pending on `y`."""
+    Cn, dev = y.C, y.t.device
+    y.scale = torch.empty(Cn, dtype=torch.float32, device=dev)
+    y.shift = torch.empty(Cn, dtype=torch.float32, device=dev)
+    if training:
+        y.mean = torch.empty(Cn, dtype=torch.float32, device=dev)
+        y.invstd = torch.empty(Cn, dtype=torch.float32, device=dev)
+        _lib.call("dn_bn_finalize", partial.data_ptr(), prow, Cn, y.rows, _ptr(conv_bias.detach()) if conv_bias is not None else None,
+                  bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                  bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps, y.mean.data_ptr(), y.invstd.data_ptr(),
+                  y.scale.data_ptr(), y.shift.data_ptr(), _nbt_ptr(bn), _stream())
+    else:
+        _lib.call("dn_bn_eval_affine", Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), bn.eps, y.scale.data_ptr(), y.shift.data_ptr(), _stream())
+
+
 # ------------------------------------------------------------------------------------------------- block helpers
 def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
     """conv3x3 -> BatchNorm (batch statistics when training) -> ReLU, with the BN-apply+ReLU left pending on the result
@@ -726,50 +806,7 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
     def backward():
         if y.grad is None:
             return
-        g = y.grad
-        if training:
-            relu_pending = not y.grad_is_dz           # g is dL/d(relu output): the mask is applied by the kernels below
-            if relu_pending:
-                if y.no_relu:
-                    raise RuntimeError("a ReLU-less BatchNorm output must be consumed by block_bn_add_relu")
-                nblk = _lib.load().dn_reduce_blocks(y.rows, Cn)
-                y.partial = torch.empty((nblk, Cn, 2), dtype=torch.float32, device=dev)
-                y.partial_rows = nblk
-                if BN_MATERIALIZE_DZ:
-                    hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 12, "dn_bn_relu_bwd_reduce", g.data_ptr(),
-                             y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
-                             y.partial.data_ptr(), _stream())
-                else:                                 # sums only: the apply pass re-derives the mask from y (one full-size write less)
-                    hbm_call("dn::colreduce_kernel<dn::BnReluBwdOp, 4>", y.rows * Cn * 8, "dn_bn_relu_bwd_sums", g.data_ptr(),
-                             y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
-                             y.partial.data_ptr(), _stream())
-            # written straight into the optimizer arena's gradient slices when there is one (no copy launches)
-            dgamma = sink.dest(bn.weight)
-            dbeta = sink.dest(bn.bias)
-            if dgamma is None:
-                dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
-            if dbeta is None:
-                dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
-            if y.pool_src is not None:                # gradient through the 2x2 max-pool: expanded here, never materialised as dz
-                dpooled, pidx = y.pool_src
-                hbm_call("dn::bn_bwd_apply_pool_kernel", y.rows * Cn * 8 + y.rows * Cn * 5 // 4, "dn_bn_bwd_apply_pool", dpooled.data_ptr(),
-                         pidx.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(),
-                         y.partial_rows, y.partial_stride, y.partial_offset, y.N, y.H, y.W, Cn, g.data_ptr(), dgamma.data_ptr(),
-                         dbeta.data_ptr(), _stream())
-                y.pool_src = None
-            elif relu_pending and not BN_MATERIALIZE_DZ:
-                hbm_call("dn::bn_bwd_apply_relu_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply_relu", g.data_ptr(), y_t.data_ptr(),
-                         y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(),
-                         y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn, dgamma.data_ptr(),
-                         dbeta.data_ptr(), _stream())
-            else:
-                hbm_call("dn::bn_bwd_apply_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
-                         y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride,
-                         y.partial_offset, y.rows, Cn, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
-            sink.put(bn.weight, dgamma)
-            sink.put(bn.bias, dbeta)
-        else:
-            raise NotImplementedError("backward through eval-mode BatchNorm (frozen statistics) is not implemented")
+        g = bn_backward(y, bn, sink, training)
         # g is now dL/d(conv output).  The conv bias sits in front of a BatchNorm: its gradient is identically zero in
         # exact arithmetic (BN removes the mean); the reference's value is rounding noise.  We store exact zeros.
         if layer.m.bias is not None:
@@ -1015,15 +1052,17 @@ def block_bn_relu(tape, y):
     return block_bn_add_relu(tape, y, None)
 
 
-def block_maxpool3s2(tape, x):
-    """MaxPool2d(kernel_size=3, stride=2, padding=1) of a plain activation (models/Disp_res_50.py:73)."""
+def block_maxpool3s2(tape, x, ceil_mode=False):
+    """MaxPool2d(kernel_size=3, stride=2, padding=1[, ceil_mode=True]) of a plain activation (models/Disp_res_50.py:73; ASPP.py:138)."""
     if x.scale is not None:
         raise RuntimeError("block_maxpool3s2 expects a plain activation")
-    OH, OW = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+    cm = 1 if ceil_mode else 0
+    lib = _lib.load()
+    OH, OW = lib.dn_maxpool3s2_out(x.H, cm), lib.dn_maxpool3s2_out(x.W, cm)
     dev = x.t.device
     o_t = torch.empty((x.N, OH, OW, x.C), dtype=torch.float32, device=dev)
     idx = torch.empty((x.N, OH, OW, x.C), dtype=torch.uint8, device=dev)
-    _lib.call("dn_maxpool3s2_fwd", x.t.data_ptr(), x.N, x.H, x.W, x.C, o_t.data_ptr(), idx.data_ptr(), _stream())
+    _lib.call("dn_maxpool3s2_fwd", x.t.data_ptr(), x.N, x.H, x.W, x.C, cm, o_t.data_ptr(), idx.data_ptr(), _stream())
     out = Act(o_t, x.N, OH, OW, x.C)
 
     def backward():
@@ -1032,7 +1071,7 @@ def block_maxpool3s2(tape, x):
         first = x.grad is None
         if first:
             x.grad = x.new_like()
-        _lib.call("dn_maxpool3s2_bwd", out.grad.data_ptr(), idx.data_ptr(), x.N, x.H, x.W, x.C, x.grad.data_ptr(), 0 if first else 1, _stream())
+        _lib.call("dn_maxpool3s2_bwd", out.grad.data_ptr(), idx.data_ptr(), x.N, x.H, x.W, x.C, cm, x.grad.data_ptr(), 0 if first else 1, _stream())
         out.grad = None
 
     tape.push(backward)
@@ -1090,6 +1129,192 @@ def block_spatial_mean(tape, x, scale=1.0):
             raise RuntimeError("block_spatial_mean: single-consumer input expected")
         x.grad = x.new_like()
         _lib.call("dn_spatial_mean_bwd", out.grad.data_ptr(), x.N, x.H * x.W, x.C, scale, x.grad.data_ptr(), _stream())
+        out.grad = None
+
+    tape.push(backward)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- FCRN / ASPP blocks
+def block_bn_plain(tape, y):
+    """Materialise bn(y) WITHOUT ReLU of a block_conv_bn(..., relu=False) result as a plain activation (FCRN: `x = self.bn2(self.conv2(x))`
+    feeds the first up-projection, models/FCRN.py:236-239).  Backward: dz = d(out); its column sums (sum dz, sum dz * xhat) come from the
+    ReLU-backward sums kernel run with an always-true mask (scale 0, shift 1), then the producer's BatchNorm backward applies them."""
+    if not y.no_relu:
+        raise RuntimeError("block_bn_plain: y must come from block_conv_bn(relu=False)")
+    out_t = y.new_like()
+    _lib.call("dn_bn_apply_fwd", y.t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.rows, y.C, out_t.data_ptr(), _stream())
+    out = Act(out_t, y.N, y.H, y.W, y.C)
+
+    def backward():
+        if out.grad is None:
+            return
+        if y.mean is None:
+            raise NotImplementedError("backward through eval-mode BatchNorm (frozen statistics) is not implemented")
+        dev = y.t.device
+        nblk = _lib.load().dn_reduce_blocks(y.rows, y.C)
+        y.partial = torch.empty((nblk, y.C, 2), dtype=torch.float32, device=dev)
+        y.partial_rows, y.partial_stride, y.partial_offset = nblk, 2, 0
+        zero, one = torch.zeros(y.C, dtype=torch.float32, device=dev), torch.ones(y.C, dtype=torch.float32, device=dev)
+        _lib.call("dn_bn_relu_bwd_sums", out.grad.data_ptr(), y.t.data_ptr(), zero.data_ptr(), one.data_ptr(), y.mean.data_ptr(),
+                  y.invstd.data_ptr(), y.rows, y.C, y.partial.data_ptr(), _stream())
+        y.grad = out.grad
+        y.grad_is_dz = True
+        out.grad = None
+
+    tape.push(backward)
+    return out
+
+
+class _CompositeConvT(object):
+    """Stand-in for the nn.ConvTranspose2d(6x6, stride 2, padding 2) that one branch of FCRN's up-projection amounts to; `.weight` is a
+    plain tensor [Cin][Cout][6][6] rebuilt from the branch's four nn.Conv2d weights before every use (assemble / scatter_grad)."""
+    kernel_size, stride, padding, output_padding, dilation, bias = (6, 6), (2, 2), (2, 2), (0, 0), (1, 1), None
+
+    def __init__(self, convs):
+        self.convs = convs                                  # phase order (0,0), (0,1), (1,0), (1,1)
+        self.in_channels, self.out_channels = convs[0].in_channels, convs[0].out_channels
+        self.weight = None
+
+    def assemble(self):
+        w0 = self.convs[0].weight
+        if self.weight is None or self.weight.device != w0.device:
+            self.weight = torch.zeros((self.in_channels, self.out_channels, 6, 6), dtype=torch.float32, device=w0.device)
+        wt = self.weight
+        for k, m in enumerate(self.convs):
+            a, b = k >> 1, k & 1
+            R, S = m.kernel_size
+            # wt[ci][co][a + 4 - 2 kr][b + 4 - 2 ks] = w[co][ci][kr][ks]
+            wt[:, :, a + 4 - 2 * (R - 1):a + 5:2, b + 4 - 2 * (S - 1):b + 5:2] = m.weight.detach().permute(1, 0, 2, 3).flip(2, 3)
+        return wt
+
+    def scatter_grad(self, dwt, sink):
+        for k, m in enumerate(self.convs):
+            a, b = k >> 1, k & 1
+            R, S = m.kernel_size
+            dw = dwt[:, :, a + 4 - 2 * (R - 1):a + 5:2, b + 4 - 2 * (S - 1):b + 5:2].flip(2, 3).permute(1, 0, 2, 3)
+            dst = sink.dest(m.weight)
+            if dst is not None:
+                dst.copy_(dw)
+                sink.put(m.weight, dst)
+            else:
+                sink.put(m.weight, dw.contiguous())
+
+
+def block_upproject(tape, sink, x, up, rt, training):
+    """FCRN's up-projection block (models/FCRN.py:52-124): per branch four convolutions (3x3, 2x3, 3x2, 2x2; one zero row above and one
+    zero column to the left, the rest implied by output size = input size) whose results interleave into a 2H x 2W map -- phase (a, b) =
+    (row parity, column parity) = conv*_1, conv*_2, conv*_3, conv*_4 --, BatchNorm over the interleaved map; branch 1: ReLU, conv3x3,
+    BatchNorm; branch 2: BatchNorm only; sum, ReLU.  A branch's four convolutions ARE a ConvTranspose2d(6x6, stride 2, padding 2) on a
+    composite weight (include/dispnet_hip.h, dn_phase_bias_add), so each branch is one run of the engine's four-phase transposed
+    convolution + the four biases; the statistics of the interleaved maps are taken by dn_bn_stats_partial; bn1_1 + ReLU stays pending
+    for conv3's loader; the tail is block_bn_add_relu.  `rt`: {"t1", "t2": ConvLayer over a _CompositeConvT, "conv3": ConvLayer}."""
+    if x.scale is not None:
+        raise RuntimeError("block_upproject expects a plain activation")
+    N, H, W = x.N, x.H, x.W
+    Cn = up.conv3.out_channels
+    dev = x.t.device
+    P = Piece
+    maps = []
+    for br in (1, 2):
+        layer = rt["t%d" % br]
+        layer.m.assemble()
+        o_t, _, _ = conv_forward(layer, [P(x)])
+        bias4 = torch.stack([m.bias.detach() for m in layer.m.convs]).contiguous()
+        _lib.call("dn_phase_bias_add", o_t.data_ptr(), N, 2 * H, 2 * W, Cn, bias4.data_ptr(), _stream())
+        o = Act(o_t, N, 2 * H, 2 * W, Cn)
+        bn = up.bn1_1 if br == 1 else up.bn1_2
+        partial, prow = None, 0
+        if training:
+            prow = _lib.load().dn_bn_stats_rows(o.rows)
+            partial = torch.empty((prow, Cn, 2), dtype=torch.float32, device=dev)
+            _lib.call("dn_bn_stats_partial", o_t.data_ptr(), o.rows, Cn, partial.data_ptr(), _stream())
+        _bn_pending(o, bn, partial, prow, training)
+        maps.append(o)
+    o1, o2 = maps
+    o2.no_relu = True
+
+    def backward():
+        # d(o1) arrives from conv3's input gradient (through the pending ReLU), d(o2) as dz from block_bn_add_relu
+        for br, o in ((1, o1), (2, o2)):
+            if o.grad is None:
+                continue
+            layer = rt["t%d" % br]
+            bn = up.bn1_1 if br == 1 else up.bn1_2
+            g = bn_backward(o, bn, sink, training)                      # dL/d(interleaved pre-BatchNorm map)
+            lib = _lib.load()
+            ws = torch.empty(lib.dn_phase_colsum_workspace_bytes(Cn) // 4, dtype=torch.float32, device=dev)
+            db4 = torch.empty((4, Cn), dtype=torch.float32, device=dev)
+            _lib.call("dn_phase_colsum", g.data_ptr(), N, H, W, Cn, ws.data_ptr(), db4.data_ptr(), _stream())
+            for k, m in enumerate(layer.m.convs):
+                dst = sink.dest(m.bias)
+                if dst is not None:
+                    dst.copy_(db4[k])
+                sink.put(m.bias, dst if dst is not None else db4[k])
+            layer.m.assemble()                                          # (the composite is shared scratch: rebuild for this branch's dgrad)
+            dwt = conv_wgrad(layer, [P(x)], g, (2 * H, 2 * W))
+            join_side_stream()                                          # the composite gradient may come from the weight-gradient side stream
+            layer.m.scatter_grad(dwt, sink)
+            conv_dgrad(layer, g, N, 2 * H, 2 * W, [P(x)], (H, W))
+            o.grad = None
+
+    tape.push(backward)
+    y3 = block_conv_bn(tape, sink, P(o1), rt["conv3"], up.bn2, training, relu=False)
+    return block_bn_add_relu(tape, y3, o2)
+
+
+def block_sum_convs_act(tape, sink, x, layers, act, p0=0.0, p1=0.0):
+    """act(sum_i conv_i(x)): the ASPP classifier (models/ASPP.py:107-123 -- four dilated 3x3 convolutions 2048 -> 1, summed, then
+    10 * sigmoid + 0.01).  The first convolution writes the map, the others accumulate into it; every bias gets the same gradient."""
+    if x.scale is not None:
+        raise RuntimeError("block_sum_convs_act expects a plain activation")
+    N, H, W = x.N, x.H, x.W
+    Cn = layers[0].Cout
+    dev = x.t.device
+    pre = torch.empty((N, H, W, Cn), dtype=torch.float32, device=dev)
+    dense = (H * W * Cn, W * Cn, Cn)
+    for i, layer in enumerate(layers):
+        conv_forward(layer, [Piece(x)], out_hw=(H, W), out_view=(pre, 0, dense, i > 0))
+    out_t = torch.empty_like(pre)
+    _lib.call("dn_act_fwd", pre.data_ptr(), pre.numel(), act, p0, p1, out_t.data_ptr(), _stream())
+    out = Act(out_t, N, H, W, Cn)
+
+    def backward():
+        if out.grad is None:
+            return
+        g = out.grad
+        db = act_bwd(g, out_t, act, p0, p1, N * H * W, Cn)
+        for layer in layers:
+            if layer.m.bias is not None:
+                dst = sink.dest(layer.m.bias)
+                if dst is not None:
+                    dst.copy_(db)
+                sink.put(layer.m.bias, dst if dst is not None else db.clone())
+            conv_wgrad(layer, [Piece(x)], g, (H, W), out=sink.dest(layer.m.weight), sink=sink)
+            conv_dgrad(layer, g, N, H, W, [Piece(x)], (H, W))
+        out.grad = None
+
+    tape.push(backward)
+    return out
+
+
+def block_resize_bilinear(tape, d, out_hw, align_corners=True):
+    """F.interpolate(d, size=out_hw, mode='bilinear', align_corners=...) of a one-channel map (models/FCRN.py:253, models/ASPP.py:192)."""
+    if d.C != 1 or d.scale is not None:
+        raise NotImplementedError("block_resize_bilinear: one-channel plain maps only")
+    OH, OW = out_hw
+    ac = 1 if align_corners else 0
+    o_t = torch.empty((d.N, OH, OW, 1), dtype=torch.float32, device=d.t.device)
+    _lib.call("dn_resize_bilinear_fwd", d.t.data_ptr(), d.N, d.H, d.W, OH, OW, ac, o_t.data_ptr(), _stream())
+    out = Act(o_t, d.N, OH, OW, 1)
+
+    def backward():
+        if out.grad is None:
+            return
+        first = d.grad is None
+        if first:
+            d.grad = d.new_like()
+        _lib.call("dn_resize_bilinear_bwd", out.grad.data_ptr(), d.N, d.H, d.W, OH, OW, ac, d.grad.data_ptr(), 0 if first else 1, _stream())
         out.grad = None
 
     tape.push(backward)

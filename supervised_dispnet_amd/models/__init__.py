@@ -1,8 +1,9 @@
 """Mirror of the reference's `models` package for the hot path (reference models/__init__.py:1-15).
 
-In-scope nets are real; the reference's remaining exports (FCRN, the ASPP / DORN
-backbones: up-projection blocks and dilated convolutions outside the op vocabulary of section 8) raise a clear error rather than
-silently running something else.
+In-scope nets (incl. FCRN's up-projection blocks and the dilated ASPP nets) are real; the
+one remaining export, the full `DORN` backbone (models/DORN.py + Dorn_backbone.py: average-pool + Linear full-image encoder, a
+five-way concat, multi-channel bilinear upsampling; train.py:257-258 constructs it with a `datasets` keyword its __init__ does not
+take, i.e. the reference's own `--network DORN` fails), raises a clear error rather than silently running something else.
 """
 from .DispNetS import DispNetS
 from .Disp_vgg_BN import Disp_vgg_BN
@@ -15,6 +16,8 @@ from .Disp_vgg import Disp_vgg
 from .Disp_vgg_feature import Disp_vgg_feature
 from .PoseExpNet import PoseExpNet
 from .monodepth2 import monodepth2
+from .FCRN import FCRN
+from .ASPP import deeplab_depth, res50_aspp
 
 
 def _out_of_scope(name):

@@ -36,6 +36,21 @@ def zoo_cases():
     ]
 
 
+# SURVEY 8 f-4 tail: FCRN's up-projection net and the dilated ASPP nets (tests/golden/zoo2.npz).  tag, product class, constructor kwargs,
+# oracle call (training forward takes the injected Dropout2d pattern for FCRN)
+def zoo2_cases():
+    from oracle import nets_zoo as Z
+    return [
+        ("fcrn", "FCRN", {"datasets": "kitti"}, lambda sd, x, tr, mask=None: Z.fcrn(sd, x, training=tr, datasets="kitti", dropout_mask=mask)),
+        ("res50_aspp", "res50_aspp", {"datasets": "kitti"}, lambda sd, x, tr, mask=None: Z.aspp_depth(sd, x, training=tr, counts=(3, 4, 6, 3))),
+        ("deeplab", "deeplab_depth", {}, lambda sd, x, tr, mask=None: Z.aspp_depth(sd, x, training=tr, counts=(3, 4, 23, 3))),
+    ]
+
+
+def zoo2_dropout_mask(tag, b=2):
+    return detgen.bernoulli((b, 64), "zoo2:fcrn:drop", 0.5).float() * 2.0 if tag == "fcrn" else None
+
+
 def make_scene_folders(root, scenes=("s1", "s2", "s3"), frames=5, h=16, w=32, seed=0):
     """A tiny dataset in the reference's KITTI layout (scene/{%07d.jpg, %07d.npy, cam.txt} + train.txt / val.txt) with random content."""
     import numpy as np

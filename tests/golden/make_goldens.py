@@ -697,6 +697,59 @@ def gold_zoo(ref_loss):
     save("zoo", **arrays)
 
 
+# FCRN / ASPP (SURVEY 8 f-4 tail).  tag, reference file, class, constructor kwargs, gradient keys, BatchNorm buffer keys
+ZOO2 = (
+    ("fcrn", "models/FCRN.py", "FCRN", {"datasets": "kitti"},
+     ["conv1.weight", "bn1.weight", "layer2.0.downsample.0.weight", "layer4.2.conv3.weight", "conv2.weight", "bn2.bias", "up1.conv1_1.weight",
+      "up1.conv1_2.weight", "up1.conv1_3.bias", "up1.conv1_4.weight", "up1.conv2_2.weight", "up1.bn1_1.weight", "up1.bn1_2.bias",
+      "up2.conv3.weight", "up2.bn2.weight", "up3.conv2_3.weight", "up4.conv2_4.weight", "up4.conv1_1.bias", "conv3.weight", "conv3.bias"],
+     ["bn1.running_mean", "bn2.running_var", "up1.bn1_1.running_mean", "up1.bn1_2.running_var", "up4.bn2.running_mean"]),
+    ("res50_aspp", "models/res_aspp.py", "res50_aspp", {"datasets": "kitti"},
+     ["Scale.conv1.weight", "Scale.layer1.0.conv1.weight", "Scale.layer2.0.conv1.weight", "Scale.layer2.0.downsample.0.weight",
+      "Scale.layer3.0.conv2.weight", "Scale.layer3.0.downsample.0.weight", "Scale.layer3.5.conv2.weight", "Scale.layer4.0.conv2.weight",
+      "Scale.layer4.2.conv3.weight", "Scale.layer5.conv2d_list.0.weight", "Scale.layer5.conv2d_list.1.bias", "Scale.layer5.conv2d_list.3.weight",
+      "Scale.bn1.weight"],
+     ["Scale.bn1.running_mean", "Scale.layer3.0.bn2.running_var", "Scale.layer4.2.bn3.running_mean"]),
+    ("deeplab", "models/ASPP.py", "deeplab_depth", {},
+     ["Scale.conv1.weight", "Scale.layer3.22.conv2.weight", "Scale.layer3.11.conv1.weight", "Scale.layer4.1.conv2.weight",
+      "Scale.layer5.conv2d_list.2.weight", "Scale.layer5.conv2d_list.0.bias"],
+     ["Scale.layer3.22.bn2.running_var"]),
+)
+
+
+def gold_zoo2(ref_loss):
+    """FCRN, res50_aspp, deeplab_depth: forward (one output at the input size, 2 x 64 x 96), l1 + 0.1 smooth backward (gradient summaries),
+    BatchNorm buffers, eval output, state_dict key list.  FCRN's Dropout2d draws from the RNG: its keep pattern is injected."""
+    b, h, w = 2, 64, 96
+    arrays = {}
+    for tag, rel, cls, kwargs, gkeys, bnkeys in ZOO2:
+        mod = _load("ref_zoo2_" + tag, rel)
+        net = getattr(mod, cls)(**kwargs)
+        detgen.fill_state_dict(net.state_dict(), "zoo2:" + tag)
+        if tag == "fcrn":
+            mask = detgen.bernoulli((b, 64), "zoo2:fcrn:drop", 0.5).float() * 2.0
+            net.drop = _FixedChannelMask(mask.view(b, 64, 1, 1))
+        x = detgen.image_batch(b, h, w, "zoo2:%s:x" % tag)
+        gt = detgen.sparse_depth(b, h, w, "zoo2:%s:gt" % tag, density=0.6, lo=0.3, hi=11.0)
+        net.train()
+        disps = net(x)
+        depth = [1 / d for d in disps]
+        loss = ref_loss.l1_loss(gt, depth, "kitti") + 0.1 * ref_loss.smooth_loss(depth)
+        loss.backward()
+        arrays[tag + ":loss"] = np.float64(loss.item())
+        arrays[tag + ":keys"] = np.array(sorted(net.state_dict().keys()))
+        arrays[tag + ":trainable"] = np.array(sorted(k for k, q in net.named_parameters() if q.requires_grad))
+        arrays[tag + ":disp0"] = _np(disps[0])
+        _grad_summaries(net, arrays, gkeys, prefix=tag + ":grad:")
+        sd = net.state_dict()
+        for key in bnkeys:
+            arrays["%s:bn:%s" % (tag, key)] = _np(sd[key])
+        net.eval()
+        with torch.no_grad():
+            arrays[tag + ":eval"] = _np(net(x))
+    save("zoo2", **arrays)
+
+
 def _reference_slice(rel, first, last, must_contain):
     """Source lines first..last (1-based, inclusive) of a reference file, dedented, for exec: the worst-pixel selection lives INLINE
     in test_disp.py's main() (it is not a function that could be imported), so the generator runs the reference's own statements on
@@ -794,6 +847,7 @@ def main():
         "config3": lambda: gold_config3(ref_vgg, ref_pose, ref_loss, ref_warp),
         "dorn80": lambda: gold_dorn80(ref_dorn, ref_utils, ref_loss),
         "zoo": lambda: gold_zoo(ref_loss),
+        "zoo2": lambda: gold_zoo2(ref_loss),
         "worst": lambda: gold_worst_pixels(ref_kitti),
     }
     for name, fn in sections.items():

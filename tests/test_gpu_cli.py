@@ -112,6 +112,20 @@ def test_train_cli_zoo_networks(tmp_path, network):
     assert key in sd["state_dict"]
 
 
+@pytest.mark.parametrize("network", ["FCRN", "res50_aspp"])
+def test_train_cli_fcrn_and_aspp_networks(tmp_path, network):
+    """The tail of SURVEY 8 f-4 through the command line (train.py:251-256): --network FCRN (up-projection blocks, one output at the
+    input size) and res50_aspp (dilated ResNet-50 + ASPP classifier, frozen BatchNorm affines) train and checkpoint with the
+    reference's keys; the frozen BatchNorm pairs of the ASPP net stay at their initial values."""
+    vals, sd, _ = _run_train(tmp_path, ["--network", network, "--loss", "L1", "--with-gt"], epochs=3)
+    assert vals[:, 0].min() > 0
+    key = {"FCRN": "up4.conv2_4.weight", "res50_aspp": "Scale.layer5.conv2d_list.3.weight"}[network]
+    assert key in sd["state_dict"]
+    if network == "res50_aspp":
+        assert torch.all(sd["state_dict"]["Scale.layer3.0.bn2.weight"] == 1) and torch.all(sd["state_dict"]["Scale.bn1.bias"] == 0)
+        assert not torch.all(sd["state_dict"]["Scale.layer3.0.bn2.running_mean"] == 0)       # ... while the statistics do move
+
+
 def test_train_cli_from_uint8_shards(tmp_path):
     """SURVEY 8 f-3 through the command line: scene folders -> tools/make_shards.py -> train.py --shards (GPU-side flip / /255 / normalise);
     validation keeps reading the scene folders."""

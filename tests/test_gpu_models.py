@@ -436,6 +436,59 @@ def test_model_zoo(golden, tag):
     close("%s:eval(golden)" % tag, e, g[tag + ":eval"], rtol=2e-3, atol_rel=2e-4)
 
 
+@pytest.mark.parametrize("tag", ["fcrn", "res50_aspp", "deeplab"])
+def test_model_zoo_fcrn_aspp(golden, tag):
+    """SURVEY 8 f-4 tail on the HIP engine: FCRN (eight-convolution up-projection blocks writing their phases into interleaved maps,
+    BatchNorm over the interleaved maps, ReLU-less BatchNorm, Dropout2d, align_corners resize) and the ASPP nets (stride on the 1x1,
+    dilated 3x3 with dilation 2 / 4, ceil-mode max-pool, frozen BatchNorm affines, the classifier's four dilated 2048 -> 1 convolutions
+    summed before the sigmoid): output and loss against the REFERENCE's own numbers, every trainable parameter's gradient against the
+    oracle with the fp64 yardstick, BatchNorm buffers, eval output."""
+    from tests.cases import zoo2_cases, zoo2_dropout_mask
+    g = golden("zoo2")
+    _, cls, kwargs, run = [c for c in zoo2_cases() if c[0] == tag][0]
+    net = getattr(models, cls)(**kwargs)
+    sd0 = _fresh(net, "zoo2:" + tag)
+    net.to(DEV).train()
+    b, h, w = 2, 64, 96
+    x = detgen.image_batch(b, h, w, "zoo2:%s:x" % tag)
+    gt = detgen.sparse_depth(b, h, w, "zoo2:%s:gt" % tag, density=0.6, lo=0.3, hi=11.0)
+    mask = zoo2_dropout_mask(tag)
+    if mask is not None:
+        net._dropout_mask = mask
+    disps = net(x.to(DEV))
+    assert isinstance(disps, list) and len(disps) == 1 and tuple(disps[0].shape) == (b, 1, h, w)
+    depth = [reciprocal(d) for d in disps]
+    loss = LF.l1_loss(gt.to(DEV), depth, "kitti") + 0.1 * LF.smooth_loss(depth)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g[tag + ":loss"]), rtol=2e-4)
+    close("%s:disp0(golden)" % tag, disps[0], g[tag + ":disp0"], rtol=2e-3, atol_rel=2e-4)
+    trainable = set(g[tag + ":trainable"].tolist())
+
+    def oparams(sd):
+        out = _oracle_params(sd)
+        for k, v in out.items():
+            if v.requires_grad and k not in trainable:
+                v.requires_grad_(False)
+        return out
+
+    osd = oparams(sd0)
+    odepth = [1 / d for d in run(osd, x, True, mask)]
+    (OL.l1_loss(gt, odepth, "kitti") + 0.1 * OL.smooth_loss(odepth)).backward()
+    osd64 = oparams({k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd0.items()})
+    d64 = [1 / d for d in run(osd64, x.double(), True, mask.double() if mask is not None else None)]
+    (OL.l1_loss(gt.double(), d64, "kitti") + 0.1 * OL.smooth_loss(d64)).backward()
+    # conv biases in front of a BatchNorm (FCRN's up-projection convolutions): the gradient is identically zero in exact arithmetic
+    # (rounding noise in the reference); the product stores what its kernels compute -- compared like any other parameter
+    _check_all_grads(net, osd, osd64=osd64, flip_allow=1.2e-2, total_allow=8e-3)
+    sd1 = net.state_dict()
+    for key in [k[len(tag) + 4:] for k in g.files if k.startswith(tag + ":bn:")]:
+        close(key, sd1[key], g["%s:bn:%s" % (tag, key)], rtol=1e-3, atol_rel=1e-4)
+    net.eval()
+    with torch.no_grad():
+        e = net(x.to(DEV))
+    close("%s:eval(golden)" % tag, e, g[tag + ":eval"], rtol=2e-3, atol_rel=2e-4)
+
+
 @pytest.mark.parametrize("tag", ["res18", "res6", "vgg"])
 def test_model_zoo_gradients_vs_fp64_yardstick(tag):
     """Every parameter gradient of the zoo nets at 2 x 128 x 416 (the KITTI training resolution): the HIP gradient is about as close

@@ -341,6 +341,41 @@ def test_model_zoo(golden, tag):
         _close(run(sd, x, False), g[tag + ":eval"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["fcrn", "res50_aspp", "deeplab"])
+def test_model_zoo_fcrn_aspp(golden, tag):
+    """SURVEY 8 f-4 tail: FCRN (up-projection blocks), res50_aspp / deeplab_depth (dilated bottlenecks, ceil-mode max-pool, summed ASPP
+    classifier, align_corners resize) -- the oracle restatement against the imported reference's own output, gradients, BatchNorm
+    buffers, eval output; the product's state_dict layout and its set of trainable parameters against the reference's."""
+    import supervised_dispnet_amd.models as models
+    from tests.cases import zoo2_cases, zoo2_dropout_mask
+    g = golden("zoo2")
+    _, cls, kwargs, run = [c for c in zoo2_cases() if c[0] == tag][0]
+    net = getattr(models, cls)(**kwargs)
+    assert sorted(net.state_dict().keys()) == sorted(g[tag + ":keys"].tolist())        # drop-in checkpoint layout
+    assert sorted(k for k, q in net.named_parameters() if q.requires_grad) == sorted(g[tag + ":trainable"].tolist())
+    assert sorted(id(q) for q in net._hot_parameters()) == sorted(id(q) for q in net.parameters() if q.requires_grad)
+    assert sorted(id(q) for q in net._grad_production_order()) == sorted(id(q) for q in net._hot_parameters())
+    sd = _params(_fresh_sd(net, "zoo2:" + tag))
+    trainable = set(g[tag + ":trainable"].tolist())
+    for k, v in sd.items():                                    # the ASPP nets freeze every BatchNorm's affine pair (models/ASPP.py:61-63)
+        if v.requires_grad and k not in trainable:
+            v.requires_grad_(False)
+    b, h, w = 2, 64, 96
+    x = detgen.image_batch(b, h, w, "zoo2:%s:x" % tag)
+    gt = detgen.sparse_depth(b, h, w, "zoo2:%s:gt" % tag, density=0.6, lo=0.3, hi=11.0)
+    disps = run(sd, x, True, zoo2_dropout_mask(tag))
+    depth = [1 / d for d in disps]
+    loss = losses.l1_loss(gt, depth, "kitti") + 0.1 * losses.smooth_loss(depth)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[tag + ":loss"], rtol=1e-5)
+    _close(disps[0], g[tag + ":disp0"], rtol=1e-4, atol=1e-5)
+    _grad_check(sd, g, prefix=tag + ":grad:")
+    for key in [k[len(tag) + 4:] for k in g.files if k.startswith(tag + ":bn:")]:
+        _close(sd[key], g["%s:bn:%s" % (tag, key)], rtol=1e-4, atol=1e-6)
+    with torch.no_grad():
+        _close(run(sd, x, False), g[tag + ":eval"], rtol=1e-4, atol=1e-5)
+
+
 def test_monodepth2_style_nets(golden):
     import supervised_dispnet_amd.models as models
     import supervised_dispnet_amd.networks as networks
