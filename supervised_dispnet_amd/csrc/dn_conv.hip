@@ -834,6 +834,409 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_u32_kernel(const IgemmParam
   conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
 }
 
+// ------------------------------------------------------------------------------ forward family, fp32 products on the bf16 matrix cores
+// igemm_conv_u32_kernel with DN_COMPUTE_F32X3 arithmetic: every fp32 operand value is split EXACTLY into three bf16
+// pieces and the six partial products of weight <= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (16x the fp32
+// instruction's rate).  Unlike the Winograd kernels, where each transformed value has exactly one consumer wave, a tile row here is read
+// by two waves, so the split is done ONCE by the staging thread (of A after the deferred BatchNorm-apply + ReLU, and of the packed fp32
+// weights -- the pack layout is unchanged) and LDS holds the pieces: [row][3 pieces][32 bf16] = 192 bytes per row, its 16-byte groups
+// rotated by (row >> 2) & 3 so that both the 8-byte staging stores and the per-lane ds_read_b128 fragment reads are bank-conflict free.
+// A 32-deep chunk is two 16-deep matrix steps; wave tiles are limited to 2 x 32 x 32 (two steps of pieces live in registers).  Operands
+// the scheduled loaders do not take (1-channel pieces, the 3-channel image, upsampled maps) keep the fp32 instruction on the same
+// accumulators (both instructions share the 32 x 32 C/D layout).
+constexpr int X3ROW = 192;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256, 2) igemm_conv_x3_kernel(const IgemmParams p) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+  static_assert(MI * NI <= 2, "the three-piece variant keeps two steps of operand pieces in registers: wave tiles of at most 2 x 32 x 32");
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                                        // [2][BM][X3ROW bytes]: per row three pieces x 32 bf16, 16-byte groups rotated by (row >> 2) & 3
+  char* AsB = reinterpret_cast<char*>(smem);
+  char* BsB = AsB + 2 * BM * X3ROW;                        // [2][BN][X3ROW bytes]
+  int* taps = reinterpret_cast<int*>(BsB + 2 * BN * X3ROW);   // [32]  (dy | dx<<16)
+  int* rowpix = taps + 32;                                 // [BM] output pixel index or -1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  // XCD-aware tile order.  Hardware places block b on XCD b % 8 (each XCD has its own 4 MiB L2): XCD x takes the CONTIGUOUS
+  // range [x*per, (x+1)*per) of logical tiles, enumerated N-tile fastest, so the N tiles that re-read one A row block and
+  // the neighbouring row blocks that share its halo rows are resident on the same L2 at the same time.
+  const int MT = (p.M + BM - 1) / BM, NT = p.Npad / BN;
+  const int per = (MT * NT + 7) >> 3;
+  const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;      // grid is rounded up to a multiple of 8 (block-uniform exit)
+  const int m0 = (q / NT) * BM, n0 = (q % NT) * BN;
+  const KPhase ph = p.ph[blockIdx.z];
+  const int ntaps = ph.ntaps;
+  const int Kp = ph.nchunks * kChunk;
+
+  if (tid < 32) taps[tid] = tid < ntaps ? (((int)p.tdy[ph.tap0 + tid] & 0xffff) | ((int)p.tdx[ph.tap0 + tid] << 16)) : 0;
+  for (int r = tid; r < BM; r += 256) {
+    int m = m0 + r, pix = -1;
+    if (m < p.M) {
+      unsigned gx, gy;
+      const unsigned t = fastdiv((unsigned)m, (unsigned)p.GW, p.mGW, &gx);
+      const int n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+      int oy = (int)gy * p.osy + ph.ooy, ox = (int)gx * p.osx + ph.oox;
+      if (oy < p.OH && ox < p.OW) pix = (n * p.OH + oy) * p.OW + ox;
+    }
+    rowpix[r] = pix;
+  }
+  __syncthreads();
+
+  // per-thread staging assignment: K group g (4 floats) of rows r0 + 32*i; per row a bit mask of the taps that land inside.
+  // The row coordinates are recomputed at each operand set-up instead of being kept live through the main loops.
+  const int g = tid & 7, r0 = tid >> 3;
+  auto row_coords = [&](int i, int* n, int* by, int* bx) {
+    const int m = m0 + r0 + 32 * i;
+    unsigned gx, gy;
+    const unsigned t = fastdiv(m < p.M ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+    *n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+    *by = (int)gy * p.sy;
+    *bx = (int)gx * p.sx;
+  };
+  unsigned vmask[AR];
+  {
+    int rn[AR], rby[AR], rbx[AR];
+    unsigned inside[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      row_coords(i, &rn[i], &rby[i], &rbx[i]);
+      inside[i] = 0u;
+    }
+    for (int j = 0; j < ntaps; ++j) {
+      const int tp = taps[j];
+      const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        inside[i] |= ((unsigned)(rby[i] + dy) < (unsigned)p.IH && (unsigned)(rbx[i] + dx) < (unsigned)p.IW) ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) vmask[i] = (m0 + r0 + 32 * i) < p.M ? inside[i] : 0u;
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const char* wrow = reinterpret_cast<const char*>(p.w + ph.w_off);   // advanced by one chunk (128 B) per iteration
+  unsigned boffB[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) boffB[i] = (unsigned)(((n0 + r0 + 32 * i) * Kp + g * 4) * 4);
+  // fp32 layout of the generic (unscheduled) operands, kept inside the same buffers: [rows][LDK floats]
+  const int stA = (r0 * LDK + g * 4) * 4;
+  const int frA = ((wm * WM + (lane & 31)) * LDK + (lane >> 5) * 4) * 4;
+  const int frB = ((wn * WN + (lane & 31)) * LDK + (lane >> 5) * 4) * 4;
+  constexpr int ABUF = BM * X3ROW, BBUF = BN * X3ROW;
+  constexpr int ROWS32 = 32 * LDK * 4;                       // byte distance of 32 tile rows (fp32 layout)
+  constexpr int XROWS32 = 32 * X3ROW;                        // ... (three-piece layout)
+  // three-piece layout: the thread's K group g (k 4g..4g+3) of row r0 + 32 i lands in 16-byte group (4 P + (g >> 1) + q) mod 12, half g & 1,
+  // q = (row >> 2) & 3 (the same for every i): rows 4 apart would otherwise share banks (192-byte rows)
+  int stX[3];
+  {
+    const int q = (r0 >> 2) & 3;
+#pragma unroll
+    for (int P = 0; P < 3; ++P) stX[P] = r0 * X3ROW + ((4 * P + (g >> 1) + q) % 12) * 16 + (g & 1) * 8;
+  }
+  // fragment read: lane (row lane & 31, k half lane >> 5) takes group 4 P + 2 s + h of step s
+  int frX[2][3];
+  {
+    const int q = ((lane & 31) >> 2) & 3;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int P = 0; P < 3; ++P) frX[st][P] = (lane & 31) * X3ROW + ((4 * P + 2 * st + (lane >> 5) + q) % 12) * 16;
+  }
+  const int frXA = wm * WM * X3ROW, frXB = wn * WN * X3ROW;
+
+  // slot schedule (compile-time): one chunk = two 16-deep steps of MI * NI * 6 matrix instructions
+  constexpr int NM = 12 * MI * NI;                 // matrix instructions per chunk
+  constexpr int NLD = AR + BR + 1;                 // load items (rows of A, scale / shift, rows of B)
+  constexpr int NS = AR + BR;                      // store-stage items (split + three 8-byte stores each)
+  constexpr int S0 = NM > NS ? NM - NS : 0;        // slot of the first store-stage item
+
+  int buf = 0;
+  for (int s = 0; s < p.n_in; ++s) {
+    const KOperand& S = p.in[s];
+    // UNI  : C % 32 == 0 -- a chunk is (one tap, 32 channels): tap and channel base are block-uniform scalars.
+    // !UNI : C in {4, 8, 16} -- a chunk is 32/C whole taps: the thread's K group sits in tap j0 + gt at channel ct, both fixed
+    //        per thread up to the uniform chunk base j0, so the tap word / validity bit / offset are per-thread VGPR values.
+    auto run_operand = [&](auto aff_tag, auto uni_tag) {
+      constexpr bool HA = decltype(aff_tag)::value;
+      constexpr bool UNI = decltype(uni_tag)::value;
+      // ---- operand set-up (block-uniform scalars + per-row base offsets)
+      const char* base = reinterpret_cast<const char*>(S.p);
+      const char* scp = reinterpret_cast<const char*>(S.scale);
+      const char* shp = reinterpret_cast<const char*>(S.shift);
+      const int sh = (int)S.sh, sw = (int)S.sw;
+      const int cpt = S.C >> 5;                       // UNI: chunks per tap
+      const int tpc = UNI ? 1 : 32 / S.C;             // !UNI: taps per chunk
+      const int nch = UNI ? ntaps * cpt : (ntaps + tpc - 1) / tpc;
+      const int gt = UNI ? 0 : (g * 4) / S.C;         // !UNI: this thread's tap within the chunk ...
+      const int ct = UNI ? g * 4 : (g * 4) % S.C;     //       ... and its channel
+      unsigned rowoffB[AR];
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int rn, rby, rbx;
+        row_coords(i, &rn, &rby, &rbx);
+        rowoffB[i] = (unsigned)((rn * (int)S.sn + rby * sh + rbx * sw + ct) * 4);
+      }
+
+      f32x4 av[AR], bv[BR], sc4, sh4;
+      bool aok[AR];
+      // cursor = the chunk whose loads are issued next: index cn = (tap j, chunk-in-tap cc); its tap word is fetched from LDS
+      // one iteration ahead and kept in a VGPR until decoded, so the scalar unit never waits inside the MFMA stream
+      int cn = 0, j = 0, cc = 0;          // UNI: j = tap, cc = chunk within the tap; !UNI: j = first tap of the chunk
+      int tapv = taps[UNI ? 0 : gt];
+      unsigned soffB = 0, jbit = 0, coffB = 0;
+      const char* wcur = wrow;
+
+      auto cursor_decode = [&]() {
+        const int tapword = UNI ? __builtin_amdgcn_readfirstlane(tapv) : tapv;
+        const int dy = (int)(short)(tapword & 0xffff), dx = tapword >> 16;
+        soffB = (unsigned)((dy * sh + dx * sw + cc * 32) * 4);
+        const int jt = j + gt;
+        jbit = jt < ntaps ? 1u << jt : 0u;
+        coffB = (unsigned)((cc * 32 + ct) * 4);
+        wcur = wrow;
+      };
+      auto cursor_advance = [&]() {      // clamps at the last chunk (the final iteration re-fetches it into the idle buffer: no branch)
+        const bool more = cn + 1 < nch;
+        cn += more ? 1 : 0;
+        if constexpr (UNI) {
+          const int cc1 = cc + 1;
+          const bool wrap = cc1 == cpt;
+          cc = more ? (wrap ? 0 : cc1) : cc;
+          j = (more && wrap) ? j + 1 : j;
+        } else {
+          j = more ? j + tpc : j;
+        }
+        wrow += more ? kChunk * 4 : 0;
+        const int jt = j + gt;
+        tapv = taps[jt < 32 ? jt : 31];
+      };
+      auto load_a = [&](int i) {
+        aok[i] = (vmask[i] & jbit) != 0u;
+        const unsigned off = aok[i] ? rowoffB[i] + soffB : 0u;
+        av[i] = *reinterpret_cast<const f32x4*>(base + off);
+      };
+      auto load_aff = [&]() {
+        sc4 = *reinterpret_cast<const f32x4*>(scp + coffB);
+        sh4 = *reinterpret_cast<const f32x4*>(shp + coffB);
+      };
+      auto load_b = [&](int i) { bv[i] = *reinterpret_cast<const f32x4*>(wcur + boffB[i]); };
+      // x = h + m + l exactly (three bf16 pieces: round, subtract, round, subtract); split ONCE here, by the staging
+      // thread -- every value is then read by two waves (the tile is 2 x 2 waves) as ready-made matrix operands
+      auto split_store = [&](char* dst, const f32x4& v) {
+        const bf16x2 h0 = __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2), h1 = __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2);
+        const f32x2 ra = f32x2{v[0], v[1]} - __builtin_convertvector(h0, f32x2), rb = f32x2{v[2], v[3]} - __builtin_convertvector(h1, f32x2);
+        const bf16x2 m0 = __builtin_convertvector(ra, bf16x2), m1 = __builtin_convertvector(rb, bf16x2);
+        const f32x2 sa = ra - __builtin_convertvector(m0, f32x2), sb = rb - __builtin_convertvector(m1, f32x2);
+        const bf16x2 l0 = __builtin_convertvector(sa, bf16x2), l1 = __builtin_convertvector(sb, bf16x2);
+        *reinterpret_cast<bf16x4*>(dst + stX[0]) = bf16x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<bf16x4*>(dst + stX[1]) = bf16x4{m0[0], m0[1], m1[0], m1[1]};
+        *reinterpret_cast<bf16x4*>(dst + stX[2]) = bf16x4{l0[0], l0[1], l1[0], l1[1]};
+      };
+      auto store_a = [&](int b, int i) {
+        f32x4 v = av[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = v[e];
+          if constexpr (HA) t = fmaxf(0.f, fmaf(t, sc4[e], sh4[e]));
+          v[e] = aok[i] ? t : 0.f;
+        }
+        split_store(AsB + b * ABUF + i * XROWS32, v);
+      };
+      auto store_b = [&](int b, int i) { split_store(BsB + b * BBUF + i * XROWS32, bv[i]); };
+
+      // pipeline fill for this operand (one exposed memory latency per operand)
+      cursor_decode();
+#pragma unroll
+      for (int i = 0; i < AR; ++i) load_a(i);
+      if constexpr (HA) load_aff();
+#pragma unroll
+      for (int i = 0; i < BR; ++i) load_b(i);
+#pragma unroll
+      for (int i = 0; i < AR; ++i) store_a(buf, i);
+#pragma unroll
+      for (int i = 0; i < BR; ++i) store_b(buf, i);
+      cursor_advance();
+      __syncthreads();
+
+      // (A variant with the store stage mid-iteration, the barrier right after the chunk's last fragment read and the next
+      //  chunk's first K group fetched under the last MFMAs measured the same 127-128 TFLOP/s: with two waves per SIMD the
+      //  partner wave already covers the LDS latency behind the barrier.  The simpler order is kept.)
+      for (int c = 0; c < nch; ++c) {
+        cursor_decode();                       // chunk min(c+1, nch-1); uses the tap word fetched during the previous iteration
+
+        const char* Ab = AsB + buf * ABUF + frXA;
+        const char* Bb = BsB + buf * BBUF + frXB;
+        bf16x8 pa[2][MI][3], pb[2][NI][3];
+        auto read_step = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int P = 0; P < 3; ++P) pa[st][i][P] = *reinterpret_cast<const bf16x8*>(Ab + i * XROWS32 + frX[st][P]);
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+            for (int P = 0; P < 3; ++P) pb[st][jn][P] = *reinterpret_cast<const bf16x8*>(Bb + jn * XROWS32 + frX[st][P]);
+        };
+        read_step(0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NM>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value;
+          constexpr int st = m / (6 * MI * NI), q = m % (6 * MI * NI);
+          constexpr int ij = q / 6, t = q % 6, i = ij / NI, jn = ij % NI;
+          // x0y2, x0y1, x1y1, x0y0, x1y0, x2y0 (the six partial products of weight <= 2^-16; smallest first)
+          constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[st][i][AS[t]], pb[st][jn][BS[t]], acc[i][jn], 0, 0, 0);
+          // ---- side work of this slot
+          if constexpr (m == 1) read_step(1);                 // the second step's operands, one step ahead
+          if constexpr (m < NLD || (NM < NLD && m == NM - 1)) {
+            // load items in order: rows of A, scale / shift, rows of B (all of what is left in the last slot of a short chunk)
+            constexpr int k0 = m, k1 = (NM < NLD && m == NM - 1) ? NLD : m + 1;
+            static_for<k1 - k0>([&](auto kc) __attribute__((always_inline)) {
+              constexpr int k = k0 + decltype(kc)::value;
+              if constexpr (k < AR) load_a(k);
+              else if constexpr (k == AR) { if constexpr (HA) load_aff(); }
+              else load_b(k - AR - 1);
+            });
+          }
+          if constexpr (m == (NM < NLD ? NM - 1 : NLD)) cursor_advance();   // after this chunk's loads are issued
+          if constexpr (m >= S0 || NM <= NS) {
+            constexpr int it0 = NM > NS ? m - S0 : (m * NS) / NM, it1 = NM > NS ? it0 + 1 : ((m + 1) * NS) / NM;
+            static_for<it1 - it0>([&](auto kc) __attribute__((always_inline)) {
+              constexpr int it = it0 + decltype(kc)::value;
+              if constexpr (it < AR) store_a(buf ^ 1, it);
+              else store_b(buf ^ 1, it - AR);
+            });
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+        buf ^= 1;
+      }
+      wrow += kChunk * 4;        // the cursor stopped on this operand's last chunk; the next operand's weights follow it
+    };
+    // Anything else (C = 1 disparity piece, the 3-channel NCHW image, upsampled or odd-width operands): plain gather, one
+    // barrier per chunk, no overlap.  These operands contribute one or two chunks to layers that are HBM-bound anyway.
+    auto run_operand_generic = [&]() {
+      const int nch = (ntaps * S.C + kChunk - 1) / kChunk;
+      // scalar operands are gathered PIXEL-major: thread = (row tid % BM, K slice tid / BM), so for one K element the lanes
+      // of a wave read neighbouring pixels (coalesced for the NCHW image and for 1-channel maps); float4 operands that the
+      // scheduled loaders do not take (odd widths, upsampled) keep the K-group-major assignment.
+      constexpr int KPT = kChunk / (256 / BM);             // K elements per thread per chunk (pixel-major)
+      const int prow = tid % BM, pk0 = (tid / BM) * KPT;
+      int pn, pby, pbx;
+      {
+        const int m = m0 + prow;
+        unsigned gx, gy;
+        const unsigned t = fastdiv(m < p.M ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+        pn = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+        pby = (int)gy * p.sy;
+        pbx = (int)gx * p.sx;
+      }
+      const bool plive = (m0 + prow) < p.M;
+      int rn[AR], rby[AR], rbx[AR];
+#pragma unroll
+      for (int i = 0; i < AR; ++i) row_coords(i, &rn[i], &rby[i], &rbx[i]);
+      for (int cl = 0; cl < nch; ++cl) {
+        if (!S.vec) {
+          float vals[KPT];
+#pragma unroll
+          for (int e = 0; e < KPT; ++e) {
+            const int k = cl * kChunk + pk0 + e;
+            unsigned c;
+            const int j = (int)fastdiv((unsigned)k, (unsigned)S.C, S.mC, &c);
+            float v = 0.f;
+            if (j < ntaps) {
+              const int tp = taps[j];
+              const int iy = pby + (int)(short)(tp & 0xffff), ix = pbx + (tp >> 16);
+              if (plive && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+                v = S.p[(long long)pn * S.sn + (long long)(iy >> S.up) * S.sh + (long long)(ix >> S.up) * S.sw + (long long)c * S.sc];
+                if (S.scale) v = fmaxf(0.f, v * S.scale[c] + S.shift[c]);
+              }
+            }
+            vals[e] = v;
+          }
+#pragma unroll
+          for (int e = 0; e < KPT; e += 4)
+            *reinterpret_cast<f32x4*>(AsB + buf * ABUF + (prow * LDK + pk0 + e) * 4) = f32x4{vals[e], vals[e + 1], vals[e + 2], vals[e + 3]};
+        } else {
+          const int kl = cl * kChunk + g * 4;
+          const int jv = kl / S.C, cv = kl - jv * S.C;
+          f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, sh4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          bool aff = false;
+          if (S.scale != nullptr && jv < ntaps) {
+            sc4 = *reinterpret_cast<const f32x4*>(S.scale + cv);
+            sh4 = *reinterpret_cast<const f32x4*>(S.shift + cv);
+            aff = true;
+          }
+#pragma unroll
+          for (int i = 0; i < AR; ++i) {
+            AGroup a = gather4(S, kl, ntaps, taps, rn[i], rby[i], rbx[i], (m0 + r0 + 32 * i) < p.M, p.IH, p.IW, jv, cv, 0);
+            f32x4 v = a.v;
+            if (aff) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * sc4[e] + sh4[e]);
+            }
+            if (!a.ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(AsB + buf * ABUF + stA + i * ROWS32) = v;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+          *reinterpret_cast<f32x4*>(BsB + buf * BBUF + stA + i * ROWS32) = *reinterpret_cast<const f32x4*>(wrow + boffB[i]);
+        wrow += kChunk * 4;
+        __syncthreads();
+        const char* Ab = AsB + buf * ABUF + frA;
+        const char* Bb = BsB + buf * BBUF + frB;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          f32x4 fa[MI], fb[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * ROWS32 + kg * 32);
+#pragma unroll
+          for (int jn = 0; jn < NI; ++jn) fb[jn] = *reinterpret_cast<const f32x4*>(Bb + jn * ROWS32 + kg * 32);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[jn][kk], acc[i][jn], 0, 0, 0);
+        }
+        buf ^= 1;      // the next chunk fills the other buffer; the barrier above orders it against this chunk's readers
+      }
+      __syncthreads();
+    };
+    if (ntaps == 0) continue;       // empty phase of a strided scatter (e.g. 1x1 stride 2): the result is bias/activation only
+    const bool fast = S.vec && S.small && S.up == 0;
+    if (fast && S.C % 32 == 0) {
+      if (S.scale != nullptr) run_operand(std::true_type{}, std::true_type{});
+      else run_operand(std::false_type{}, std::true_type{});
+    } else if (fast && (S.C == 4 || S.C == 8 || S.C == 16)) {
+      if (S.scale != nullptr) run_operand(std::true_type{}, std::false_type{});
+      else run_operand(std::false_type{}, std::false_type{});
+    } else {
+      run_operand_generic();
+    }
+  }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
+}
+
 // ------------------------------------------------------------------------------------------------ first layer (stem)
 // conv3x3 of a <= 4-channel image (the NCHW user tensor through its strides) to 64 channels, torchvision vgg16_bn features[0]:
 // K = 27 is one MFMA chunk, so on the tiled kernel a block's whole "main loop" is a single barrier-bound iteration and the launch
@@ -1540,6 +1943,19 @@ static int launch_conv_u32(const IgemmParams& p, hipStream_t stream) {
 }
 
 template <int BM, int BN, int WM, int WN>
+static int launch_conv_x3(const IgemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)(2 * BM + 2 * BN) * X3ROW + (32 + BM) * sizeof(int);
+  auto kernel = igemm_conv_x3_kernel<BM, BN, WM, WN>;
+  int rc = enable_big_lds(kernel, lds);
+  if (rc != DN_OK) return rc;
+  const int tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+  dim3 grid((tiles + 7) / 8 * 8, 1, p.nphases);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  set_last_kernel("dn::igemm_conv_x3_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
+  return check_launch("igemm_conv_x3_kernel");
+}
+
+template <int BM, int BN, int WM, int WN>
 static int launch_conv(const IgemmParams& p, hipStream_t stream) {
   if (p.uni32 && !knobs().no_u32)
     return launch_conv_u32<BM, BN, WM, WN>(p, stream);
@@ -1574,6 +1990,16 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
   // bn_partial layout is per 128-row tile.
   const long long blocks128 = (long long)((p.M + 127) / 128) * (p.Npad / p.BN) * p.nphases;
   const bool small_m = p.uni32 && p.bn_partial == nullptr && blocks128 <= 208 && !knobs().no_bm64;
+  if (p.compute == DN_COMPUTE_F32X3 && p.uni32 && !knobs().no_u32 && !knobs().no_x3_direct && p.BN >= 64) {
+    // (the 32-wide N tile -- one 32 x 32 tile per wave, 12 matrix instructions per chunk against five split-and-store items -- measured
+    //  4-17 % slower than the fp32 instruction: it stays on that)
+    // fp32 products on the bf16 matrix cores (wave tiles of at most 2 x 32 x 32: the 128-wide N tile runs as 64-row blocks)
+    switch (p.BN) {
+      case 128: return p.bn_partial == nullptr ? launch_conv_x3<64, 128, 32, 64>(p, s) : launch_conv_x3<128, 64, 64, 32>(p, s);   // (statistics rows are per 128-row tile)
+      case 64: return (small_m || p.bn_partial == nullptr && blocks128 <= 416) ? launch_conv_x3<64, 64, 32, 32>(p, s) : launch_conv_x3<128, 64, 64, 32>(p, s);
+      default: return launch_conv_x3<128, 32, 32, 32>(p, s);
+    }
+  }
   switch (p.BN) {
     case 128: return small_m ? launch_conv_u32<64, 128, 32, 64>(p, s) : launch_conv<128, 128, 64, 64>(p, s);
     case 64: return small_m ? launch_conv_u32<64, 64, 32, 32>(p, s) : launch_conv<128, 64, 64, 32>(p, s);

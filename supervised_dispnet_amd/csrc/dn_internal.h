@@ -22,6 +22,7 @@ struct Knobs {
   int wino_dbg, wino_mtw, wino_wg_dbg;   // DN_WINO_DBG / DN_WINO_MTW / DN_WINO_WG_DBG: ablation variants (tools/wino_timing.py)
   unsigned long long wino_dbgptr;
   int wino_min_tiles;       // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (default 192)
+  bool no_x3_direct;        // DN_NO_X3_DIRECT: keep the fp32 matrix instruction in the direct (implicit-GEMM) forward family under DN_COMPUTE_F32X3
   int wino8, wino8_min_k;   // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel; DN_WINO8_MIN_K: its rule's channel floor
 };
 const Knobs& knobs();

@@ -98,6 +98,7 @@ static void read_knobs(Knobs* k) {
   k->wino_wg_dbg = num("DN_WINO_WG_DBG", 0);
   k->wino_dbgptr = getenv("DN_WINO_DBGPTR") ? strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0) : 0ull;
   k->wino_min_tiles = num("DN_WINO_MIN_TILES", 192);
+  k->no_x3_direct = on("DN_NO_X3_DIRECT");
   k->wino8 = num("DN_WINO8", -1);
   k->wino8_min_k = num("DN_WINO8_MIN_K", 128);
 }
