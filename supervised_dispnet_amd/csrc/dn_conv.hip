@@ -2101,7 +2101,7 @@ int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int3
   const PackEntry* tab = reinterpret_cast<const PackEntry*>(entries_dev);
   hipStream_t s = as_stream(stream);
   if (n_direct > 0) {
-    hipLaunchKernelGGL(pack_weights_many_kernel, dim3(64, n_direct), dim3(256), 0, s, tab);
+    hipLaunchKernelGGL(pack_weights_many_kernel, dim3(knobs().pack_blocks, n_direct), dim3(256), 0, s, tab);
     int rc = check_launch("pack_weights_many_kernel");
     if (rc != DN_OK) return rc;
   }

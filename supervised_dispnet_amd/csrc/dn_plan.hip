@@ -99,6 +99,8 @@ static void read_knobs(Knobs* k) {
   k->wino_dbgptr = getenv("DN_WINO_DBGPTR") ? strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0) : 0ull;
   k->wino_min_tiles = num("DN_WINO_MIN_TILES", 192);
   k->no_x3_direct = on("DN_NO_X3_DIRECT");
+  k->pack_blocks = num("DN_PACK_BLOCKS", 512);
+  if (k->pack_blocks < 1) k->pack_blocks = 1;
   k->wino8 = num("DN_WINO8", -1);
   k->wino8_min_k = num("DN_WINO8_MIN_K", 128);
 }

@@ -157,7 +157,7 @@ __global__ void wino_pack_many_kernel(const PackEntry* __restrict__ tab) {
 }
 
 int launch_wino_pack_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(wino_pack_many_kernel, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
+  hipLaunchKernelGGL(wino_pack_many_kernel, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
   return check_launch("wino_pack_many_kernel");
 }
 
@@ -254,8 +254,8 @@ __global__ void wino_pack16_many_kernel(const PackEntry* __restrict__ tab) {
 }
 
 int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, int pieces, hipStream_t stream) {
-  if (pieces == 3) hipLaunchKernelGGL(wino_pack16_many_kernel<3>, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
-  else hipLaunchKernelGGL(wino_pack16_many_kernel<1>, dim3(128, n), dim3(256), 0, stream, tab_dev + first);
+  if (pieces == 3) hipLaunchKernelGGL(wino_pack16_many_kernel<3>, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
+  else hipLaunchKernelGGL(wino_pack16_many_kernel<1>, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
   return check_launch("wino_pack16_many_kernel");
 }
 
