@@ -628,6 +628,22 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
           if constexpr (j < 3 && q12 == 1) read_raw(Ab, j + 1);
           if constexpr (j < 3 && q12 >= 6 * MTW && q12 < 10 * MTW) split_pair((j + 1) & 1, (q12 - 6 * MTW) / 4, (q12 - 6 * MTW) % 4);
           constexpr bool STG = !(DBG & 64);                       // (DBG 64: ablation without the staging of the next chunk)
+          if constexpr (MTW == 1 && !(DBG & 256)) {
+            // round 3 (measured on the 8-wave form, dn_winograd8.hip): the 16 patch loads on every OTHER slot instead of back to back --
+            // a wave whose load finds the vector-memory queue full stalls in order, with its matrix instructions behind it --, the
+            // clamp / row / column transform + stores packed into the last fourteen slots
+            if constexpr (STG && m >= 1 && m < 33 && (m & 1)) load_v_t((m - 1) / 2, std::false_type{}, lmask);
+            if constexpr (STG && m == 2) load_aff();
+            if constexpr (STG && m >= 34 && m < 38) {
+#pragma unroll
+              for (int u4 = 0; u4 < 4; ++u4) affine_piece(4 * (m - 34) + u4);
+            }
+            if constexpr (STG && m >= 38 && m < 40) {
+              row_piece(2 * (m - 38));
+              row_piece(2 * (m - 38) + 1);
+            }
+            if constexpr (STG && m >= 40 && m < 48) col_piece(buf ^ 1, (m - 40) / 2, (m - 40) % 2);
+          } else {
           if constexpr (STG && m >= 2 && m < 18) load_v_t(m - 2, std::false_type{}, lmask);
           if constexpr (STG && m == 18) load_aff();
           // transform + stores of the next chunk: 16 affine pieces, 4 row pieces, 8 column pieces from slot 22 MTW on
@@ -642,6 +658,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
           }
           if constexpr (STG && m >= R0 && m < R0 + 4) row_piece(m - R0);
           if constexpr (STG && m >= C0 && m < C0 + 8) col_piece(buf ^ 1, (m - C0) / 2, (m - C0) % 2);
+          }
           __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (!(DBG & 32)) load_b3(3 * 7 + 2 + WRING);      // successor of the last unit's piece 0
