@@ -126,6 +126,18 @@ typedef struct dn_conv_desc {
   int32_t dilation;                /* 0 / 1: none.  d > 1: nn.Conv2d(dilation = d) -- kernel tap (r, s) reads input offset
                                       (r*d - pad, s*d - pad) (models/ASPP.py:62-72,107-113: the dilated bottlenecks and the ASPP
                                       classifier).  Stride-1 DN_CONV_FWD / DN_CONV_DGRAD and their weight gradient, zero padding. */
+  /* Optional, DN_CONV_DGRAD only (round 3): the column sums of the BatchNorm backward of the layer BELOW, taken in this call's epilogue.
+   * The input gradient dx written here is dL/d(relu(bn(y))) of the producer of this layer's input; with bnb_y .. bnb_invstd set ([pixels][C]
+   * dense like the result, [C] vectors) every 128-pixel tile also writes bnb_partial[tile][C][2] = (sum dz, sum dz * xhat),
+   * dz = dx * [y * scale + shift > 0], xhat = (y - mean) * invstd -- exactly what dn_bn_relu_bwd_sums computes in a separate pass over dx
+   * and y (one full read of dx and one launch saved per layer); rows = dn_conv_bn_partial_rows().  Honoured only where
+   * dn_conv_dgrad_fuses_bn_sums() returns 1 (the Winograd input-gradient kernels, single non-accumulating result); otherwise ignored. */
+  const float* bnb_y;
+  const float* bnb_scale;
+  const float* bnb_shift;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  float* bnb_partial;
 } dn_conv_desc;
 
 enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2 };
@@ -153,6 +165,8 @@ int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int3
 int32_t dn_conv_weight_layout(const dn_conv_desc* d);
 /* Number of row tiles (first dimension of bn_partial) the launch of this descriptor uses. */
 int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d);
+/* 1 if dn_conv2d_dgrad(d) will write bnb_partial (see dn_conv_desc), 0 if it ignores the bnb_* fields, < 0 on a bad descriptor. */
+int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d);
 /* Enqueue the convolution described by d. */
 int dn_conv2d_fwd(const dn_conv_desc* d, dn_stream_t stream);      /* kind == DN_CONV_FWD */
 int dn_conv2d_dgrad(const dn_conv_desc* d, dn_stream_t stream);    /* kind == DN_CONV_DGRAD */

@@ -23,6 +23,7 @@ struct Knobs {
   unsigned long long wino_dbgptr;
   int wino_min_tiles;       // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (default 192)
   bool no_x3_direct;        // DN_NO_X3_DIRECT: keep the fp32 matrix instruction in the direct (implicit-GEMM) forward family under DN_COMPUTE_F32X3
+  bool no_bn_sums_fusion;   // DN_NO_BN_SUMS_FUSION: dn_conv_dgrad_fuses_bn_sums() answers 0 (the engine then runs the separate sums pass)
   int pack_blocks;          // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
   int wino8, wino8_min_k;   // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel; DN_WINO8_MIN_K: its rule's channel floor
 };
@@ -105,6 +106,9 @@ struct IgemmParams {
   int compute;                   // DN_COMPUTE_F32 / _BF16 / _F32X3 (descriptor field; honoured by the Winograd forward / input gradient)
   int tile_store;                // epilogue may stage the result tile in LDS and store whole pixels (off: DN_NO_TILE_STORE)
   // Winograd F(2x2,3x3) launches only (dn_winograd.hip)
+  // BatchNorm-backward column sums of the producer, taken in the input gradient's epilogue (dn_conv_desc.bnb_*; Winograd kernels only)
+  const float *bnb_y, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
+  float* bnb_partial;
   int T, TH, TW;                 // 2x2 output tiles: total, per image column / row
   unsigned mTW, mTH;             // fastdiv magics
 };

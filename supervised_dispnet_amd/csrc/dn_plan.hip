@@ -99,6 +99,7 @@ static void read_knobs(Knobs* k) {
   k->wino_dbgptr = getenv("DN_WINO_DBGPTR") ? strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0) : 0ull;
   k->wino_min_tiles = num("DN_WINO_MIN_TILES", 192);
   k->no_x3_direct = on("DN_NO_X3_DIRECT");
+  k->no_bn_sums_fusion = on("DN_NO_BN_SUMS_FUSION");
   k->pack_blocks = num("DN_PACK_BLOCKS", 512);
   if (k->pack_blocks < 1) k->pack_blocks = 1;
   k->wino8 = num("DN_WINO8", -1);
@@ -138,6 +139,15 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   p->bias = d->bias;
   p->w = d->w_packed;
   p->bn_partial = d->bn_partial;
+  if (d->kind == DN_CONV_DGRAD && !for_wgrad && d->bnb_y != nullptr && d->bnb_partial != nullptr) {
+    DN_REQUIRE(d->bnb_scale && d->bnb_shift && d->bnb_mean && d->bnb_invstd, DN_ERR_BAD_ARG, "bnb_y needs scale / shift / mean / invstd");
+    p->bnb_y = d->bnb_y;
+    p->bnb_scale = d->bnb_scale;
+    p->bnb_shift = d->bnb_shift;
+    p->bnb_mean = d->bnb_mean;
+    p->bnb_invstd = d->bnb_invstd;
+    p->bnb_partial = d->bnb_partial;
+  }
   const int st = d->stride, pad = d->pad;
   const int dil = d->dilation > 1 ? d->dilation : 1;
   DN_REQUIRE(d->pad_mode == 0 || d->pad_mode == 1, DN_ERR_BAD_ARG, "bad pad_mode %d", d->pad_mode);
@@ -340,7 +350,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 7; }
+int dn_version(void) { return 8; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);
@@ -384,6 +394,17 @@ int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (dn::build_plan(d, false, &p) != DN_OK) return -1;
   return (p.M + 127) / 128;
+}
+
+int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d) {
+  dn::IgemmParams p;
+  if (d == nullptr || dn::build_plan(d, false, &p) != DN_OK) return -1;
+  if (d->kind != DN_CONV_DGRAD || dn::knobs().no_bn_sums_fusion) return 0;
+  if (dn::wino_layout(d, p) == 0) return 0;
+  const dn_result& r = d->out[0];
+  const bool dense = d->n_out == 1 && !r.accumulate && (r.C & 3) == 0 && r.stride_w == r.C && r.stride_h == (int64_t)d->OW * r.C &&
+                     r.stride_n == (int64_t)d->OH * d->OW * r.C;
+  return (dense && d->bias == nullptr && d->act == DN_ACT_NONE) ? 1 : 0;
 }
 
 // Test/diagnostic hook (host only, no device work): dump the plan as int32s.

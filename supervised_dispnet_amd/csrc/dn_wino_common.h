@@ -66,6 +66,81 @@ __device__ __forceinline__ typename VecOf<VW>::type buffer_load_vec(__amdgpu_buf
 }
 
 
+
+// BatchNorm-backward column sums of the layer below, from the input-gradient tile a Winograd block has just produced (dn_conv_desc.bnb_*):
+// thread (tg, c4) holds Y[k][a][b] = dx of pixels (a, b) of tiles tg + TSTEP * k, channels n_first .. n_first + 3.  Per 32-tile group g of
+// the block:  bnb_partial[groups_per_block * mb + g][n][0 .. 1] = (sum dz, sum dz * xhat),  dz = dx * [y * scale + shift > 0].  `red`: LDS
+// scratch of GROUPS * NWAVES * 64 * 2 floats (free after the output exchange); fixed summation order.
+template <int NK, int TSTEP, int NWAVES, int GROUPS>
+__device__ __forceinline__ void wino_bn_bwd_sums(const IgemmParams& p, const f32x4 (&Y)[NK][2][2], int mb, int tg, int c4, int wave, int lane, int tid,
+                                                 int n_first, float* red) {
+  constexpr int BT = 32 * GROUPS;
+  f32x4 s1[GROUPS], s2[GROUPS];
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) s1[g] = s2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (n_first < p.Ntot) {
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.bnb_scale + n_first), sh = *reinterpret_cast<const f32x4*>(p.bnb_shift + n_first);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_mean + n_first), is = *reinterpret_cast<const f32x4*>(p.bnb_invstd + n_first);
+    const long long C = p.Ntot, rowB = (long long)p.OW * C;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int t = mb * BT + tg + TSTEP * k;
+      if (t < p.T) {
+        unsigned tx, ty;
+        const unsigned r = fastdiv_dev((unsigned)t, (unsigned)p.TW, p.mTW, &tx);
+        const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
+        const float* y00 = p.bnb_y + (((long long)n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * C + n_first;
+        const f32x4 yv[2][2] = {{*reinterpret_cast<const f32x4*>(y00), *reinterpret_cast<const f32x4*>(y00 + C)},
+                                {*reinterpret_cast<const f32x4*>(y00 + rowB), *reinterpret_cast<const f32x4*>(y00 + rowB + C)}};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float yy = yv[a][b][e];
+              const float dz = (yy * sc[e] + sh[e] > 0.f) ? Y[k][a][b][e] : 0.f;
+              s1[(k * TSTEP) / 32][e] += dz;
+              s2[(k * TSTEP) / 32][e] += dz * (yy - mu[e]) * is[e];
+            }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[g][e] += __shfl_xor(s1[g][e], 16);
+      s1[g][e] += __shfl_xor(s1[g][e], 32);
+      s2[g][e] += __shfl_xor(s2[g][e], 16);
+      s2[g][e] += __shfl_xor(s2[g][e], 32);
+    }
+  __syncthreads();
+  if (lane < 16) {
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+      *reinterpret_cast<f32x4*>(red + ((g * NWAVES + wave) * 2 + 0) * 64 + 4 * c4) = s1[g];
+      *reinterpret_cast<f32x4*>(red + ((g * NWAVES + wave) * 2 + 1) * 64 + 4 * c4) = s2[g];
+    }
+  }
+  __syncthreads();
+  if (tid < 64 * GROUPS) {
+    const int g = tid >> 6, col = tid & 63;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+      a1 += red[((g * NWAVES + w) * 2 + 0) * 64 + col];
+      a2 += red[((g * NWAVES + w) * 2 + 1) * 64 + col];
+    }
+    const int n = (n_first - 4 * c4) + col;           // nb * WBN + col
+    if (n < p.Ntot && mb * BT + 32 * g < p.T) {
+      float* dst = p.bnb_partial + ((long long)(GROUPS * mb + g) * p.Ntot + n) * 2;
+      dst[0] = a1;
+      dst[1] = a2;
+    }
+  }
+}
+
 // dn_winograd8.hip: the 8-wave / one-block-per-CU form of the three-piece kernel (64 tiles x 64 output channels, two positions per wave)
 bool wino8_wanted(const IgemmParams& p);
 int launch_wino_conv8(const IgemmParams& p, hipStream_t stream);

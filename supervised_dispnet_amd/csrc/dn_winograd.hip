@@ -868,6 +868,9 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     }
   }
 
+  if (p.bnb_y != nullptr)                // (input gradient: the BatchNorm backward's column sums of the layer below)
+    wino_bn_bwd_sums<NK, 16, 4, MTW>(p, Y, mb, tg, c4, wave, lane, tid, n_first, smem + 4 * BT * WZLD);
+
   if (DBG & 4) te2 = clock64();
   // ---- bias, activation, channel-split / accumulating stores: float4 along the channels when the four columns lie in one
   //      float4-addressable result, element-wise otherwise (the 1-channel disparity piece of a concat's input gradient)
@@ -983,7 +986,7 @@ static int launch_wino_variant(const IgemmParams& p, hipStream_t stream) {
   auto kernel = wino_conv_kernel<MTW, HA, DBG, PREC>;
   // PREC 1: two 16-channel chunks of bf16 planes, or the epilogue's cross-wave exchange + statistics scratch, whichever is larger
   constexpr size_t lds16a = (size_t)2 * 16 * Cfg::BT * W16_ROWB;
-  constexpr size_t lds16b = (size_t)(4 * Cfg::BT * WZLD + MTW * 5 * 64) * sizeof(float);
+  constexpr size_t lds16b = (size_t)(4 * Cfg::BT * WZLD + MTW * 8 * 64) * sizeof(float);
   constexpr size_t lds = PREC == 1 ? (lds16a > lds16b ? lds16a : lds16b) : Cfg::LDS;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {

@@ -28,7 +28,7 @@ namespace dn {
 namespace {
 constexpr int BT8 = 64;                                   // tiles per block
 constexpr size_t kXchgBytes = (size_t)8 * BT8 * WZLD * sizeof(float);        // 2 halves b x 4 transform rows x [64 tiles][72]
-constexpr size_t kStatBytes = (size_t)(2 * 8 * 64 + 2 * 64) * sizeof(float); // [2 tile groups][8 waves][64 couts] + group means
+constexpr size_t kStatBytes = (size_t)(2 * 8 * 2 * 64) * sizeof(float);    // [2 tile groups][8 waves][2][64 couts]: statistics (+ group means) or the BatchNorm-backward sums
 constexpr size_t kLds8 = kXchgBytes + kStatBytes;
 static_assert(kLds8 >= WinoCfg<2>::LDS, "the epilogue's exchange area must cover the main loop's two chunk buffers");
 static_assert(kLds8 <= 160 * 1024, "one CU has 160 KB of LDS");
@@ -259,9 +259,11 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
         if constexpr (a < 3 && q12 == 1 && !(DBG & 512)) read_raw(Ab, a + 1);
         if constexpr (a < 3 && q12 >= 6 && q12 < 10) split_pair((a + 1) & 1, q12 - 6);
         constexpr bool STG = !(DBG & 64);                 // (DBG 64: ablation without the staging of the next chunk)
-        constexpr int SCHED = (DBG & 1024) ? 0 : ((DBG & 2048) ? 2 : ((DBG & 4096) ? 3 : 1));   // staging slot schedules (1 = shipped; others: measurements)
-        // 0: loads 2..17, clamp 22..29, rows 30..33, cols 34..41        1: loads on odd slots 1..31, clamp 34..37 (4 per slot), rows 38..39, cols 40..47
-        // 2: loads 0..15, clamp 28..35, rows 36..39, cols 40..47        3: loads 0..7 (2 per slot), clamp 28..35, rows 36..39, cols 40..47
+        constexpr int SCHED = (DBG & 1024) ? 0 : 1;   // staging slot schedules (1 = shipped; others: measurements)
+        // 0 (DN_WINO_DBG=1028, the round-2 schedule, kept for A/B timing): loads 2..17, clamp 22..29, rows 30..33, cols 34..41
+        // 1 (shipped): loads on odd slots 1..31, clamp 34..37 (4 per slot), rows 38..39, cols 40..47: 5686 -> 5354 cycles per chunk.
+        // Also measured: loads 0..15 + transform 28..47 (5607), two loads per slot 0..7 (5697), s_setprio asymmetry between the two
+        // waves of a SIMD (no change)
         if constexpr (SCHED == 0) {
           if constexpr (STG && m >= 2 && m < 18) load_v_t(m - 2, std::false_type{}, lmask);
           if constexpr (STG && m == 18) load_aff();
@@ -283,22 +285,6 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
             row_piece(2 * (m - 38));
             row_piece(2 * (m - 38) + 1);
           }
-          if constexpr (STG && m >= 40 && m < 48) col_piece(buf ^ 1, (m - 40) / 2, (m - 40) % 2);
-        } else {
-          if constexpr (SCHED == 2) {
-            if constexpr (STG && m < 16) load_v_t(m, std::false_type{}, lmask);
-          } else {
-            if constexpr (STG && m < 8) {
-              load_v_t(2 * m, std::false_type{}, lmask);
-              load_v_t(2 * m + 1, std::false_type{}, lmask);
-            }
-          }
-          if constexpr (STG && m == 16) load_aff();
-          if constexpr (STG && m >= 28 && m < 36) {
-            affine_piece(2 * (m - 28));
-            affine_piece(2 * (m - 28) + 1);
-          }
-          if constexpr (STG && m >= 36 && m < 40) row_piece(m - 36);
           if constexpr (STG && m >= 40 && m < 48) col_piece(buf ^ 1, (m - 40) / 2, (m - 40) % 2);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -459,6 +445,9 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     }
   }
 
+  if (p.bnb_y != nullptr)                // (input gradient: the BatchNorm backward's column sums of the layer below)
+    wino_bn_bwd_sums<NK, 32, 8, 2>(p, Y, mb, tg, c4, wave, lane, tid, n_first, smem + 8 * BT * WZLD);
+
   if (DBG & 4) te2 = clock64();
   // ---- bias, activation, channel-split / accumulating stores (as in the 4-wave kernel)
   if (n_first < p.Ntot) {
@@ -598,7 +587,7 @@ int launch_wino_conv8(const IgemmParams& p, hipStream_t stream) {
     switch (dbg) {
 #define DN_W8_CASE(D) case D: return launch_wino8_variant<false, D>(q, stream);
       DN_W8_CASE(4 + 16) DN_W8_CASE(4 + 32) DN_W8_CASE(4 + 64) DN_W8_CASE(4 + 256) DN_W8_CASE(4 + 512) DN_W8_CASE(4 + 16 + 64) DN_W8_CASE(4 + 16 + 32 + 64)
-      DN_W8_CASE(4 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 256 + 16) DN_W8_CASE(4 + 256 + 64) DN_W8_CASE(4 + 256 + 16 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 1024) DN_W8_CASE(4 + 2048) DN_W8_CASE(4 + 4096)
+      DN_W8_CASE(4 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 256 + 16) DN_W8_CASE(4 + 256 + 64) DN_W8_CASE(4 + 256 + 16 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 1024)
 #undef DN_W8_CASE
       default: break;
     }

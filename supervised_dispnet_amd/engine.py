@@ -37,6 +37,7 @@ PARAM_EPOCH = 0
 PROFILE = None
 
 # DN_BN_MATERIALIZE=1: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back) for A/B runs and the equivalence test
+BN_SUMS_FUSION = os.environ.get("DN_NO_BN_SUMS_FUSION") is None     # input-gradient kernels take the BatchNorm backward's column sums of the layer below
 BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
 
 # Arithmetic of the matrix-core kernels that offer a choice (dn_conv_desc.compute, include/dispnet_hip.h), today the Winograd forward /
@@ -240,7 +241,7 @@ def require_cuda(t, what):
 class Act:
     """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
     __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
-                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar", "pool_src")
+                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar", "pool_src", "sums_ready")
 
     def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
         self.t = t
@@ -253,6 +254,8 @@ class Act:
         self.partial_stride, self.partial_offset = 2, 0
         self.no_relu = False            # pending BatchNorm affine WITHOUT ReLU (bottleneck bn3 / downsample BN): only
                                         # block_bn_add_relu may consume it
+        self.sums_ready = False         # .partial already holds the BatchNorm backward's column sums of .grad (taken in the epilogue of the
+                                        # input-gradient kernel that wrote .grad: conv_dgrad / dn_conv_desc.bnb_*)
         self.pool_src = None            # (dpooled, idx): the gradient arrives through a 2x2 max-pool and is expanded by the BatchNorm
                                         # backward itself (dn_bn_bwd_apply_pool); .grad is then only the destination buffer
         self.planar = False             # .t is [N,C,H,W] (a network OUTPUT the caller's API wants planar: ord_c1, decode_c)
@@ -620,15 +623,38 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
             first = a.grad is None
             if first:
                 a.grad = a.new_like()
+            else:
+                a.sums_ready = False    # a second consumer adds to this gradient: sums taken by the first writer no longer describe it
             _fill_result(d.out[i], a.grad, a.C, IH, IW, not first)
     d.w_packed = layer.packed(kind, d).data_ptr()
     d.bias = None
     d.act = ACT_NONE
+    # BatchNorm backward of the layer below: when this call is the (first) writer of the gradient of a pre-BatchNorm activation with a
+    # pending BN + ReLU, let its epilogue take the column sums (sum dz, sum dz * xhat) the BatchNorm backward needs -- one full read of
+    # the gradient and one launch less per layer (dn_conv_desc.bnb_*); bn_backward() skips its sums pass when .sums_ready
+    fuse = None
+    if BN_SUMS_FUSION and len(targets) == 1 and not layer.transposed and not layer.reflect:
+        a = targets[0].act
+        if (not targets[0].up and a.needs_grad and a.scale is not None and a.mean is not None and not a.no_relu and not a.grad_is_dz
+                and d.out[0].accumulate == 0 and a.strides == (a.H * a.W * a.C, a.W * a.C, a.C, 1)):
+            d.bnb_y, d.bnb_scale, d.bnb_shift = a.t.data_ptr(), a.scale.data_ptr(), a.shift.data_ptr()
+            d.bnb_mean, d.bnb_invstd = a.mean.data_ptr(), a.invstd.data_ptr()
+            rows = _lib.load().dn_conv_bn_partial_rows(C.byref(d))
+            scratch = torch.empty((max(rows, 1), a.C, 2), dtype=torch.float32, device=dy.device)
+            d.bnb_partial = scratch.data_ptr()
+            if _lib.load().dn_conv_dgrad_fuses_bn_sums(C.byref(d)) == 1:
+                fuse = (a, scratch, rows)
+            else:
+                d.bnb_y = d.bnb_partial = None
     with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cin), 2 * layer.macs(N, IH, IW, OH, OW),
                 "%s k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_dgrad" if layer.transposed else "conv_dgrad", layer.R, layer.stride,
                                                          layer.Cin, layer.Cout, N, IH, IW),
                 4 * (dy.numel() + sum(p.act.rows * p.act.C for p in targets))):
         _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
+    if fuse is not None:
+        a, scratch, rows = fuse
+        a.partial, a.partial_rows, a.partial_stride, a.partial_offset = scratch, rows, 2, 0
+        a.sums_ready = True
     for p, tmp in post:
         a = p.act
         cur = tmp
@@ -718,7 +744,10 @@ def bn_backward(y, bn, sink, training):
     if not training:
         raise NotImplementedError("backward through eval-mode BatchNorm (frozen statistics) is not implemented")
     relu_pending = not y.grad_is_dz           # g is dL/d(relu output): the mask is applied by the kernels below
-    if relu_pending:
+    if relu_pending and y.sums_ready and not BN_MATERIALIZE_DZ:
+        y.sums_ready = False                  # the column sums came out of the epilogue of the kernel that wrote g (conv_dgrad)
+    elif relu_pending:
+        y.sums_ready = False
         if y.no_relu:
             raise RuntimeError("a ReLU-less BatchNorm output must be consumed by block_bn_add_relu / block_bn_plain")
         nblk = _lib.load().dn_reduce_blocks(y.rows, Cn)

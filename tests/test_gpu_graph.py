@@ -91,6 +91,9 @@ def test_bn_backward_without_materialised_dz_is_bitwise_the_two_pass_form(monkey
     from supervised_dispnet_amd import engine
     img, gt = bench.synthetic_batch(4, 128, 416, DEV, 3)
     grads = {}
+    # (the sums taken in the input-gradient epilogues, round 3, are the same numbers in another summation order: that fusion has its own
+    #  test, tests/test_gpu_kernels.py::test_bn_backward_sums_fused_into_the_input_gradient, and is switched off for this bitwise one)
+    monkeypatch.setattr(engine, "BN_SUMS_FUSION", False)
     for mode in (False, True):
         monkeypatch.setattr(engine, "BN_MATERIALIZE_DZ", mode)
         net, opt = _make()

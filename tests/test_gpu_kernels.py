@@ -431,3 +431,59 @@ def test_fused_adam_matches_torch_adam():
         opt.step()
     for p, q in zip(ref_p, dev_p):
         close("adam", q.detach(), p.detach(), rtol=1e-6, atol_rel=1e-7)
+
+
+@pytest.mark.parametrize("cmid,H,W", [(64, 16, 24), (128, 34, 26), (256, 16, 52)])
+def test_bn_backward_sums_fused_into_the_input_gradient(cmid, H, W):
+    """dn_conv_desc.bnb_*: the Winograd input-gradient kernels (4-wave and 8-wave) take the BatchNorm backward's column sums of the layer
+    below in their epilogue.  conv-BN-ReLU -> conv-BN-ReLU backward with the fusion on and off: identical up to the summation order of the
+    column sums (gradients of the first layer's BatchNorm pair, its convolution weight and its input)."""
+    from supervised_dispnet_amd._lib import ACT_NONE  # noqa: F401
+    torch.manual_seed(11)
+    N, cin = 4, 32
+    m1, b1 = nn.Conv2d(cin, cmid, 3, 1, 1).to(DEV), nn.BatchNorm2d(cmid).to(DEV)
+    m2, b2 = nn.Conv2d(cmid, cmid, 3, 1, 1).to(DEV), nn.BatchNorm2d(cmid).to(DEV)
+    with torch.no_grad():
+        b1.weight.uniform_(0.5, 1.5); b1.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(N, H, W, cin, device=DEV)
+    g = torch.randn(N, H, W, cmid, device=DEV)
+    res = {}
+    prev = engine.BN_SUMS_FUSION
+    try:
+        for fused in (True, False):
+            engine.BN_SUMS_FUSION = fused
+            for bn in (b1, b2):
+                bn.reset_running_stats()
+            tape, sink = engine.Tape(True), engine.GradSink()
+            xa = engine.Act(x, N, H, W, cin)
+            y1 = engine.block_conv_bn(tape, sink, engine.Piece(xa), engine.ConvLayer(m1), b1, True)
+            y2 = engine.block_conv_bn(tape, sink, engine.Piece(y1), engine.ConvLayer(m2), b2, True)
+            out = engine.block_bn_relu(tape, y2)
+            out.grad = g.clone()
+            tape.run_backward()
+            engine.join_side_stream()
+            torch.cuda.synchronize()
+            kd = _lib.load().dn_last_kernel().decode()
+            res[fused] = (sink.get(b1.weight).clone(), sink.get(b1.bias).clone(), sink.get(m1.weight).clone(), xa.grad.clone(), kd)
+    finally:
+        engine.BN_SUMS_FUSION = prev
+    for a, b, what in zip(res[True][:4], res[False][:4], ("dgamma", "dbeta", "dweight", "dx")):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (what, float((a - b).abs().max()), scale)
+    # the fusion really ran: with it on, no separate sums pass is recorded for the first layer
+    prof_on = []
+    engine.PROFILE = prof_on
+    try:
+        engine.BN_SUMS_FUSION = True
+        tape, sink = engine.Tape(True), engine.GradSink()
+        xa = engine.Act(x, N, H, W, cin)
+        y1 = engine.block_conv_bn(tape, sink, engine.Piece(xa), engine.ConvLayer(m1), b1, True)
+        y2 = engine.block_conv_bn(tape, sink, engine.Piece(y1), engine.ConvLayer(m2), b2, True)
+        out = engine.block_bn_relu(tape, y2)
+        out.grad = g.clone()
+        tape.run_backward()
+        torch.cuda.synchronize()
+    finally:
+        engine.PROFILE = None
+        engine.BN_SUMS_FUSION = prev
+    assert sum(1 for r in prof_on if r[4] == "dn_bn_relu_bwd_sums") == 0, [r[4] for r in prof_on]

@@ -479,7 +479,10 @@ def test_model_zoo_fcrn_aspp(golden, tag):
     (OL.l1_loss(gt.double(), d64, "kitti") + 0.1 * OL.smooth_loss(d64)).backward()
     # conv biases in front of a BatchNorm (FCRN's up-projection convolutions): the gradient is identically zero in exact arithmetic
     # (rounding noise in the reference); the product stores what its kernels compute -- compared like any other parameter
-    _check_all_grads(net, osd, osd64=osd64, flip_allow=1.2e-2, total_allow=8e-3)
+    # FCRN's layer4 normalises over 2 x 2 x 3 = 12 values per channel here: ONE ReLU within fp32 rounding of zero flips 8 % of a channel's
+    # BatchNorm gradient, and which ones flip depends on the rounding of the 1x1 convolutions in front (fp32 instruction: layer4.2.bn3.bias
+    # at 0.049 of the fp64 value's norm; three exact bf16 pieces: 0.053; PyTorch-CPU fp32 itself: 0.013) -- hence 2e-2 instead of 1.2e-2
+    _check_all_grads(net, osd, osd64=osd64, flip_allow=2e-2 if tag == "fcrn" else 1.2e-2, total_allow=8e-3)
     sd1 = net.state_dict()
     for key in [k[len(tag) + 4:] for k in g.files if k.startswith(tag + ":bn:")]:
         close(key, sd1[key], g["%s:bn:%s" % (tag, key)], rtol=1e-3, atol_rel=1e-4)
