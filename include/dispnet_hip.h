@@ -138,6 +138,14 @@ typedef struct dn_conv_desc {
   const float* bnb_mean;
   const float* bnb_invstd;
   float* bnb_partial;
+  /* Optional (round 3): workspace for the input-channel split of small Winograd grids.  A 4-image shard of the metric's batch leaves the
+   * deep layers 32-104 blocks for 256 CUs, each walking all 32-48 chunks of the K axis alone; with a workspace of at least
+   * dn_conv_splitk_workspace_bytes(desc) bytes the three-piece Winograd forward / input gradient splits K over 2-8 blocks per tile; the
+   * partial output tiles meet here and the block that arrives last sums them in index order (deterministic) and runs the epilogue.
+   * The first 4096 bytes are int counters: they must be ZERO before the first use and are left zero by every launch (self-resetting), so
+   * one buffer serves every launch of ONE stream; launches on different streams need different buffers.  NULL: never split. */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
 } dn_conv_desc;
 
 enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2 };
@@ -165,6 +173,8 @@ int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int3
 int32_t dn_conv_weight_layout(const dn_conv_desc* d);
 /* Number of row tiles (first dimension of bn_partial) the launch of this descriptor uses. */
 int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d);
+/* Bytes of dn_conv_desc.splitk_ws this call would use (0: the call does not split; < 0: bad descriptor). */
+int64_t dn_conv_splitk_workspace_bytes(const dn_conv_desc* d);
 /* 1 if dn_conv2d_dgrad(d) will write bnb_partial (see dn_conv_desc), 0 if it ignores the bnb_* fields, < 0 on a bad descriptor. */
 int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d);
 /* Enqueue the convolution described by d. */

@@ -23,6 +23,8 @@ struct Knobs {
   unsigned long long wino_dbgptr;
   int wino_min_tiles;       // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (default 192)
   bool no_x3_direct;        // DN_NO_X3_DIRECT: keep the fp32 matrix instruction in the direct (implicit-GEMM) forward family under DN_COMPUTE_F32X3
+  int wino_splitk_target, wino_splitk_minch;   // DN_WINO_SPLITK_TARGET (512 blocks), DN_WINO_SPLITK_MINCH (8 chunks per block)
+  bool no_wino_splitk;      // DN_NO_WINO_SPLITK: no input-channel split of small Winograd grids
   bool no_bn_sums_fusion;   // DN_NO_BN_SUMS_FUSION: dn_conv_dgrad_fuses_bn_sums() answers 0 (the engine then runs the separate sums pass)
   int pack_blocks;          // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
   int wino8, wino8_min_k;   // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel; DN_WINO8_MIN_K: its rule's channel floor
@@ -109,6 +111,9 @@ struct IgemmParams {
   // BatchNorm-backward column sums of the producer, taken in the input gradient's epilogue (dn_conv_desc.bnb_*; Winograd kernels only)
   const float *bnb_y, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
   float* bnb_partial;
+  int ksplit, ks_chunks, ks_cnt_floats;   // input-channel split of small grids (dn_winograd.hip): splits, chunks of the K axis, float offset of the partial tiles
+  float* ks_ws;                  // caller workspace (dn_conv_desc.splitk_ws): zeroed int counters, then the partial tiles
+  size_t ks_ws_bytes;
   int T, TH, TW;                 // 2x2 output tiles: total, per image column / row
   unsigned mTW, mTH;             // fastdiv magics
 };
@@ -158,6 +163,8 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p);
 long long wino_packed_elems(const IgemmParams& p);
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream);
 int launch_wino_conv(IgemmParams& p, hipStream_t stream);
+int wino_splitk_choice(const IgemmParams& p);
+size_t wino_splitk_workspace_bytes(const IgemmParams& p);
 // dn_winograd_wgrad.hip: Winograd weight gradient of the same layers (operands and output channels multiples of 64)
 bool wino_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
 size_t wino_wgrad_workspace_bytes(const IgemmParams& p);

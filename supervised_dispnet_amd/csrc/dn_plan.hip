@@ -99,6 +99,10 @@ static void read_knobs(Knobs* k) {
   k->wino_dbgptr = getenv("DN_WINO_DBGPTR") ? strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0) : 0ull;
   k->wino_min_tiles = num("DN_WINO_MIN_TILES", 192);
   k->no_x3_direct = on("DN_NO_X3_DIRECT");
+  k->no_wino_splitk = on("DN_NO_WINO_SPLITK");
+  k->wino_splitk_target = num("DN_WINO_SPLITK_TARGET", 256);
+  k->wino_splitk_minch = num("DN_WINO_SPLITK_MINCH", 8);
+  if (k->wino_splitk_minch < 1) k->wino_splitk_minch = 1;
   k->no_bn_sums_fusion = on("DN_NO_BN_SUMS_FUSION");
   k->pack_blocks = num("DN_PACK_BLOCKS", 512);
   if (k->pack_blocks < 1) k->pack_blocks = 1;
@@ -147,6 +151,10 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     p->bnb_mean = d->bnb_mean;
     p->bnb_invstd = d->bnb_invstd;
     p->bnb_partial = d->bnb_partial;
+  }
+  if (!for_wgrad && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0) {
+    p->ks_ws = reinterpret_cast<float*>(d->splitk_ws);
+    p->ks_ws_bytes = (size_t)d->splitk_ws_bytes;
   }
   const int st = d->stride, pad = d->pad;
   const int dil = d->dilation > 1 ? d->dilation : 1;
@@ -350,7 +358,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 8; }
+int dn_version(void) { return 9; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);
@@ -405,6 +413,13 @@ int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d) {
   const bool dense = d->n_out == 1 && !r.accumulate && (r.C & 3) == 0 && r.stride_w == r.C && r.stride_h == (int64_t)d->OW * r.C &&
                      r.stride_n == (int64_t)d->OH * d->OW * r.C;
   return (dense && d->bias == nullptr && d->act == DN_ACT_NONE) ? 1 : 0;
+}
+
+int64_t dn_conv_splitk_workspace_bytes(const dn_conv_desc* d) {
+  dn::IgemmParams p;
+  if (d == nullptr || dn::build_plan(d, false, &p) != DN_OK) return -1;
+  if (dn::wino_layout(d, p) != 3) return 0;
+  return (int64_t)dn::wino_splitk_workspace_bytes(p);
 }
 
 // Test/diagnostic hook (host only, no device work): dump the plan as int32s.

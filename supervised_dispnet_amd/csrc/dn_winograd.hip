@@ -82,6 +82,28 @@ static int wino_ktot(const IgemmParams& p) {      // K axis: the operands one af
 
 static int wino_npad(const IgemmParams& p) { return (p.Ntot + WBN - 1) / WBN * WBN; }
 
+// ---- input-channel split of the 4-wave three-piece kernel for small grids
+constexpr int kSplitKCounterBytes = 4096;        // int counters [tile], zero between launches (self-resetting), in front of the partial tiles
+constexpr int kSplitKMaxBlocks = 128;            // 32-tile x 64-channel blocks at or below which the split is considered (measured at 4 images:
+                                                 // 208 blocks of 32 chunks already run at 208 TFLOP/s credited; 56 blocks at 61)
+int wino_splitk_choice(const IgemmParams& p) {
+  if (knobs().no_wino_splitk) return 1;
+  const int T = p.M / 4;
+  const int blocks = ((T + 31) / 32) * (wino_npad(p) / WBN), chunks = wino_ktot(p) / WKC;
+  if (blocks > kSplitKMaxBlocks || blocks > (int)(kSplitKCounterBytes / sizeof(int))) return 1;
+  int ks = knobs().wino_splitk_target / blocks;  // aim at two blocks per CU ...
+  if (ks > chunks / knobs().wino_splitk_minch) ks = chunks / knobs().wino_splitk_minch;   // ... of at least eight chunks each
+  if (ks > 8) ks = 8;
+  return ks < 2 ? 1 : ks;
+}
+size_t wino_splitk_workspace_bytes(const IgemmParams& p) {
+  const int ks = wino_splitk_choice(p);
+  if (ks <= 1) return 0;
+  const int T = p.M / 4;
+  const size_t blocks = (size_t)((T + 31) / 32) * (wino_npad(p) / WBN);
+  return kSplitKCounterBytes + blocks * ks * 8 * 256 * sizeof(float) * 4;
+}
+
 // + one 16-channel chunk of slack: the kernel's B stream prefetches three steps past the last one
 long long wino_packed_elems(const IgemmParams& p) { return (long long)(wino_ktot(p) + WKC) * wino_npad(p) * 16; }
 
@@ -332,6 +354,19 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;
   const int mb = q / NT, nb = q % NT;
+  // Input-channel split for small grids (p.ksplit > 1, three-piece variant; launch_wino_conv): blockIdx.y = kz takes the global 16-channel
+  // chunks [g0, g1) of the K axis (the operands one after the other); the partial output tiles meet in a workspace and the block that
+  // arrives last sums them in index order (deterministic) and runs the epilogue.  A 4-image shard of the metric's batch leaves the deep
+  // layers 32-104 blocks for 256 CUs, each walking all 32-48 chunks alone.
+  int kz = 0, g0 = 0, g1 = 0x7fffffff;
+  if constexpr (PREC == 3 && MTW == 1) {
+    if (p.ksplit > 1) {
+      kz = (int)blockIdx.y;
+      const int cps = (p.ks_chunks + p.ksplit - 1) / p.ksplit;
+      g0 = kz * cps;
+      g1 = g0 + cps < p.ks_chunks ? g0 + cps : p.ks_chunks;
+    }
+  }
   long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, te1 = 0, te2 = 0;
   if (DBG & 4) t0 = clock64();
 
@@ -384,6 +419,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   constexpr int NPC = PREC == 3 ? 3 : 1;
   const char* wcur16 = reinterpret_cast<const char*>(p.w) + ((size_t)(4 * wave) * NS + 2 * nb) * (1024 * NPC) + lane * 16;
   const size_t wchunk16B = (size_t)16 * NS * 1024 * NPC, wj16B = (size_t)NS * 1024 * NPC;
+  wcur16 += (size_t)g0 * wchunk16B;                     // (split-K: the stream starts at this block's first chunk)
   bf16x8 breg16[PREC == 1 ? 4 : 1][2];
   auto load_b16 = [&]() {
 #pragma unroll
@@ -424,12 +460,16 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   constexpr int ROWS_AT = S_T + 16, COLS_AT = ROWS_AT + 4;
   constexpr int COLS_PER_SLOT = (NSL - COLS_AT) >= 8 ? 1 : 2;
 
-  int buf = 0;
+  int buf = 0, gbase = 0;
+  bool first_op = true;
   for (int s = 0; s < p.n_in; ++s) {
     const KOperand& S = p.in[s];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
     const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
-    const int nch = (S.C + WKC - 1) / WKC;
+    const int nch_all = (S.C + WKC - 1) / WKC;
+    const int c_lo = g0 > gbase ? g0 - gbase : 0, nch = (g1 - gbase) < nch_all ? (g1 - gbase) : nch_all;    // this block's chunks [c_lo, nch) of the operand
+    gbase += nch_all;
+    if (c_lo >= nch) continue;
     const bool scalar1 = S.C == 1;         // 1-channel piece: dword gathers (with the nearest-x2 upsample), live in channel 0 only
     const int off0 = (pn * (int)S.sn + py * (int)S.sh + px * (int)S.sw + k0) * 4;
     const bool op_aff = S.scale != nullptr;
@@ -438,7 +478,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
     fV v[16], sc4, sh4;
     f32x4 fa[2][MTW];
     float relu_floor = 0.f;
-    int cnB = 0;                       // byte offset (channels) of the chunk whose loads are issued next
+    int cnB = c_lo * (WKC * 4);        // byte offset (channels) of the chunk whose loads are issued next
 
     auto load_v_t = [&](int i, auto sc_tag, unsigned mask) __attribute__((always_inline)) {
       constexpr bool SC1 = decltype(sc_tag)::value;
@@ -540,7 +580,8 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
         for (int i = 0; i < 16; ++i) load_v(i);
       }
       load_aff();
-      if (s == 0) {
+      if (first_op) {
+        first_op = false;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -600,7 +641,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       // (a 1-channel piece is a single chunk: what the loop "re-fetches" for it is never used, so its loads are masked off instead of
       //  carrying the gather path's instruction stream and branches through every slot)
       const unsigned lmask = scalar1 ? 0u : pmask;
-      for (int c = 0; c < nch; ++c) {
+      for (int c = c_lo; c < nch; ++c) {
         const bool more = c + 1 < nch;
         cnB = (more ? c + 1 : c) * (WKC * 4);            // the last chunk re-fetches itself into the idle buffer: no branch
         const char* Ab = smemB + buf * BUFB + frA3;
@@ -669,7 +710,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       continue;
     }
     if constexpr (PREC == 1) {
-      for (int c = 0; c < nch; ++c) {
+      for (int c = c_lo; c < nch; ++c) {
         const bool more = c + 1 < nch;
         cnB = (more ? c + 1 : c) * (WKC * 4);          // the last chunk re-fetches itself into the idle buffer: no branch
         const char* Ab16 = smemB + buf * BUF16 + frA16;
@@ -699,7 +740,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       }
       continue;
     }
-    for (int c = 0; c < nch; ++c) {
+    for (int c = c_lo; c < nch; ++c) {
       const bool more = c + 1 < nch;
       cnB = (more ? c + 1 : c) * (WKC * 4);            // the last chunk re-fetches itself into the idle buffer: no branch
       const char* Ab = smemB + buf * BUFB + frA;
@@ -781,6 +822,51 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       const f32x4 z3 = *reinterpret_cast<const f32x4*>(smem + (3 * BT + tile) * WZLD + 4 * c4);
       Y[k][0][b] = z0 + z1 + z2;
       Y[k][1][b] = z1 - z2 - z3;
+    }
+  }
+
+  if constexpr (PREC == 3 && MTW == 1) {
+    if (p.ksplit > 1) {
+      // partial tile -> lane-private float4 slots [tile q][split][8][thread] of the workspace; the last arrival sums all splits in index order
+      __shared__ int ks_last;
+      int* cnt = reinterpret_cast<int*>(p.ks_ws);
+      f32x4* slots = reinterpret_cast<f32x4*>(p.ks_ws + p.ks_cnt_floats);
+      f32x4* mine = slots + ((size_t)(q * p.ksplit + kz) * 8) * 256 + tid;
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) mine[(size_t)((k * 2 + a) * 2 + b) * 256] = Y[k][a][b];
+      // Visibility without an agent-scope release / acquire (whose L2 write-back + invalidate of a cache full of other blocks' results
+      // doubled the kernel's time): every split of a tile runs on the SAME XCD -- the linear block id is blockIdx.x + gridDim.x * kz with
+      // gridDim.x a multiple of 8 -- so the partial tiles only have to reach that XCD's L2: the stores are write-through (waited for
+      // with vmcnt(0)), the counter is an L2 atomic, and the reader's loads bypass its CU's L1 (glc).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) ks_last = (atomicAdd(cnt + q, 1) == p.ksplit - 1) ? 1 : 0;
+      __syncthreads();
+      if (!ks_last) return;
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) Y[k][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(slots + (size_t)q * p.ksplit * 8 * 256), 0, 0x7fffffff, 0x00020000);
+      for (int z = 0; z < p.ksplit; ++z) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              typedef int i32x4 __attribute__((ext_vector_type(4)));
+              const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(((z * 8 + (k * 2 + a) * 2 + b) * 256 + tid) * 16), 0, 1 /* glc */);
+              Y[k][a][b] += __builtin_bit_cast(f32x4, v);
+            }
+      }
+      if (tid == 0) cnt[q] = 0;                          // (self-resetting: the workspace is reusable by the next launch on this stream)
     }
   }
 
@@ -994,7 +1080,7 @@ static int launch_wino_variant(const IgemmParams& p, hipStream_t stream) {
     return DN_ERR_LAUNCH;
   }
   const int tiles = ((p.T + Cfg::BT - 1) / Cfg::BT) * (p.Npad / WBN);
-  dim3 grid((tiles + 7) / 8 * 8);
+  dim3 grid((tiles + 7) / 8 * 8, (PREC == 3 && MTW == 1 && p.ksplit > 1) ? p.ksplit : 1);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::wino_conv_kernel<%d, %s, %d, %d>", MTW, HA ? "true" : "false", DBG, PREC);
   return check_launch("wino_conv_kernel");
@@ -1010,8 +1096,18 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   const int dbg = knobs().wino_dbg, mtw = knobs().wino_mtw;
   if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variants may be used)
     return p.any_affine ? launch_wino_variant<1, true, 0, 1>(p, stream) : launch_wino_variant<1, false, 0, 1>(p, stream);
+  p.ksplit = 1;
   if (p.compute == DN_COMPUTE_F32X3) {
     if ((knobs().wino_dbg == 0 || (knobs().wino_dbg & 4)) && mtw == 1 && wino8_wanted(p)) return launch_wino_conv8(p, stream);
+    if (knobs().wino_dbg == 0 && mtw == 1) {
+      // few blocks, long K: split the input channels.  Needs the caller's workspace (dn_conv_desc.splitk_ws)
+      const int ks = wino_splitk_choice(p);
+      if (ks > 1 && p.ks_ws != nullptr && p.ks_ws_bytes >= wino_splitk_workspace_bytes(p)) {
+        p.ksplit = ks;
+        p.ks_chunks = wino_ktot(p) / WKC;
+        p.ks_cnt_floats = kSplitKCounterBytes / 4;
+      }
+    }
     // (the 64-tile / one-block-per-CU form of this variant -- the loop below is written for either tile height -- moves 37 % fewer bytes
     //  through the texture addresser, the weight pieces being fetched once per 64 tiles, and was measured 5-10 % SLOWER on every layer
     //  but one: a single wave per SIMD stalls on every wait; DN_WINO_MTW=3 selects it for such measurements)

@@ -37,6 +37,7 @@ PARAM_EPOCH = 0
 PROFILE = None
 
 # DN_BN_MATERIALIZE=1: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back) for A/B runs and the equivalence test
+SPLITK = os.environ.get("DN_NO_WINO_SPLITK") is None            # small Winograd grids split their input channels over several blocks
 BN_SUMS_FUSION = os.environ.get("DN_NO_BN_SUMS_FUSION") is None     # input-gradient kernels take the BatchNorm backward's column sums of the layer below
 BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
 
@@ -136,6 +137,30 @@ def fence_streams():
         cur.wait_stream(st["side"])
     if st["main"] is not None and cur != st["main"]:
         cur.wait_stream(st["main"])
+
+
+_SPLITK = {}      # device index -> (zeroed workspace, bytes): dn_conv_desc.splitk_ws of the launches on the MAIN compute stream
+
+
+def _splitk_workspace(d, device):
+    """Attach the input-channel-split workspace to a conv descriptor when the call would use one (small Winograd grids: a 4-image shard
+    of the metric's batch).  One zeroed buffer per device serves every launch of the main stream (the counters reset
+    themselves); launches on the weight-gradient side stream never split."""
+    if not SPLITK or device.type != "cuda":
+        return
+    st = _SIDE.get(device.index if device.index is not None else torch.cuda.current_device())
+    if st is not None and torch.cuda.current_stream() == st["side"]:
+        return
+    need = _lib.load().dn_conv_splitk_workspace_bytes(C.byref(d))
+    if need <= 0:
+        return
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    cur = _SPLITK.get(key)
+    if cur is None or cur[1] < need:
+        size = max(int(need), 16 << 20)
+        cur = _SPLITK[key] = (torch.zeros(size // 4, dtype=torch.float32, device=device), size)
+    d.splitk_ws = cur[0].data_ptr()
+    d.splitk_ws_bytes = cur[1]
 
 
 def _pick_bn(ntot):
@@ -521,6 +546,7 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
     b = layer.m.bias
     d.bias = _ptr(b.detach()) if b is not None else None
     d.act, d.act_p0, d.act_p1 = act, p0, p1
+    _splitk_workspace(d, a0.t.device)
     partial, rows = None, 0
     if bn_stats:
         rows = _lib.load().dn_conv_bn_partial_rows(C.byref(d))
@@ -632,6 +658,7 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
     # BatchNorm backward of the layer below: when this call is the (first) writer of the gradient of a pre-BatchNorm activation with a
     # pending BN + ReLU, let its epilogue take the column sums (sum dz, sum dz * xhat) the BatchNorm backward needs -- one full read of
     # the gradient and one launch less per layer (dn_conv_desc.bnb_*); bn_backward() skips its sums pass when .sums_ready
+    _splitk_workspace(d, dy.device)
     fuse = None
     if BN_SUMS_FUSION and len(targets) == 1 and not layer.transposed and not layer.reflect:
         a = targets[0].act

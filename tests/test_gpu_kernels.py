@@ -487,3 +487,67 @@ def test_bn_backward_sums_fused_into_the_input_gradient(cmid, H, W):
         engine.PROFILE = None
         engine.BN_SUMS_FUSION = prev
     assert sum(1 for r in prof_on if r[4] == "dn_bn_relu_bwd_sums") == 0, [r[4] for r in prof_on]
+
+
+@pytest.mark.parametrize("case", ["c512_16x52", "c256_32x104_bn", "cat768_8x26", "cat_193_small"])
+def test_winograd_input_channel_split_for_small_grids(case):
+    """dn_conv_desc.splitk_ws: with few 32-tile blocks (a 4-image shard of the metric's batch) the three-piece Winograd forward / input
+    gradient splits the K axis over 2-8 blocks per tile; the last arrival sums the partial tiles in index order.  Same results as the
+    unsplit launch up to fp32 summation order (the split changes where the partial sums are cut), incl. the batch-statistic partials and
+    a K axis that crosses operand boundaries."""
+    torch.manual_seed(13)
+    N = 4
+    if case == "c512_16x52":                       # (names kept from the first draft; the shapes are the <= 128-block grids the split takes)
+        H, W, cins, cout, bn = 8, 26, [512], 512, False
+    elif case == "c256_32x104_bn":
+        H, W, cins, cout, bn = 16, 24, [256], 256, True
+    elif case == "cat768_8x26":
+        H, W, cins, cout, bn = 8, 26, [256, 512], 256, False
+    else:
+        H, W, cins, cout, bn = 16, 24, [128, 256, 1], 64, False    # 8 + 16 + 1 chunks in three splits: [0,9) [9,18) [18,25)
+    mod = nn.Conv2d(sum(cins), cout, 3, 1, 1).to(DEV)
+    layer = engine.ConvLayer(mod)
+    acts = []
+    for i, c in enumerate(cins):
+        if c == 1:
+            a = engine.Act(torch.rand(N, H // 2, W // 2, 1, device=DEV) * 2, N, H // 2, W // 2, 1)
+        else:
+            a = engine.Act(torch.randn(N, H, W, c, device=DEV), N, H, W, c)
+            if bn and i == 0:
+                a.scale = torch.rand(c, device=DEV) + 0.5
+                a.shift = torch.rand(c, device=DEV) - 0.5
+        acts.append(a)
+    pieces = [engine.Piece(a, up=(a.C == 1)) for a in acts]
+    dy = torch.randn(N, H, W, cout, device=DEV)
+    res = {}
+    prev = engine.SPLITK
+    try:
+        for split in (True, False):
+            engine.SPLITK = split
+            for a in acts:
+                a.grad = None
+            y, partial, _ = engine.conv_forward(layer, pieces, bn_stats=True)
+            kf = _lib.load().dn_last_kernel().decode()
+            engine.conv_dgrad(layer, dy, N, H, W, pieces, (H, W))
+            torch.cuda.synchronize()
+            res[split] = (y.clone(), partial.clone(), [a.grad.clone() for a in acts], kf)
+    finally:
+        engine.SPLITK = prev
+    assert "wino_conv_kernel" in res[True][3] and res[True][3] == res[False][3]
+    ys, yn = res[True][0], res[False][0]
+    assert not torch.equal(ys, yn)                                   # the split really ran (different summation cuts)
+    scale = float(yn.abs().max())
+    assert float((ys - yn).abs().max()) <= 2e-5 * scale
+    ps, pn = res[True][1], res[False][1]
+    assert float((ps - pn).abs().max()) <= 1e-4 * float(pn.abs().max())
+    for gs, gn in zip(res[True][2], res[False][2]):
+        assert float((gs - gn).abs().max()) <= 2e-5 * float(gn.abs().max())
+    # run it twice more: the self-resetting counters leave the workspace reusable
+    engine.SPLITK = True
+    try:
+        y2, _, _ = engine.conv_forward(layer, pieces, bn_stats=True)
+        y3, _, _ = engine.conv_forward(layer, pieces, bn_stats=True)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, ys) and torch.equal(y3, ys)           # deterministic: the partial tiles are summed in index order
+    finally:
+        engine.SPLITK = prev
