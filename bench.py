@@ -168,6 +168,7 @@ def measured_peaks(dev):
 
 def build_workload(cfg, batch, dev, seed, models, LF, U, reciprocal, FusedAdam):
     """-> (step callable, optimizer, description).  Every config: forward -> loss -> zero_grad/backward -> (all-reduce) -> Adam."""
+    from supervised_dispnet_amd.graph import backward as seeded_backward
     metric, netname, H, W, _b, ds, _gf = CONFIGS[cfg]
     torch.manual_seed(0)                                   # identical random-init replicas on every rank
     if netname == "Disp_vgg_BN":
@@ -192,7 +193,7 @@ def build_workload(cfg, batch, dev, seed, models, LF, U, reciprocal, FusedAdam):
 
     def finish_step(loss):
         opt.zero_grad()
-        loss.backward()
+        seeded_backward(loss)                # loss.backward() from a persistent ones tensor (a launch tape cannot see autograd's fill)
         red = state["reducer"]
         opt.step(grad_scale=red.finish() if red is not None else 1.0)
         return loss
@@ -257,6 +258,11 @@ def main():
     ap.add_argument("--graph", default="0", choices=["0", "1"],
                     help="1: replay the whole step (fwd + loss + bwd + Adam) as ONE captured hipGraph.  Off by default: measured on "
                          "ROCm 7.2 the replay is 1-4 %% SLOWER than the eager launches at every batch size (profiles/r02_strong_1gpu.txt)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph", "tape"],
+                    help="how the host issues the step.  tape: the launches of one real step are recorded once by libdispnet_hip (dn_tape_*) "
+                         "and re-issued by one C call per step -- same kernels, streams and fences as eager, ~2 us of host time per launch "
+                         "instead of ~20 (the step is launch-bound at 4 images per GPU); graph: hipGraph replay (= --graph 1); "
+                         "auto: tape for the metric's config when the recording succeeds, else eager (config.launch says which ran)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only plumbing check of the N>1 path: build the net, the arena, the buckets, one fake all-reduce cycle, tear down")
     args = ap.parse_args()
@@ -317,7 +323,22 @@ def main():
         torch.cuda.synchronize()
 
     eager_step, graphed, graph_note = step, False, None
-    if args.graph == "1":
+    launch_mode = "graph" if args.graph == "1" else args.launch
+    if launch_mode == "auto":
+        launch_mode = "tape" if args.config == "vggbn128" else "eager"
+    taped = None
+    if launch_mode == "tape":
+        from supervised_dispnet_amd.graph import TapedStep
+        for _ in range(2):
+            eager_step()
+        try:
+            taped = TapedStep(eager_step, optimizer=opt, warmup=2).capture()
+            step = taped
+        except Exception as e:                        # noqa: BLE001 -- the eager path is the same kernels; say why it was used
+            graph_note = "%s: %s" % (type(e).__name__, str(e)[:200])
+            taped = None
+            torch.cuda.synchronize()
+    if launch_mode == "graph":
         from supervised_dispnet_amd.graph import GraphedStep
         for _ in range(2):
             eager_step()                              # the arena / caches exist before the capture
@@ -515,7 +536,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "launch": "one hipGraph replay per step" if graphed else "eager launches", "graph_fallback": graph_note,
+                       "launch": ("one hipGraph replay per step" if graphed else
+                                  ("launch tape: %d launches + %d stream fences of one recorded step re-issued by dn_tape_replay, %d segment(s)"
+                                   % (taped.launches, taped.fences, taped.segments)) if taped is not None else "eager launches"),
+                       "graph_fallback": graph_note,
                        "comm": reducer.path if reducer is not None else "none (one rank)",
                        "dist_backend": dist.get_backend() if world > 1 else None},
             "step_tflops_credited_per_gpu": (step_credited_flops / sec_step / 1e12) if step_credited_flops else None,

@@ -467,6 +467,36 @@ int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
 int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* hyper, double eps, double weight_decay,
                      int32_t* step, float* derived, double grad_scale, dn_stream_t stream);
 int dn_fill(float* p, float value, int64_t n, dn_stream_t stream);
+/* dst[i] = src[i], n floats (the owned copy engine.seed_grad takes of a gradient autograd hands over; on the launch tape like every
+ * other kernel of this library, which a framework-side copy would not be). */
+int dn_copy(const float* src, float* dst, int64_t n, dn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Launch tape (round 3).  The reference drives one training step as ~200 framework calls (train.py:437-455: forward, loss, backward,
+ * optimizer.step()); at 4 images per GPU -- BASELINE.json's b32 over 8 GPUs -- the device needs ~4 ms for them and the Python side of
+ * this library ~4 ms to issue them.  While a tape is being recorded (between dn_tape_begin and dn_tape_end, any thread) every kernel
+ * launch of this library is ALSO kept: kernel, grid, block, LDS bytes, stream and the by-value kernel arguments.  dn_tape_replay
+ * re-issues them with plain launches on the recorded streams (~2 us of host time each; a hipGraph of the same step replays SLOWER on
+ * the device than the eager launches on ROCm 7.2).  The caller guarantees that every pointer the recorded
+ * arguments hold is still valid and means the same at replay (graph.TapedStep records under a private memory pool and replays into the
+ * same buffers), that the recorded streams exist, and that NO work the step needs was done outside this library while recording.
+ *   dn_tape_fence(tape, waiter, waitee)  record "waiter waits for everything enqueued on waitee so far" (event record + stream wait at
+ *                                        replay; does nothing now -- the caller fences the live run itself)
+ *   dn_tape_mark(tape)                   cut: returns the number of the segment that starts here; the caller replays segment by
+ *                                        segment and does its own host work in between (a gradient bucket's all-reduce)
+ *   dn_tape_pause(tape, 1 / 0)           launches in between are executed but not recorded (such host work, when it is live at replay)
+ *   dn_tape_replay(tape, segment)        segment -1: the whole tape
+ * ------------------------------------------------------------------------------------------------------------ */
+void* dn_tape_begin(void);
+int dn_tape_end(void* tape);
+int dn_tape_pause(void* tape, int32_t paused);
+int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee);
+int32_t dn_tape_mark(void* tape);
+int32_t dn_tape_segments(void* tape);
+int64_t dn_tape_launches(void* tape);
+int64_t dn_tape_fences(void* tape);
+int dn_tape_replay(void* tape, int32_t segment);
+void dn_tape_free(void* tape);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Input pipeline on the device (reference custom_transforms.py: RandomHorizontalFlip :56-72, ArrayToTensor :40-53, Normalize :25-37;

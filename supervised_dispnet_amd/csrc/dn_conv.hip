@@ -1342,7 +1342,7 @@ static bool stem_eligible(const dn_conv_desc* d, const IgemmParams& p) {
 static int launch_stem(const IgemmParams& p, hipStream_t stream) {
   int blocks = (p.M + 127) / 128;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  DN_LAUNCH(stem_conv_kernel, dim3(blocks), dim3(256), 0, stream, p);
   set_last_kernel("dn::stem_conv_kernel");
   return check_launch("stem_conv_kernel");
 }
@@ -1924,7 +1924,7 @@ static int launch_conv_v(const IgemmParams& p, hipStream_t stream) {
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
   dim3 grid((p.M + BM - 1) / BM, p.Npad / BN, p.nphases);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::igemm_conv_kernel<%d, %d, %d, %d, %s>", BM, BN, WM, WN, ALLVEC ? "true" : "false");
   return check_launch("igemm_conv_kernel");
 }
@@ -1937,7 +1937,7 @@ static int launch_conv_u32(const IgemmParams& p, hipStream_t stream) {
   if (rc != DN_OK) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
   dim3 grid((tiles + 7) / 8 * 8, 1, p.nphases);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::igemm_conv_u32_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
   return check_launch("igemm_conv_u32_kernel");
 }
@@ -1950,7 +1950,7 @@ static int launch_conv_x3(const IgemmParams& p, hipStream_t stream) {
   if (rc != DN_OK) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
   dim3 grid((tiles + 7) / 8 * 8, 1, p.nphases);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::igemm_conv_x3_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
   return check_launch("igemm_conv_x3_kernel");
 }
@@ -2014,7 +2014,7 @@ static int launch_wgrad_v(const IgemmParams& p, hipStream_t stream) {
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
   dim3 grid((p.ph[0].nchunks + 3) / 4, p.Npad / BNW, p.splits);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::igemm_wgrad_kernel<%d, %d, %d, %s>", BNW, WNn, WKk, ALLVEC ? "true" : "false");
   return check_launch("igemm_wgrad_kernel");
 }
@@ -2027,7 +2027,7 @@ static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
   if (rc != DN_OK) return rc;
   const int total = ((p.ph[0].nchunks + 3) / 4) * (p.Npad / BNW) * p.splits;
   dim3 grid((total + 7) / 8 * 8);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::igemm_wgrad_u32_kernel<%d, %d, %d, %s>", BNW, WNn, WKk, AFF ? "true" : "false");
   return check_launch("igemm_wgrad_u32_kernel");
 }
@@ -2101,7 +2101,7 @@ int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int3
   const PackEntry* tab = reinterpret_cast<const PackEntry*>(entries_dev);
   hipStream_t s = as_stream(stream);
   if (n_direct > 0) {
-    hipLaunchKernelGGL(pack_weights_many_kernel, dim3(knobs().pack_blocks, n_direct), dim3(256), 0, s, tab);
+    DN_LAUNCH(pack_weights_many_kernel, dim3(knobs().pack_blocks, n_direct), dim3(256), 0, s, tab);
     int rc = check_launch("pack_weights_many_kernel");
     if (rc != DN_OK) return rc;
   }
@@ -2129,7 +2129,7 @@ int dn_conv_pack_weights(const dn_conv_desc* d, const float* w, float* w_packed,
   if (total == 0) return DN_OK;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, w, w_packed, total);
+  DN_LAUNCH(pack_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, w, w_packed, total);
   return check_launch("pack_weights_kernel");
 }
 
@@ -2216,7 +2216,7 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
   const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;
   int blocks = (int)((total + 63) / 64);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, dw);
+  DN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, dw);
   return check_launch("wgrad_reduce_kernel");
 }
 

@@ -380,7 +380,7 @@ int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
   if (head2_geometry(p, p.in[0].C) && p.GH == p.IH && p.GW == p.IW) {
     const int tilesX = (p.GW + kH2TX - 1) / kH2TX, tilesY = (p.GH + kH2TY - 1) / kH2TY;
     const size_t lds = (size_t)(9 * p.in[0].C + 9 * (kH2TY + 2) * kH2LD) * sizeof(float);
-    hipLaunchKernelGGL(head_fwd2_kernel, dim3(p.N * tilesX * tilesY), dim3(256), lds, stream, p, tilesX, tilesY);
+    DN_LAUNCH(head_fwd2_kernel, dim3(p.N * tilesX * tilesY), dim3(256), lds, stream, p, tilesX, tilesY);
     set_last_kernel("dn::head_fwd2_kernel");
     return check_launch("head_fwd2_kernel");
   }
@@ -388,7 +388,7 @@ int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
   const int px = 256 >> LG;
   int hblocks = (p.M + px - 1) / px;
   if (hblocks > 2048) hblocks = 2048;          // 8 blocks per CU, grid-stride
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(hblocks), dim3(256), p.ph[0].ntaps * p.in[0].C * sizeof(float), stream, p, LG);
+  DN_LAUNCH(head_fwd_kernel, dim3(hblocks), dim3(256), p.ph[0].ntaps * p.in[0].C * sizeof(float), stream, p, LG);
   set_last_kernel("dn::head_fwd_kernel");
   return check_launch("head_fwd_kernel");
 }
@@ -404,7 +404,7 @@ int launch_head_dgrad(const IgemmParams& p, hipStream_t stream) {
   if (head2_geometry(p, p.Ntot)) {
     long long hb = ((long long)p.M + 255) / 256;
     if (hb > 4096) hb = 4096;
-    hipLaunchKernelGGL(head_dgrad2_kernel, dim3((int)hb), dim3(256), 9 * p.Ntot * sizeof(float), stream, p, p.ph[0].nchunks * kChunk);
+    DN_LAUNCH(head_dgrad2_kernel, dim3((int)hb), dim3(256), 9 * p.Ntot * sizeof(float), stream, p, p.ph[0].nchunks * kChunk);
     set_last_kernel("dn::head_dgrad2_kernel");
     return check_launch("head_dgrad2_kernel");
   }
@@ -412,7 +412,7 @@ int launch_head_dgrad(const IgemmParams& p, hipStream_t stream) {
   const int px = 256 >> LG;
   int hblocks = (p.M + px - 1) / px;
   if (hblocks > 2048) hblocks = 2048;
-  hipLaunchKernelGGL(head_dgrad_kernel, dim3(hblocks), dim3(256), p.ph[0].ntaps * p.Ntot * sizeof(float), stream, p, LG,
+  DN_LAUNCH(head_dgrad_kernel, dim3(hblocks), dim3(256), p.ph[0].ntaps * p.Ntot * sizeof(float), stream, p, LG,
                      p.ph[0].nchunks * kChunk);
   set_last_kernel("dn::head_dgrad_kernel");
   return check_launch("head_dgrad_kernel");
@@ -427,7 +427,7 @@ size_t head_wgrad_workspace_bytes(const IgemmParams& p) { return (size_t)kHeadSl
 
 template <int CG>
 static void launch_head_wgrad2(const IgemmParams& p, float* workspace, int blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(head_wgrad2_kernel<CG>, dim3(blocks), dim3(256), 0, stream, p, workspace);
+  DN_LAUNCH(head_wgrad2_kernel<CG>, dim3(blocks), dim3(256), 0, stream, p, workspace);
 }
 
 int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStream_t stream) {
@@ -447,7 +447,7 @@ int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStre
       set_last_kernel("dn::head_wgrad2_kernel");
       int rc = check_launch("head_wgrad2_kernel");
       if (rc != DN_OK) return rc;
-      hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(9 * S0.C), dim3(256), 0, stream, p, workspace, blocks, dw);
+      DN_LAUNCH(head_wgrad_reduce_kernel, dim3(9 * S0.C), dim3(256), 0, stream, p, workspace, blocks, dw);
       return check_launch("head_wgrad_reduce_kernel");
     }
   }
@@ -456,12 +456,12 @@ int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStre
   const long long npix = (long long)p.N * p.IH * p.IW;
   int blocks = (int)((npix + px - 1) / px);
   if (blocks > kHeadSlabs) blocks = kHeadSlabs;
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, p, LG, workspace);
+  DN_LAUNCH(head_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, p, LG, workspace);
   set_last_kernel("dn::head_wgrad_kernel");
   int rc = check_launch("head_wgrad_kernel");
   if (rc != DN_OK) return rc;
   const int tot = p.ph[0].ntaps * p.in[0].C;
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(tot), dim3(256), 0, stream, p, workspace, blocks, dw);
+  DN_LAUNCH(head_wgrad_reduce_kernel, dim3(tot), dim3(256), 0, stream, p, workspace, blocks, dw);
   return check_launch("head_wgrad_reduce_kernel");
 }
 

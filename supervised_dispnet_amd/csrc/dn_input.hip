@@ -98,19 +98,19 @@ int dn_u8_normalize_flip(const uint8_t* src, const uint8_t* flip, int32_t B, int
                    (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (dst_stride_n & 3) == 0 && (dst_stride_c & 3) == 0;
   if (vec) {
     const long long total = (long long)B * H * (W >> 2);
-    hipLaunchKernelGGL(u8_norm_flip_vec_kernel, dim3(in_blocks(total)), dim3(kInThreads), 0, s, src, flip, B, H, W, mean_host[0], mean_host[1],
+    DN_LAUNCH(u8_norm_flip_vec_kernel, dim3(in_blocks(total)), dim3(kInThreads), 0, s, src, flip, B, H, W, mean_host[0], mean_host[1],
                        mean_host[2], std_host[0], std_host[1], std_host[2], dst, (long long)dst_stride_n, (long long)dst_stride_c);
     return check_launch("u8_norm_flip_vec_kernel");
   }
   DN_REQUIRE(mean && stdv, DN_ERR_BAD_ARG, "dn_u8_normalize_flip: the general path needs mean / std on the device");
-  hipLaunchKernelGGL(u8_norm_flip_kernel, dim3(in_blocks((long long)B * C * H * W)), dim3(kInThreads), 0, s, src, flip, B, H, W, C, mean, stdv, dst,
+  DN_LAUNCH(u8_norm_flip_kernel, dim3(in_blocks((long long)B * C * H * W)), dim3(kInThreads), 0, s, src, flip, B, H, W, C, mean, stdv, dst,
                      (long long)dst_stride_n, (long long)dst_stride_c);
   return check_launch("u8_norm_flip_kernel");
 }
 
 int dn_flip_w(const float* src, const uint8_t* flip, int32_t B, int32_t H, int32_t W, float* dst, dn_stream_t stream) {
   DN_REQUIRE(src && dst && src != dst && B > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_flip_w: bad argument (not in place)");
-  hipLaunchKernelGGL(flip_w_kernel, dim3(in_blocks((long long)B * H * W)), dim3(kInThreads), 0, as_stream(stream), src, flip, B, H, W, dst);
+  DN_LAUNCH(flip_w_kernel, dim3(in_blocks((long long)B * H * W)), dim3(kInThreads), 0, as_stream(stream), src, flip, B, H, W, dst);
   return check_launch("flip_w_kernel");
 }
 

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <functional>
+
 #include "dispnet_hip.h"
 
 namespace dn {
@@ -14,6 +17,24 @@ int check_launch(const char* what);
 
 static inline hipStream_t as_stream(dn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- launch tape (dn_tape.hip; dn_tape_* in dispnet_hip.h).  Every kernel launch of this library goes through DN_LAUNCH.  While a
+// tape is being recorded the launch is ALSO kept -- kernel, grid, LDS bytes, stream and the by-value kernel arguments -- so that the
+// whole launch sequence of a training step can be re-issued later by one C call (dn_tape_replay) without any of the host work that
+// produced it (Python, descriptor marshalling, planning): at 4 images per GPU the step is ~210 dependent launches of ~20 us of host
+// time each.  Replays are only valid while every pointer baked into the recorded arguments is (the caller records under a private
+// memory pool and replays into the same buffers).
+struct LaunchTape;
+extern std::atomic<LaunchTape*> g_tape_rec;          // the tape being recorded, or nullptr
+void tape_push(LaunchTape* t, std::function<void()>&& op);
+
+template <typename... KArgs, typename... Args>
+static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+  kernel<<<grid, block, lds, stream>>>(args...);
+  if (LaunchTape* t = g_tape_rec.load(std::memory_order_relaxed))
+    tape_push(t, [=]() { kernel<<<grid, block, lds, stream>>>(args...); });
+}
+#define DN_LAUNCH(...) ::dn::launch(__VA_ARGS__)
+
 // Tuning / test switches (DN_* environment variables), read ONCE and again only on dn_reload_knobs(): the conv entry points
 // consult a dozen of them per launch.
 struct Knobs {
@@ -23,7 +44,8 @@ struct Knobs {
   unsigned long long wino_dbgptr;
   int wino_min_tiles;       // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (default 192)
   bool no_x3_direct;        // DN_NO_X3_DIRECT: keep the fp32 matrix instruction in the direct (implicit-GEMM) forward family under DN_COMPUTE_F32X3
-  int wino_splitk_target, wino_splitk_minch;   // DN_WINO_SPLITK_TARGET (512 blocks), DN_WINO_SPLITK_MINCH (8 chunks per block)
+  int wino_splitk_target, wino_splitk_minch;   // DN_WINO_SPLITK_TARGET (256 blocks), DN_WINO_SPLITK_MINCH (8 chunks per block)
+  int wino_splitk_maxblocks;                   // DN_WINO_SPLITK_MAXBLOCKS: 32-tile x 64-channel blocks at or below which the split is considered
   bool no_wino_splitk;      // DN_NO_WINO_SPLITK: no input-channel split of small Winograd grids
   bool no_bn_sums_fusion;   // DN_NO_BN_SUMS_FUSION: dn_conv_dgrad_fuses_bn_sums() answers 0 (the engine then runs the separate sums pass)
   int pack_blocks;          // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)

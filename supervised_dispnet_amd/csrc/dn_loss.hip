@@ -515,13 +515,13 @@ int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t G, int64_t pi
   hipStream_t s = as_stream(stream);
   const int nsp = loss_splits(pixels);
   float* partial = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(masked_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, kind, partial);
-  hipLaunchKernelGGL(masked_reduceA_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+  DN_LAUNCH(masked_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, kind, partial);
+  DN_LAUNCH(masked_reduceA_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
   if (kind == DN_LOSS_BERHU) {
-    hipLaunchKernelGGL(berhu_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, stats, partial);
-    hipLaunchKernelGGL(masked_reduceB_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+    DN_LAUNCH(berhu_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, stats, partial);
+    DN_LAUNCH(masked_reduceB_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
   }
-  hipLaunchKernelGGL(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, s, stats, G, kind, weight, accumulate, loss);
+  DN_LAUNCH(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, s, stats, G, kind, weight, accumulate, loss);
   return check_launch("masked_loss_fwd");
 }
 
@@ -539,18 +539,18 @@ int dn_masked_loss_stats(const float* gt, const float* pred, int32_t G, int64_t 
   const int nsp = loss_splits(pixels);
   float* partial = reinterpret_cast<float*>(workspace);
   if (pass == 0) {
-    hipLaunchKernelGGL(masked_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, kind, partial);
-    hipLaunchKernelGGL(masked_reduceA_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+    DN_LAUNCH(masked_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, kind, partial);
+    DN_LAUNCH(masked_reduceA_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
   } else {
-    hipLaunchKernelGGL(berhu_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, stats, partial);
-    hipLaunchKernelGGL(masked_reduceB_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
+    DN_LAUNCH(berhu_stats_kernel, dim3(nsp, G), dim3(256), 0, s, gt, pred, (long long)pixels, max_depth, stats, partial);
+    DN_LAUNCH(masked_reduceB_kernel, dim3((G + 63) / 64), dim3(64), 0, s, partial, G, nsp, stats);
   }
   return check_launch("masked_loss_stats");
 }
 
 int dn_masked_loss_finalize(float* stats, int32_t G, int32_t kind, float weight, int32_t accumulate, float* loss, dn_stream_t stream) {
   DN_REQUIRE(stats && loss && G > 0 && kind >= DN_LOSS_L1 && kind <= DN_LOSS_SCALE_INV, DN_ERR_BAD_ARG, "dn_masked_loss_finalize: bad argument");
-  hipLaunchKernelGGL(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), stats, G, kind, weight, accumulate, loss);
+  DN_LAUNCH(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), stats, G, kind, weight, accumulate, loss);
   return check_launch("masked_loss_finalize_kernel");
 }
 
@@ -559,7 +559,7 @@ int dn_masked_loss_bwd(const float* gt, const float* pred, const float* stats, c
   DN_REQUIRE(gt && pred && stats && dloss && dpred && G > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_bwd: bad argument");
   long long total = (long long)G * pixels;
   int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(masked_loss_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gt, pred, stats, dloss, G,
+  DN_LAUNCH(masked_loss_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gt, pred, stats, dloss, G,
                      (long long)pixels, max_depth, kind, weight, dpred);
   return check_launch("masked_loss_bwd_kernel");
 }
@@ -571,19 +571,19 @@ static inline int ew_blocks(long long total) {
 
 int dn_pyramid_down2(const float* in, int32_t N, int32_t H, int32_t W, int32_t mode, float* out, dn_stream_t stream) {
   DN_REQUIRE(in && out && N > 0 && H >= 2 && W >= 2 && mode >= 0 && mode <= 2, DN_ERR_BAD_ARG, "dn_pyramid_down2: bad argument");
-  hipLaunchKernelGGL(pyramid_down2_kernel, dim3(ew_blocks((long long)N * (H / 2) * (W / 2))), dim3(256), 0, as_stream(stream), in, N, H, W, mode, out);
+  DN_LAUNCH(pyramid_down2_kernel, dim3(ew_blocks((long long)N * (H / 2) * (W / 2))), dim3(256), 0, as_stream(stream), in, N, H, W, mode, out);
   return check_launch("pyramid_down2_kernel");
 }
 
 int dn_upsample_int_fwd(const float* low, int32_t N, int32_t h, int32_t w, int32_t scale, int32_t mode, float* out, dn_stream_t stream) {
   DN_REQUIRE(low && out && N > 0 && h > 0 && w > 0 && scale >= 1 && (mode == 0 || mode == 1), DN_ERR_BAD_ARG, "dn_upsample_int_fwd: bad argument");
-  hipLaunchKernelGGL(upsample_int_fwd_kernel, dim3(ew_blocks((long long)N * h * w * scale * scale)), dim3(256), 0, as_stream(stream), low, N, h, w, scale, mode, out);
+  DN_LAUNCH(upsample_int_fwd_kernel, dim3(ew_blocks((long long)N * h * w * scale * scale)), dim3(256), 0, as_stream(stream), low, N, h, w, scale, mode, out);
   return check_launch("upsample_int_fwd_kernel");
 }
 
 int dn_upsample_int_bwd(const float* dout, int32_t N, int32_t h, int32_t w, int32_t scale, int32_t mode, float* dlow, dn_stream_t stream) {
   DN_REQUIRE(dout && dlow && N > 0 && h > 0 && w > 0 && scale >= 1 && (mode == 0 || mode == 1), DN_ERR_BAD_ARG, "dn_upsample_int_bwd: bad argument");
-  hipLaunchKernelGGL(upsample_int_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dout, N, h, w, scale, mode, dlow);
+  DN_LAUNCH(upsample_int_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dout, N, h, w, scale, mode, dlow);
   return check_launch("upsample_int_bwd_kernel");
 }
 
@@ -593,14 +593,14 @@ int dn_explainability_fwd(const float* mask, int64_t n, float weight, int32_t ac
   DN_REQUIRE(mask && partial && loss && n > 0, DN_ERR_BAD_ARG, "dn_explainability_fwd: bad argument");
   hipStream_t s = as_stream(stream);
   const int blocks = dn_reduce1d_blocks(n);
-  hipLaunchKernelGGL(neglog_sum_kernel, dim3(blocks), dim3(256), 0, s, mask, (long long)n, partial);
-  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, (double)n, weight, accumulate, loss);
+  DN_LAUNCH(neglog_sum_kernel, dim3(blocks), dim3(256), 0, s, mask, (long long)n, partial);
+  DN_LAUNCH(mean_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, (double)n, weight, accumulate, loss);
   return check_launch("explainability_fwd");
 }
 
 int dn_explainability_bwd(const float* mask, const float* dloss, int64_t n, float* dmask, dn_stream_t stream) {
   DN_REQUIRE(mask && dloss && dmask && n > 0, DN_ERR_BAD_ARG, "dn_explainability_bwd: bad argument");
-  hipLaunchKernelGGL(neglog_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), mask, dloss, (long long)n, dmask);
+  DN_LAUNCH(neglog_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), mask, dloss, (long long)n, dmask);
   return check_launch("neglog_bwd_kernel");
 }
 
@@ -610,14 +610,14 @@ int dn_smooth2_fwd(const float* map, int32_t B, int32_t H, int32_t W, float weig
   DN_REQUIRE(map && partial && loss && B > 0 && H >= 3 && W >= 3, DN_ERR_BAD_ARG, "dn_smooth2_fwd: bad argument (needs H,W >= 3)");
   hipStream_t s = as_stream(stream);
   const int blocks = smooth_blocks(B, H, W);
-  hipLaunchKernelGGL(smooth2_fwd_kernel, dim3(blocks), dim3(256), 0, s, map, B, H, W, partial);
-  hipLaunchKernelGGL(smooth2_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, B, H, W, weight, loss);
+  DN_LAUNCH(smooth2_fwd_kernel, dim3(blocks), dim3(256), 0, s, map, B, H, W, partial);
+  DN_LAUNCH(smooth2_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, B, H, W, weight, loss);
   return check_launch("smooth2_fwd");
 }
 
 int dn_smooth2_bwd(const float* map, const float* dloss, int32_t B, int32_t H, int32_t W, float weight, float* dmap, dn_stream_t stream) {
   DN_REQUIRE(map && dloss && dmap && B > 0 && H >= 3 && W >= 3, DN_ERR_BAD_ARG, "dn_smooth2_bwd: bad argument");
-  hipLaunchKernelGGL(smooth2_bwd_kernel, dim3(smooth_blocks(B, H, W)), dim3(256), 0, as_stream(stream), map, dloss, B, H, W, weight, dmap);
+  DN_LAUNCH(smooth2_bwd_kernel, dim3(smooth_blocks(B, H, W)), dim3(256), 0, as_stream(stream), map, dloss, B, H, W, weight, dmap);
   return check_launch("smooth2_bwd_kernel");
 }
 
@@ -628,10 +628,10 @@ int dn_compute_errors(const float* gt, const float* pred, int32_t B, int32_t H, 
   float* medians = nullptr;
   if (median_scaling) {
     medians = scratch + (size_t)B * 9;
-    hipLaunchKernelGGL(median_select_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, H, W, max_depth, y1, y2, x1, x2, medians);
+    DN_LAUNCH(median_select_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, H, W, max_depth, y1, y2, x1, x2, medians);
   }
-  hipLaunchKernelGGL(errors_stats_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, H, W, max_depth, y1, y2, x1, x2, medians, scratch);
-  hipLaunchKernelGGL(errors_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, B, out8);
+  DN_LAUNCH(errors_stats_kernel, dim3(B), dim3(kLossThreads), 0, s, gt, pred, H, W, max_depth, y1, y2, x1, x2, medians, scratch);
+  DN_LAUNCH(errors_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, B, out8);
   return check_launch("compute_errors");
 }
 

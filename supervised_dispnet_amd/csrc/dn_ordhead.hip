@@ -282,11 +282,11 @@ int dn_ord_head_fwd(const float* x, const float* mask, const float* w, const flo
   dim3 grid(oh_blocks(chunks)), block(kOhThreads);
   long long* dec = reinterpret_cast<long long*>(decode);
   switch (npt) {
-    case 1: hipLaunchKernelGGL(ord_head_fwd_kernel<1>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
-    case 2: hipLaunchKernelGGL(ord_head_fwd_kernel<2>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
-    case 3: hipLaunchKernelGGL(ord_head_fwd_kernel<3>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
-    case 4: hipLaunchKernelGGL(ord_head_fwd_kernel<4>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
-    default: hipLaunchKernelGGL(ord_head_fwd_kernel<5>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
+    case 1: DN_LAUNCH(ord_head_fwd_kernel<1>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
+    case 2: DN_LAUNCH(ord_head_fwd_kernel<2>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
+    case 3: DN_LAUNCH(ord_head_fwd_kernel<3>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
+    case 4: DN_LAUNCH(ord_head_fwd_kernel<4>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
+    default: DN_LAUNCH(ord_head_fwd_kernel<5>, grid, block, 0, s, x, mask, w, bias, (long long)HW, chunks, K, ord, dec); break;
   }
   return check_launch("ord_head_fwd_kernel");
 }
@@ -301,14 +301,14 @@ int dn_ord_head_bwd(const float* x, const float* mask, const float* w, const flo
   const int nb = oh_blocks(chunks);
   dim3 grid(nb), block(kOhThreads);
   switch (npt) {
-    case 1: hipLaunchKernelGGL(ord_head_bwd_kernel<1>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
-    case 2: hipLaunchKernelGGL(ord_head_bwd_kernel<2>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
-    case 3: hipLaunchKernelGGL(ord_head_bwd_kernel<3>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
-    case 4: hipLaunchKernelGGL(ord_head_bwd_kernel<4>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
-    default: hipLaunchKernelGGL(ord_head_bwd_kernel<5>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
+    case 1: DN_LAUNCH(ord_head_bwd_kernel<1>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
+    case 2: DN_LAUNCH(ord_head_bwd_kernel<2>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
+    case 3: DN_LAUNCH(ord_head_bwd_kernel<3>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
+    case 4: DN_LAUNCH(ord_head_bwd_kernel<4>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
+    default: DN_LAUNCH(ord_head_bwd_kernel<5>, grid, block, 0, s, x, mask, w, bias, dord, (long long)HW, chunks, K, dx, accumulate, workspace); break;
   }
   const int n = 2 * K * kOhCin + 2 * K;
-  hipLaunchKernelGGL(ord_head_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace, nb, n, 2 * K * kOhCin, dw, dbias);
+  DN_LAUNCH(ord_head_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace, nb, n, 2 * K * kOhCin, dw, dbias);
   return check_launch("ord_head_bwd_kernel");
 }
 

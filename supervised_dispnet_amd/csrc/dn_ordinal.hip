@@ -180,7 +180,7 @@ extern "C" {
 int dn_ordinal_fwd(const float* pre, int64_t stride_n, int64_t stride_pix, int64_t stride_c, int32_t N, int64_t HW, int32_t K, float* ord,
                    int64_t* decode, dn_stream_t stream) {
   DN_REQUIRE(pre && ord && decode && N > 0 && HW > 0 && K > 0, DN_ERR_BAD_ARG, "dn_ordinal_fwd: bad argument");
-  hipLaunchKernelGGL(ordinal_fwd_kernel, dim3(ew_blocks_o((long long)N * HW)), dim3(256), 0, as_stream(stream), pre, (long long)stride_n,
+  DN_LAUNCH(ordinal_fwd_kernel, dim3(ew_blocks_o((long long)N * HW)), dim3(256), 0, as_stream(stream), pre, (long long)stride_n,
                      (long long)stride_pix, (long long)stride_c, N, (long long)HW, K, ord, reinterpret_cast<long long*>(decode));
   return check_launch("ordinal_fwd_kernel");
 }
@@ -188,7 +188,7 @@ int dn_ordinal_fwd(const float* pre, int64_t stride_n, int64_t stride_pix, int64
 int dn_ordinal_bwd(const float* pre, int64_t stride_n, int64_t stride_pix, int64_t stride_c, const float* ord, const float* dord, int32_t N,
                    int64_t HW, int32_t K, float* dpre, dn_stream_t stream) {
   DN_REQUIRE(pre && ord && dord && dpre && N > 0 && HW > 0 && K > 0, DN_ERR_BAD_ARG, "dn_ordinal_bwd: bad argument");
-  hipLaunchKernelGGL(ordinal_bwd_kernel, dim3(ew_blocks_o((long long)N * HW)), dim3(256), 0, as_stream(stream), pre, (long long)stride_n,
+  DN_LAUNCH(ordinal_bwd_kernel, dim3(ew_blocks_o((long long)N * HW)), dim3(256), 0, as_stream(stream), pre, (long long)stride_n,
                      (long long)stride_pix, (long long)stride_c, ord, dord, N, (long long)HW, K, dpre);
   return check_launch("ordinal_bwd_kernel");
 }
@@ -200,41 +200,41 @@ int dn_ordinal_loss_fwd(const float* ord, const float* gt, const int32_t* target
   DN_REQUIRE(ord && gt && target && partial && stats && loss && N > 0 && HW > 0 && K > 0, DN_ERR_BAD_ARG, "dn_ordinal_loss_fwd: bad argument");
   hipStream_t s = as_stream(stream);
   const int nb = dn_ordinal_loss_blocks(N, HW);
-  hipLaunchKernelGGL(ordinal_loss_fwd_kernel, dim3(nb), dim3(256), 0, s, ord, gt, target, N, (long long)HW, K, max_depth, partial);
-  hipLaunchKernelGGL(ordinal_loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, stats, loss);
+  DN_LAUNCH(ordinal_loss_fwd_kernel, dim3(nb), dim3(256), 0, s, ord, gt, target, N, (long long)HW, K, max_depth, partial);
+  DN_LAUNCH(ordinal_loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, stats, loss);
   return check_launch("ordinal_loss_fwd");
 }
 
 int dn_ordinal_loss_finalize(const float* stats, float* loss, dn_stream_t stream) {
   DN_REQUIRE(stats && loss, DN_ERR_BAD_ARG, "dn_ordinal_loss_finalize: bad argument");
-  hipLaunchKernelGGL(ordinal_loss_refinalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), stats, loss);
+  DN_LAUNCH(ordinal_loss_refinalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), stats, loss);
   return check_launch("ordinal_loss_refinalize_kernel");
 }
 
 int dn_ordinal_loss_bwd(const float* ord, const float* gt, const int32_t* target, const float* stats, const float* dloss, int32_t N,
                         int64_t HW, int32_t K, float max_depth, float grad_scale, float* dord, dn_stream_t stream) {
   DN_REQUIRE(ord && gt && target && stats && dloss && dord && N > 0 && HW > 0 && K > 0, DN_ERR_BAD_ARG, "dn_ordinal_loss_bwd: bad argument");
-  hipLaunchKernelGGL(ordinal_loss_bwd_kernel, dim3(ew_blocks_o((long long)N * HW)), dim3(256), 0, as_stream(stream), ord, gt, target, stats,
+  DN_LAUNCH(ordinal_loss_bwd_kernel, dim3(ew_blocks_o((long long)N * HW)), dim3(256), 0, as_stream(stream), ord, gt, target, stats,
                      dloss, N, (long long)HW, K, max_depth, grad_scale, dord);
   return check_launch("ordinal_loss_bwd_kernel");
 }
 
 int dn_sid_labels(const float* depth, int64_t n, float ordinal_c, float beta, int32_t* labels, dn_stream_t stream) {
   DN_REQUIRE(depth && labels && n > 0 && ordinal_c > 0.f && beta > 1.f, DN_ERR_BAD_ARG, "dn_sid_labels: bad argument");
-  hipLaunchKernelGGL(sid_labels_kernel, dim3(ew_blocks_o(n)), dim3(256), 0, as_stream(stream), depth, (long long)n, ordinal_c, beta, labels);
+  DN_LAUNCH(sid_labels_kernel, dim3(ew_blocks_o(n)), dim3(256), 0, as_stream(stream), depth, (long long)n, ordinal_c, beta, labels);
   return check_launch("sid_labels_kernel");
 }
 
 int dn_sid_depth(const int64_t* labels, int64_t n, float ordinal_c, float beta, float* depth, dn_stream_t stream) {
   DN_REQUIRE(depth && labels && n > 0 && ordinal_c > 0.f && beta > 1.f, DN_ERR_BAD_ARG, "dn_sid_depth: bad argument");
-  hipLaunchKernelGGL(sid_depth_kernel, dim3(ew_blocks_o(n)), dim3(256), 0, as_stream(stream), reinterpret_cast<const long long*>(labels),
+  DN_LAUNCH(sid_depth_kernel, dim3(ew_blocks_o(n)), dim3(256), 0, as_stream(stream), reinterpret_cast<const long long*>(labels),
                      (long long)n, ordinal_c, beta, depth);
   return check_launch("sid_depth_kernel");
 }
 
 int dn_channel_scale(const float* x, const float* mask, int32_t N, int64_t HW, int32_t C, float* out, dn_stream_t stream) {
   DN_REQUIRE(x && mask && out && N > 0 && HW > 0 && C > 0, DN_ERR_BAD_ARG, "dn_channel_scale: bad argument");
-  hipLaunchKernelGGL(channel_scale_kernel, dim3(ew_blocks_o((long long)N * HW * C)), dim3(256), 0, as_stream(stream), x, mask, N,
+  DN_LAUNCH(channel_scale_kernel, dim3(ew_blocks_o((long long)N * HW * C)), dim3(256), 0, as_stream(stream), x, mask, N,
                      (long long)HW, C, out);
   return check_launch("channel_scale_kernel");
 }

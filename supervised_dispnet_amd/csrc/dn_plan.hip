@@ -102,6 +102,7 @@ static void read_knobs(Knobs* k) {
   k->no_wino_splitk = on("DN_NO_WINO_SPLITK");
   k->wino_splitk_target = num("DN_WINO_SPLITK_TARGET", 256);
   k->wino_splitk_minch = num("DN_WINO_SPLITK_MINCH", 8);
+  k->wino_splitk_maxblocks = num("DN_WINO_SPLITK_MAXBLOCKS", 128);
   if (k->wino_splitk_minch < 1) k->wino_splitk_minch = 1;
   k->no_bn_sums_fusion = on("DN_NO_BN_SUMS_FUSION");
   k->pack_blocks = num("DN_PACK_BLOCKS", 512);
@@ -358,7 +359,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 9; }
+int dn_version(void) { return 10; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);

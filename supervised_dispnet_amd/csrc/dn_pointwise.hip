@@ -76,9 +76,9 @@ template <class Op>
 static int launch_colreduce(const Op& op, long long rows, int C, float* partial, hipStream_t s, const char* what) {
   const int blocks = reduce_blocks(rows, C);
   if (C % 4 == 0)
-    hipLaunchKernelGGL((colreduce_kernel<Op, 4>), dim3(blocks), dim3(kThreads), 0, s, op, rows, C, partial);
+    DN_LAUNCH((colreduce_kernel<Op, 4>), dim3(blocks), dim3(kThreads), 0, s, op, rows, C, partial);
   else
-    hipLaunchKernelGGL((colreduce_kernel<Op, 1>), dim3(blocks), dim3(kThreads), 0, s, op, rows, C, partial);
+    DN_LAUNCH((colreduce_kernel<Op, 1>), dim3(blocks), dim3(kThreads), 0, s, op, rows, C, partial);
   return check_launch(what);
 }
 
@@ -858,7 +858,7 @@ int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count,
                    float* scale, float* shift, int64_t* num_batches_tracked, dn_stream_t stream) {
   DN_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, DN_ERR_BAD_ARG,
              "dn_bn_finalize: bad argument");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, as_stream(stream), partial, rows, C, (double)count, conv_bias, gamma,
+  DN_LAUNCH(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, as_stream(stream), partial, rows, C, (double)count, conv_bias, gamma,
                      beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                      reinterpret_cast<long long*>(num_batches_tracked));
   return check_launch("bn_finalize_kernel");
@@ -867,7 +867,7 @@ int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count,
 int dn_bn_eval_affine(int32_t C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                       float* scale, float* shift, dn_stream_t stream) {
   DN_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, DN_ERR_BAD_ARG, "dn_bn_eval_affine: bad argument");
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, gamma, beta, running_mean,
+  DN_LAUNCH(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, gamma, beta, running_mean,
                      running_var, eps, scale, shift);
   return check_launch("bn_eval_affine_kernel");
 }
@@ -877,7 +877,7 @@ int dn_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, 
   DN_REQUIRE(y && pooled && idx && ((scale == nullptr) == (shift == nullptr)), DN_ERR_BAD_ARG, "dn_bn_relu_pool_fwd: null pointer");
   DN_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && N > 0, DN_ERR_UNSUPPORTED, "dn_bn_relu_pool_fwd: need C%%4==0 and even H,W");
   const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, as_stream(stream), y, scale, shift, N, H, W, C,
+  DN_LAUNCH(bn_relu_pool_fwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, as_stream(stream), y, scale, shift, N, H, W, C,
                      pooled, idx);
   return check_launch("bn_relu_pool_fwd_kernel");
 }
@@ -887,7 +887,7 @@ int dn_maxpool2_bwd(const float* dpooled, const uint8_t* idx, int32_t N, int32_t
   DN_REQUIRE(dpooled && idx && dx && N > 0, DN_ERR_BAD_ARG, "dn_maxpool2_bwd: bad argument");
   DN_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool2_bwd: need C%%4==0 and even H,W");
   const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, as_stream(stream), dpooled, idx, N, H, W, C, dx, accumulate);
+  DN_LAUNCH(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, as_stream(stream), dpooled, idx, N, H, W, C, dx, accumulate);
   return check_launch("maxpool2_bwd_kernel");
 }
 
@@ -927,7 +927,7 @@ static int bn_bwd_sums_to_params(const float* partial, int32_t partial_rows, int
   DN_REQUIRE(partial && dgamma && dbeta && partial_rows > 0, DN_ERR_BAD_ARG, "%s: bad argument", who);
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "%s: need C%%4==0", who);
   DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "%s: partial layout", who);
-  hipLaunchKernelGGL(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
+  DN_LAUNCH(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
                      dgamma);
   return DN_OK;
 }
@@ -939,7 +939,7 @@ int dn_bn_bwd_apply_relu(float* da_dy, const float* y, const float* scale, const
   hipStream_t s = as_stream(stream);
   int rc = bn_bwd_sums_to_params(partial, partial_rows, partial_stride, partial_offset, C, dgamma, dbeta, s, "dn_bn_bwd_apply_relu");
   if (rc != DN_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_apply_relu_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean, invstd, gamma,
+  DN_LAUNCH(bn_bwd_apply_relu_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean, invstd, gamma,
                      dgamma, dbeta, (long long)rows, C, (float)(1.0 / (double)rows));
   return check_launch("bn_bwd_apply_relu");
 }
@@ -953,7 +953,7 @@ int dn_bn_bwd_apply_pool(const float* dpooled, const uint8_t* idx, const float* 
   int rc = bn_bwd_sums_to_params(partial, partial_rows, partial_stride, partial_offset, C, dgamma, dbeta, s, "dn_bn_bwd_apply_pool");
   if (rc != DN_OK) return rc;
   const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, s, dpooled, idx, y, mean, invstd, gamma, dgamma, dbeta, N,
+  DN_LAUNCH(bn_bwd_apply_pool_kernel, dim3(ew_blocks(total)), dim3(kThreads), 0, s, dpooled, idx, y, mean, invstd, gamma, dgamma, dbeta, N,
                      H, W, C, (float)(1.0 / ((double)N * H * W)), dy);
   return check_launch("bn_bwd_apply_pool");
 }
@@ -965,9 +965,9 @@ int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply: need C%%4==0");
   DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: partial layout");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
+  DN_LAUNCH(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
                      dgamma);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, dz_dy, y, mean, invstd, gamma, dgamma, dbeta,
+  DN_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, dz_dy, y, mean, invstd, gamma, dgamma, dbeta,
                      (long long)rows, C, (float)(1.0 / (double)rows));
   return check_launch("bn_bwd_apply");
 }
@@ -981,20 +981,20 @@ int dn_act_bwd_reduce(float* g, const float* y_post, int32_t act, float p0, floa
 
 int dn_colsum_finalize(const float* partial, int32_t rows, int32_t C, int32_t stride, int32_t offset, float* out, dn_stream_t stream) {
   DN_REQUIRE(partial && out && rows > 0 && C > 0 && stride > 0 && offset >= 0 && offset < stride, DN_ERR_BAD_ARG, "dn_colsum_finalize: bad argument");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), partial, rows, C, stride, offset, out);
+  DN_LAUNCH(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), partial, rows, C, stride, offset, out);
   return check_launch("colsum_finalize_kernel");
 }
 
 int dn_upsample2x_nearest_bwd(const float* dfull, int32_t N, int32_t h, int32_t w, float* dlow, int32_t accumulate, dn_stream_t stream) {
   DN_REQUIRE(dfull && dlow && N > 0 && h > 0 && w > 0, DN_ERR_BAD_ARG, "dn_upsample2x_nearest_bwd: bad argument");
-  hipLaunchKernelGGL(upsample2x_nearest_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dfull, N, h, w,
+  DN_LAUNCH(upsample2x_nearest_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dfull, N, h, w,
                      dlow, accumulate);
   return check_launch("upsample2x_nearest_bwd_kernel");
 }
 
 int dn_upsample2x_bilinear_fwd(const float* low, int32_t N, int32_t h, int32_t w, int32_t OH, int32_t OW, float* out, dn_stream_t stream) {
   DN_REQUIRE(low && out && N > 0 && OH <= 2 * h && OW <= 2 * w && OH > 0 && OW > 0, DN_ERR_BAD_ARG, "dn_upsample2x_bilinear_fwd: bad argument");
-  hipLaunchKernelGGL(upsample2x_bilinear_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW)), dim3(256), 0, as_stream(stream), low, N, h, w,
+  DN_LAUNCH(upsample2x_bilinear_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW)), dim3(256), 0, as_stream(stream), low, N, h, w,
                      OH, OW, out);
   return check_launch("upsample2x_bilinear_fwd_kernel");
 }
@@ -1002,7 +1002,7 @@ int dn_upsample2x_bilinear_fwd(const float* low, int32_t N, int32_t h, int32_t w
 int dn_upsample2x_bilinear_bwd(const float* dout, int32_t N, int32_t h, int32_t w, int32_t OH, int32_t OW, float* dlow, int32_t accumulate,
                                dn_stream_t stream) {
   DN_REQUIRE(dout && dlow && N > 0 && OH <= 2 * h && OW <= 2 * w && OH > 0 && OW > 0, DN_ERR_BAD_ARG, "dn_upsample2x_bilinear_bwd: bad argument");
-  hipLaunchKernelGGL(upsample2x_bilinear_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dout, N, h, w,
+  DN_LAUNCH(upsample2x_bilinear_bwd_kernel, dim3(ew_blocks((long long)N * h * w)), dim3(256), 0, as_stream(stream), dout, N, h, w,
                      OH, OW, dlow, accumulate);
   return check_launch("upsample2x_bilinear_bwd_kernel");
 }
@@ -1012,7 +1012,7 @@ int dn_bn_add_relu_fwd(const float* y, const float* scale, const float* shift, c
   DN_REQUIRE(y && scale && shift && out && rows > 0 && C > 0 && ((r_scale == nullptr) == (r_shift == nullptr)) && (r || !r_scale),
              DN_ERR_BAD_ARG, "dn_bn_add_relu_fwd: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_add_relu_fwd: need C%%4==0");
-  hipLaunchKernelGGL(bn_add_relu_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, as_stream(stream), y, scale, shift, r, r_scale,
+  DN_LAUNCH(bn_add_relu_fwd_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, as_stream(stream), y, scale, shift, r, r_scale,
                      r_shift, (long long)rows, C, out);
   return check_launch("bn_add_relu_fwd_kernel");
 }
@@ -1038,7 +1038,7 @@ int dn_maxpool3s2_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C
   DN_REQUIRE(x && out && idx && N > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_maxpool3s2_fwd: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool3s2_fwd: need C%%4==0");
   const int OH = dn_maxpool3s2_out(H, ceil_mode), OW = dn_maxpool3s2_out(W, ceil_mode);
-  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * (C / 4))), dim3(kThreads), 0, as_stream(stream), x, N, H, W,
+  DN_LAUNCH(maxpool3s2_fwd_kernel, dim3(ew_blocks((long long)N * OH * OW * (C / 4))), dim3(kThreads), 0, as_stream(stream), x, N, H, W,
                      C, OH, OW, out, idx);
   return check_launch("maxpool3s2_fwd_kernel");
 }
@@ -1048,7 +1048,7 @@ int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t 
   DN_REQUIRE(dout && idx && dx && N > 0 && H > 0 && W > 0, DN_ERR_BAD_ARG, "dn_maxpool3s2_bwd: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_maxpool3s2_bwd: need C%%4==0");
   const int OH = dn_maxpool3s2_out(H, ceil_mode), OW = dn_maxpool3s2_out(W, ceil_mode);
-  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(kThreads), 0, as_stream(stream), dout, idx, N, H,
+  DN_LAUNCH(maxpool3s2_bwd_kernel, dim3(ew_blocks((long long)N * H * W * (C / 4))), dim3(kThreads), 0, as_stream(stream), dout, idx, N, H,
                      W, C, OH, OW, dx, accumulate);
   return check_launch("maxpool3s2_bwd_kernel");
 }
@@ -1056,54 +1056,65 @@ int dn_maxpool3s2_bwd(const float* dout, const uint8_t* idx, int32_t N, int32_t 
 int dn_upsample2x_nearest_bwd_nhwc(const float* dfull, int32_t N, int32_t h, int32_t w, int32_t C, float* dlow, int32_t accumulate,
                                    dn_stream_t stream) {
   DN_REQUIRE(dfull && dlow && N > 0 && h > 0 && w > 0 && C > 0, DN_ERR_BAD_ARG, "dn_upsample2x_nearest_bwd_nhwc: bad argument");
-  hipLaunchKernelGGL(upsample2x_nearest_bwd_nhwc_kernel, dim3(ew_blocks((long long)N * h * w * C)), dim3(256), 0, as_stream(stream), dfull, N, h,
+  DN_LAUNCH(upsample2x_nearest_bwd_nhwc_kernel, dim3(ew_blocks((long long)N * h * w * C)), dim3(256), 0, as_stream(stream), dfull, N, h,
                      w, C, dlow, accumulate);
   return check_launch("upsample2x_nearest_bwd_nhwc_kernel");
 }
 
 int dn_reflect_fold(const float* dxp, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, float* dx, int32_t accumulate, dn_stream_t stream) {
   DN_REQUIRE(dxp && dx && N > 0 && C > 0 && pad >= 1 && H > pad && W > pad, DN_ERR_BAD_ARG, "dn_reflect_fold: bad argument (needs H, W > pad)");
-  hipLaunchKernelGGL(reflect_fold_kernel, dim3(ew_blocks((long long)N * H * W * C)), dim3(256), 0, as_stream(stream), dxp, N, H, W, C, pad, dx,
+  DN_LAUNCH(reflect_fold_kernel, dim3(ew_blocks((long long)N * H * W * C)), dim3(256), 0, as_stream(stream), dxp, N, H, W, C, pad, dx,
                      accumulate);
   return check_launch("reflect_fold_kernel");
 }
 
 int dn_sub_div(const float* x, int64_t n, float sub, float div, float* out, dn_stream_t stream) {
   DN_REQUIRE(x && out && n > 0 && div != 0.f, DN_ERR_BAD_ARG, "dn_sub_div: bad argument");
-  hipLaunchKernelGGL(sub_div_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x, (long long)n, sub, div, out);
+  DN_LAUNCH(sub_div_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x, (long long)n, sub, div, out);
   return check_launch("sub_div_kernel");
 }
 
 int dn_spatial_mean_fwd(const float* x, int32_t N, int64_t HW, int32_t C, float scale, float* out, dn_stream_t stream) {
   DN_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, DN_ERR_BAD_ARG, "dn_spatial_mean_fwd: bad argument");
-  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(N), dim3(kThreads), 0, as_stream(stream), x, (long long)HW, C, scale, out);
+  DN_LAUNCH(spatial_mean_fwd_kernel, dim3(N), dim3(kThreads), 0, as_stream(stream), x, (long long)HW, C, scale, out);
   return check_launch("spatial_mean_fwd_kernel");
 }
 
 int dn_spatial_mean_bwd(const float* dout, int32_t N, int64_t HW, int32_t C, float scale, float* dx, dn_stream_t stream) {
   DN_REQUIRE(dout && dx && N > 0 && HW > 0 && C > 0, DN_ERR_BAD_ARG, "dn_spatial_mean_bwd: bad argument");
-  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(ew_blocks((long long)N * HW * C)), dim3(256), 0, as_stream(stream), dout, N, (long long)HW, C,
+  DN_LAUNCH(spatial_mean_bwd_kernel, dim3(ew_blocks((long long)N * HW * C)), dim3(256), 0, as_stream(stream), dout, N, (long long)HW, C,
                      scale, dx);
   return check_launch("spatial_mean_bwd_kernel");
 }
 
 int dn_reciprocal_fwd(const float* x, float* y, int64_t n, dn_stream_t stream) {
   DN_REQUIRE(x && y && n > 0, DN_ERR_BAD_ARG, "dn_reciprocal_fwd: bad argument");
-  hipLaunchKernelGGL(reciprocal_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x, y, (long long)n);
+  DN_LAUNCH(reciprocal_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x, y, (long long)n);
   return check_launch("reciprocal_fwd_kernel");
 }
 
 int dn_reciprocal_bwd(const float* dy, const float* y, float* dx, int64_t n, dn_stream_t stream) {
   DN_REQUIRE(dy && y && dx && n > 0, DN_ERR_BAD_ARG, "dn_reciprocal_bwd: bad argument");
-  hipLaunchKernelGGL(reciprocal_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), dy, y, dx, (long long)n);
+  DN_LAUNCH(reciprocal_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), dy, y, dx, (long long)n);
   return check_launch("reciprocal_bwd_kernel");
 }
 
 int dn_fill(float* p, float value, int64_t n, dn_stream_t stream) {
   DN_REQUIRE(p && n >= 0, DN_ERR_BAD_ARG, "dn_fill: bad argument");
   if (n == 0) return DN_OK;
-  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), p, value, (long long)n);
+  DN_LAUNCH(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), p, value, (long long)n);
   return check_launch("fill_kernel");
+}
+
+__global__ void __launch_bounds__(256) copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int dn_copy(const float* src, float* dst, int64_t n, dn_stream_t stream) {
+  DN_REQUIRE(src && dst && n >= 0, DN_ERR_BAD_ARG, "dn_copy: bad argument");
+  if (n == 0) return DN_OK;
+  DN_LAUNCH(copy_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), src, dst, (long long)n);
+  return check_launch("copy_kernel");
 }
 
 int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
@@ -1113,7 +1124,7 @@ int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, as_stream(stream), p, g, m, v, (long long)n, (float)beta1, (float)beta2, (float)eps,
+  DN_LAUNCH(adam_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, as_stream(stream), p, g, m, v, (long long)n, (float)beta1, (float)beta2, (float)eps,
                      (float)weight_decay, step_size, bc2_sqrt, (float)grad_scale);
   return check_launch("adam_kernel");
 }
@@ -1122,8 +1133,8 @@ int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, co
                      int32_t* step, float* derived, double grad_scale, dn_stream_t stream) {
   DN_REQUIRE(p && g && m && v && n > 0 && hyper && step && derived, DN_ERR_BAD_ARG, "dn_adam_step_dev: bad argument");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, step, hyper, derived);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, s, p, g, m, v, (long long)n, (float)eps, (float)weight_decay,
+  DN_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, s, step, hyper, derived);
+  DN_LAUNCH(adam_dev_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, s, p, g, m, v, (long long)n, (float)eps, (float)weight_decay,
                      derived, (float)grad_scale);
   return check_launch("adam_dev_kernel");
 }

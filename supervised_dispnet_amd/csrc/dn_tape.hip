@@ -1,0 +1,149 @@
+// Launch tape: record the kernel launches of a training step once, re-issue them with one C call per segment (dn_tape_* in
+// dispnet_hip.h; the DN_LAUNCH wrapper in dn_internal.h does the recording).
+//
+// Why not a hipGraph: measured on ROCm 7.2 the replay of the captured step is SLOWER on the device than the same launches issued
+// eagerly (4 images: 5.43 vs 5.19 ms, profiles/r03_a_strong_1gpu.txt) -- a pre-queued eager sequence runs at the device's floor, the
+// graph does not.  The tape re-issues the plain launches (same streams, same event fences between the two compute streams), so the
+// device sees exactly the eager sequence while the host spends ~2 us per launch instead of ~20.
+//
+// A tape holds, in issue order: kernel launches (closure over kernel, grid, block, LDS bytes, stream, by-value arguments), stream
+// fences (record an event on one stream, make another wait for it) and marks.  Marks cut the tape into segments: the caller replays
+// segment by segment and does its own host work in between (a gradient bucket's all-reduce on another library's communicator).
+#include <mutex>
+#include <vector>
+
+#include "dn_internal.h"
+
+namespace dn {
+
+struct LaunchTape {
+  std::vector<std::function<void()>> ops;
+  std::vector<size_t> marks;           // ops.size() at each dn_tape_mark
+  std::vector<hipEvent_t> events;
+  std::mutex mu;                       // forward is recorded on the caller's thread, backward on autograd's
+  size_t launches = 0, fences = 0;
+};
+
+std::atomic<LaunchTape*> g_tape_rec{nullptr};
+
+void tape_push(LaunchTape* t, std::function<void()>&& op) {
+  std::lock_guard<std::mutex> lock(t->mu);
+  t->ops.emplace_back(std::move(op));
+  ++t->launches;
+}
+
+}  // namespace dn
+
+extern "C" {
+
+void* dn_tape_begin(void) {
+  dn::LaunchTape* t = new dn::LaunchTape();
+  dn::LaunchTape* expected = nullptr;
+  if (!dn::g_tape_rec.compare_exchange_strong(expected, t)) {
+    delete t;
+    dn::set_error("dn_tape_begin: another tape is being recorded");
+    return nullptr;
+  }
+  return t;
+}
+
+int dn_tape_end(void* tape) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  dn::LaunchTape* expected = t;
+  if (t == nullptr || !dn::g_tape_rec.compare_exchange_strong(expected, nullptr)) {
+    dn::set_error("dn_tape_end: this tape is not the one being recorded");
+    return DN_ERR_BAD_ARG;
+  }
+  return DN_OK;
+}
+
+int dn_tape_pause(void* tape, int32_t paused) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  if (t == nullptr) {
+    dn::set_error("dn_tape_pause: null tape");
+    return DN_ERR_BAD_ARG;
+  }
+  dn::LaunchTape* expected = paused ? t : nullptr;
+  if (!dn::g_tape_rec.compare_exchange_strong(expected, paused ? nullptr : t)) {
+    dn::set_error("dn_tape_pause: the tape is not in the state this call expects");
+    return DN_ERR_BAD_ARG;
+  }
+  return DN_OK;
+}
+
+int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  if (t == nullptr || dn::g_tape_rec.load() != t) {
+    dn::set_error("dn_tape_fence: this tape is not being recorded");
+    return DN_ERR_BAD_ARG;
+  }
+  hipEvent_t ev;
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    dn::set_error("dn_tape_fence: hipEventCreate: %s", hipGetErrorString(e));
+    return DN_ERR_LAUNCH;
+  }
+  hipStream_t w = dn::as_stream(waiter), s = dn::as_stream(waitee);
+  std::lock_guard<std::mutex> lock(t->mu);
+  t->events.push_back(ev);
+  t->ops.emplace_back([=]() {
+    (void)hipEventRecord(ev, s);
+    (void)hipStreamWaitEvent(w, ev, 0);
+  });
+  ++t->fences;
+  return DN_OK;
+}
+
+int32_t dn_tape_mark(void* tape) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  if (t == nullptr) {
+    dn::set_error("dn_tape_mark: null tape");
+    return -1;
+  }
+  std::lock_guard<std::mutex> lock(t->mu);
+  t->marks.push_back(t->ops.size());
+  return (int32_t)t->marks.size();      // number of the segment that starts here
+}
+
+int32_t dn_tape_segments(void* tape) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  return t == nullptr ? -1 : (int32_t)t->marks.size() + 1;
+}
+
+int64_t dn_tape_launches(void* tape) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  return t == nullptr ? -1 : (int64_t)t->launches;
+}
+
+int64_t dn_tape_fences(void* tape) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  return t == nullptr ? -1 : (int64_t)t->fences;
+}
+
+int dn_tape_replay(void* tape, int32_t segment) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  if (t == nullptr || dn::g_tape_rec.load() == t) {
+    dn::set_error("dn_tape_replay: null tape, or the tape is still being recorded");
+    return DN_ERR_BAD_ARG;
+  }
+  const int32_t nseg = (int32_t)t->marks.size() + 1;
+  if (segment < -1 || segment >= nseg) {
+    dn::set_error("dn_tape_replay: segment %d of %d", segment, nseg);
+    return DN_ERR_BAD_ARG;
+  }
+  const size_t lo = segment <= 0 ? 0 : t->marks[segment - 1];
+  const size_t hi = (segment == -1 || segment == nseg - 1) ? t->ops.size() : t->marks[segment];
+  for (size_t i = lo; i < hi; ++i) t->ops[i]();
+  return dn::check_launch("dn_tape_replay");
+}
+
+void dn_tape_free(void* tape) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  if (t == nullptr) return;
+  dn::LaunchTape* expected = t;
+  dn::g_tape_rec.compare_exchange_strong(expected, nullptr);
+  for (hipEvent_t ev : t->events) (void)hipEventDestroy(ev);
+  delete t;
+}
+
+}  // extern "C"

@@ -244,13 +244,13 @@ int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   const int blocks = thin_blocks(p);
   const int rows = p.N * p.GH;
   const int rpw = (rows + blocks * 4 - 1) / (blocks * 4);
-  if (ntc == 1) hipLaunchKernelGGL((thin_wgrad_kernel<1, 10>), dim3(blocks), dim3(256), 0, stream, p, tab, rpw);
-  else hipLaunchKernelGGL((thin_wgrad_kernel<4, 2>), dim3(blocks), dim3(256), 0, stream, p, tab, rpw);
+  if (ntc == 1) DN_LAUNCH((thin_wgrad_kernel<1, 10>), dim3(blocks), dim3(256), 0, stream, p, tab, rpw);
+  else DN_LAUNCH((thin_wgrad_kernel<4, 2>), dim3(blocks), dim3(256), 0, stream, p, tab, rpw);
   set_last_kernel("dn::thin_wgrad_kernel<%d, %d>", ntc, nkt);
   int rc = check_launch("thin_wgrad_kernel");
   if (rc != DN_OK) return rc;
   const int total = ntc * nkt * 256;
-  hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, p, tab, p.ws, dw, blocks, ntc, nkt);
+  DN_LAUNCH(thin_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, p, tab, p.ws, dw, blocks, ntc, nkt);
   return check_launch("thin_wgrad_reduce_kernel");
 }
 
@@ -499,8 +499,8 @@ int launch_thin_conv(const IgemmParams& p, hipStream_t stream) {
   const int ngroups = (p.M + 63) / 64;
   int blocks = (ngroups + 3) / 4;
   if (blocks > 1024) blocks = 1024;
-  if (NT == 1) hipLaunchKernelGGL((thin_conv_kernel<1>), dim3(blocks, p.nphases), dim3(256), lds, stream, p, k4);
-  else hipLaunchKernelGGL((thin_conv_kernel<2>), dim3(blocks, p.nphases), dim3(256), lds, stream, p, k4);
+  if (NT == 1) DN_LAUNCH((thin_conv_kernel<1>), dim3(blocks, p.nphases), dim3(256), lds, stream, p, k4);
+  else DN_LAUNCH((thin_conv_kernel<2>), dim3(blocks, p.nphases), dim3(256), lds, stream, p, k4);
   set_last_kernel("dn::thin_conv_kernel<%d>", NT);
   return check_launch("thin_conv_kernel");
 }

@@ -57,7 +57,7 @@ int dn_ubench_copy(const float* src, float* dst, int64_t n, dn_stream_t stream) 
   DN_REQUIRE(src && dst && n > 0 && n % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, DN_ERR_BAD_ARG,
              "dn_ubench_copy: need 16-byte aligned buffers and n %% 4 == 0");
   static const int blocks = getenv("DN_UBENCH_COPY_BLOCKS") ? atoi(getenv("DN_UBENCH_COPY_BLOCKS")) : 256 * 16;
-  hipLaunchKernelGGL(ubench_copy_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const f32x4*)src, (f32x4*)dst, (long long)(n / 4));
+  DN_LAUNCH(ubench_copy_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const f32x4*)src, (f32x4*)dst, (long long)(n / 4));
   return check_launch("ubench_copy_kernel");
 }
 
@@ -68,7 +68,7 @@ int64_t dn_ubench_mfma_f32_flops(int32_t blocks, int32_t iters) {
 
 int dn_ubench_mfma_f32(float* out, int32_t blocks, int32_t iters, dn_stream_t stream) {
   DN_REQUIRE(out && blocks > 0 && iters > 0, DN_ERR_BAD_ARG, "dn_ubench_mfma_f32: bad argument");   // out: blocks * 256 floats
-  hipLaunchKernelGGL(ubench_mfma_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), out, iters);
+  DN_LAUNCH(ubench_mfma_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), out, iters);
   return check_launch("ubench_mfma_kernel");
 }
 

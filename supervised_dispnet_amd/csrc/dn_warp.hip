@@ -523,7 +523,7 @@ int dn_pose_proj_fwd(const float* pose, int64_t pose_stride_b, const float* K, c
                      float downscale, float* proj, float* kinv_scaled, dn_stream_t stream) {
   DN_REQUIRE(pose && K && Kinv && proj && kinv_scaled && B > 0 && (rotation_mode == 0 || rotation_mode == 1) && downscale > 0.f,
              DN_ERR_BAD_ARG, "dn_pose_proj_fwd: bad argument");
-  hipLaunchKernelGGL(pose_proj_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), pose, (long long)pose_stride_b, K, Kinv, B,
+  DN_LAUNCH(pose_proj_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), pose, (long long)pose_stride_b, K, Kinv, B,
                      rotation_mode, downscale, proj, kinv_scaled);
   return check_launch("pose_proj_fwd_kernel");
 }
@@ -534,7 +534,7 @@ int dn_pose_proj_bwd(const float* pose, int64_t pose_stride_b, const float* K, i
                      const float* dproj_partial, int32_t nblk, float* dpose, int64_t dpose_stride_b, int32_t accumulate,
                      dn_stream_t stream) {
   DN_REQUIRE(pose && K && dproj_partial && dpose && B > 0 && nblk > 0, DN_ERR_BAD_ARG, "dn_pose_proj_bwd: bad argument");
-  hipLaunchKernelGGL(pose_proj_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), pose, (long long)pose_stride_b, K, B,
+  DN_LAUNCH(pose_proj_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), pose, (long long)pose_stride_b, K, B,
                      rotation_mode, downscale, dproj_partial, nblk, dpose, (long long)dpose_stride_b, accumulate);
   return check_launch("pose_proj_bwd_kernel");
 }
@@ -545,7 +545,7 @@ int dn_inverse_warp_fwd(const float* img, const float* depth, const float* proj,
   int rc = fill_warp_args(&a, img, depth, proj, kinv, B, h, w, padding_mode, align_corners);
   if (rc != DN_OK) return rc;
   DN_REQUIRE(warped != nullptr, DN_ERR_BAD_ARG, "dn_inverse_warp_fwd: null output");
-  hipLaunchKernelGGL(warp_fwd_kernel, dim3(warp_blocks(h, w), B), dim3(256), 0, as_stream(stream), a, warped, (float*)nullptr);
+  DN_LAUNCH(warp_fwd_kernel, dim3(warp_blocks(h, w), B), dim3(256), 0, as_stream(stream), a, warped, (float*)nullptr);
   return check_launch("warp_fwd_kernel");
 }
 
@@ -556,7 +556,7 @@ int dn_inverse_warp_bwd(const float* img, const float* depth, const float* proj,
   int rc = fill_warp_args(&a, img, depth, proj, kinv, B, h, w, padding_mode, align_corners);
   if (rc != DN_OK) return rc;
   DN_REQUIRE(dwarped && ddepth && dproj_partial, DN_ERR_BAD_ARG, "dn_inverse_warp_bwd: null pointer");
-  hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_blocks(h, w), B), dim3(256), 0, as_stream(stream), a, dwarped, (const float*)nullptr, 1.f,
+  DN_LAUNCH(warp_bwd_kernel, dim3(warp_blocks(h, w), B), dim3(256), 0, as_stream(stream), a, dwarped, (const float*)nullptr, 1.f,
                      ddepth, accumulate_depth, dproj_partial, (float*)nullptr, 0ll);
   return check_launch("warp_bwd_kernel");
 }
@@ -571,8 +571,8 @@ int dn_photometric_fwd(const float* tgt, const float* ref, const float* depth, c
   a.tgt = tgt; a.mask = mask; a.mask_sb = mask_stride_b;
   hipStream_t s = as_stream(stream);
   const int nb = warp_blocks(h, w);
-  hipLaunchKernelGGL(warp_fwd_kernel, dim3(nb, B), dim3(256), 0, s, a, (float*)nullptr, partial);
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb * B, (double)B * 3 * h * w, weight, accumulate, loss);
+  DN_LAUNCH(warp_fwd_kernel, dim3(nb, B), dim3(256), 0, s, a, (float*)nullptr, partial);
+  DN_LAUNCH(sum_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb * B, (double)B * 3 * h * w, weight, accumulate, loss);
   return check_launch("photometric_fwd");
 }
 
@@ -586,7 +586,7 @@ int dn_photometric_bwd(const float* tgt, const float* ref, const float* depth, c
   DN_REQUIRE(tgt && dloss && ddepth && dproj_partial, DN_ERR_BAD_ARG, "dn_photometric_bwd: null pointer");
   a.tgt = tgt; a.mask = mask; a.mask_sb = mask_stride_b;
   const float scale = weight / ((float)B * 3.f * (float)h * (float)w);
-  hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_blocks(h, w), B), dim3(256), 0, as_stream(stream), a, (const float*)nullptr, dloss, scale,
+  DN_LAUNCH(warp_bwd_kernel, dim3(warp_blocks(h, w), B), dim3(256), 0, as_stream(stream), a, (const float*)nullptr, dloss, scale,
                      ddepth, accumulate_depth, dproj_partial, dmask, (long long)dmask_stride_b);
   return check_launch("warp_bwd_kernel(photometric)");
 }
@@ -594,14 +594,14 @@ int dn_photometric_bwd(const float* tgt, const float* ref, const float* depth, c
 int dn_area_down(const float* in, int64_t planes, int32_t H, int32_t W, int32_t factor, float* out, dn_stream_t stream) {
   DN_REQUIRE(in && out && planes > 0 && factor >= 1 && H % factor == 0 && W % factor == 0, DN_ERR_BAD_ARG,
              "dn_area_down: %dx%d is not a multiple of %d", H, W, factor);
-  hipLaunchKernelGGL(area_down_kernel, dim3(ew_blocks(planes * (H / factor) * (W / factor))), dim3(256), 0, as_stream(stream), in,
+  DN_LAUNCH(area_down_kernel, dim3(ew_blocks(planes * (H / factor) * (W / factor))), dim3(256), 0, as_stream(stream), in,
                      (long long)planes, H, W, factor, out);
   return check_launch("area_down_kernel");
 }
 
 int dn_ssim_fwd(const float* x, const float* y, int64_t planes, int32_t H, int32_t W, float* out, dn_stream_t stream) {
   DN_REQUIRE(x && y && out && planes > 0 && H >= 2 && W >= 2, DN_ERR_BAD_ARG, "dn_ssim_fwd: bad argument");
-  hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ew_blocks(planes * H * W)), dim3(256), 0, as_stream(stream), x, y, (long long)planes, H, W, out);
+  DN_LAUNCH(ssim_fwd_kernel, dim3(ew_blocks(planes * H * W)), dim3(256), 0, as_stream(stream), x, y, (long long)planes, H, W, out);
   return check_launch("ssim_fwd_kernel");
 }
 
@@ -610,8 +610,8 @@ int dn_ssim_bwd(const float* x, const float* y, const float* dout, int64_t plane
   DN_REQUIRE(x && y && dout && workspace && planes > 0 && H >= 2 && W >= 2, DN_ERR_BAD_ARG, "dn_ssim_bwd: bad argument");
   hipStream_t s = as_stream(stream);
   const int nb = ew_blocks(planes * H * W);
-  hipLaunchKernelGGL(ssim_bwd_coef_kernel, dim3(nb), dim3(256), 0, s, x, y, dout, (long long)planes, H, W, workspace);
-  hipLaunchKernelGGL(ssim_bwd_gather_kernel, dim3(nb), dim3(256), 0, s, x, y, workspace, (long long)planes, H, W, dx, dy);
+  DN_LAUNCH(ssim_bwd_coef_kernel, dim3(nb), dim3(256), 0, s, x, y, dout, (long long)planes, H, W, workspace);
+  DN_LAUNCH(ssim_bwd_gather_kernel, dim3(nb), dim3(256), 0, s, x, y, workspace, (long long)planes, H, W, dx, dy);
   return check_launch("ssim_bwd");
 }
 
@@ -620,15 +620,15 @@ int dn_edge_smooth_fwd(const float* disp, const float* img, int32_t B, int32_t C
   DN_REQUIRE(disp && img && partial && loss && B > 0 && C > 0 && H >= 2 && W >= 2, DN_ERR_BAD_ARG, "dn_edge_smooth_fwd: bad argument");
   hipStream_t s = as_stream(stream);
   const int nb = ew_blocks((long long)B * H * W, 1024);
-  hipLaunchKernelGGL(edge_smooth_fwd_kernel, dim3(nb), dim3(256), 0, s, disp, img, B, C, H, W, partial);
-  hipLaunchKernelGGL(edge_smooth_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, B, H, W, loss);
+  DN_LAUNCH(edge_smooth_fwd_kernel, dim3(nb), dim3(256), 0, s, disp, img, B, C, H, W, partial);
+  DN_LAUNCH(edge_smooth_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, B, H, W, loss);
   return check_launch("edge_smooth_fwd");
 }
 
 int dn_edge_smooth_bwd(const float* disp, const float* img, const float* dloss, int32_t B, int32_t C, int32_t H, int32_t W, float* ddisp,
                        dn_stream_t stream) {
   DN_REQUIRE(disp && img && dloss && ddisp && B > 0 && C > 0 && H >= 2 && W >= 2, DN_ERR_BAD_ARG, "dn_edge_smooth_bwd: bad argument");
-  hipLaunchKernelGGL(edge_smooth_bwd_kernel, dim3(ew_blocks((long long)B * H * W)), dim3(256), 0, as_stream(stream), disp, img, dloss, B, C,
+  DN_LAUNCH(edge_smooth_bwd_kernel, dim3(ew_blocks((long long)B * H * W)), dim3(256), 0, as_stream(stream), disp, img, dloss, B, C,
                      H, W, ddisp);
   return check_launch("edge_smooth_bwd_kernel");
 }

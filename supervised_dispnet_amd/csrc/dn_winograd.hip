@@ -84,13 +84,11 @@ static int wino_npad(const IgemmParams& p) { return (p.Ntot + WBN - 1) / WBN * W
 
 // ---- input-channel split of the 4-wave three-piece kernel for small grids
 constexpr int kSplitKCounterBytes = 4096;        // int counters [tile], zero between launches (self-resetting), in front of the partial tiles
-constexpr int kSplitKMaxBlocks = 128;            // 32-tile x 64-channel blocks at or below which the split is considered (measured at 4 images:
-                                                 // 208 blocks of 32 chunks already run at 208 TFLOP/s credited; 56 blocks at 61)
 int wino_splitk_choice(const IgemmParams& p) {
   if (knobs().no_wino_splitk) return 1;
   const int T = p.M / 4;
   const int blocks = ((T + 31) / 32) * (wino_npad(p) / WBN), chunks = wino_ktot(p) / WKC;
-  if (blocks > kSplitKMaxBlocks || blocks > (int)(kSplitKCounterBytes / sizeof(int))) return 1;
+  if (blocks > knobs().wino_splitk_maxblocks || blocks > (int)(kSplitKCounterBytes / sizeof(int))) return 1;
   int ks = knobs().wino_splitk_target / blocks;  // aim at two blocks per CU ...
   if (ks > chunks / knobs().wino_splitk_minch) ks = chunks / knobs().wino_splitk_minch;   // ... of at least eight chunks each
   if (ks > 8) ks = 8;
@@ -179,7 +177,7 @@ __global__ void wino_pack_many_kernel(const PackEntry* __restrict__ tab) {
 }
 
 int launch_wino_pack_many(const PackEntry* tab_dev, int first, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(wino_pack_many_kernel, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
+  DN_LAUNCH(wino_pack_many_kernel, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
   return check_launch("wino_pack_many_kernel");
 }
 
@@ -276,8 +274,8 @@ __global__ void wino_pack16_many_kernel(const PackEntry* __restrict__ tab) {
 }
 
 int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, int pieces, hipStream_t stream) {
-  if (pieces == 3) hipLaunchKernelGGL(wino_pack16_many_kernel<3>, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
-  else hipLaunchKernelGGL(wino_pack16_many_kernel<1>, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
+  if (pieces == 3) DN_LAUNCH(wino_pack16_many_kernel<3>, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
+  else DN_LAUNCH(wino_pack16_many_kernel<1>, dim3(2 * knobs().pack_blocks, n), dim3(256), 0, stream, tab_dev + first);
   return check_launch("wino_pack16_many_kernel");
 }
 
@@ -285,8 +283,8 @@ int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, int piec
   const long long total = wino_packed_elems(p);              // (n, k) pairs x 16 positions, as for the fp32 layout
   int blocks = (int)(((total >> 4) + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  if (pieces == 3) hipLaunchKernelGGL(wino_pack16_kernel<3>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
-  else hipLaunchKernelGGL(wino_pack16_kernel<1>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
+  if (pieces == 3) DN_LAUNCH(wino_pack16_kernel<3>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
+  else DN_LAUNCH(wino_pack16_kernel<1>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
   return check_launch("wino_pack16_kernel");
 }
 
@@ -310,7 +308,7 @@ int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_
   const long long total = wino_packed_elems(p);
   int blocks = (int)(((total >> 4) + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
+  DN_LAUNCH(wino_pack_kernel, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
   return check_launch("wino_pack_kernel");
 }
 
@@ -1081,7 +1079,7 @@ static int launch_wino_variant(const IgemmParams& p, hipStream_t stream) {
   }
   const int tiles = ((p.T + Cfg::BT - 1) / Cfg::BT) * (p.Npad / WBN);
   dim3 grid((tiles + 7) / 8 * 8, (PREC == 3 && MTW == 1 && p.ksplit > 1) ? p.ksplit : 1);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, p);
   set_last_kernel("dn::wino_conv_kernel<%d, %s, %d, %d>", MTW, HA ? "true" : "false", DBG, PREC);
   return check_launch("wino_conv_kernel");
 }

@@ -559,7 +559,7 @@ static int launch_wino8_variant(const IgemmParams& p, hipStream_t stream) {
   }
   const int tiles = ((p.T + BT8 - 1) / BT8) * (p.Npad / WBN);
   dim3 grid((tiles + 7) / 8 * 8);
-  hipLaunchKernelGGL(kernel, grid, dim3(512), kLds8, stream, p);
+  DN_LAUNCH(kernel, grid, dim3(512), kLds8, stream, p);
   set_last_kernel("dn::wino_conv8_kernel<%s, %d>", HA ? "true" : "false", DBG);
   return check_launch("wino_conv8_kernel");
 }

@@ -788,7 +788,7 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   }
   const int Ktot = wg_ktot(p);
   const int total = (p.Ntot / 64) * (Ktot / 64) * splits;
-  hipLaunchKernelGGL(kernel, dim3((total + 7) / 8 * 8), dim3(512), kWgLds, stream, p);
+  DN_LAUNCH(kernel, dim3((total + 7) / 8 * 8), dim3(512), kWgLds, stream, p);
   if (x3) set_last_kernel("dn::wino_wgrad_x3_kernel<%s, 0>", p.any_affine ? "true" : "false");
   else set_last_kernel("dn::wino_wgrad_kernel<%s, %d>", p.any_affine ? "true" : "false", (dbg == 2 || dbg == 6 || dbg == 22 || dbg == 54 || dbg == 118) ? dbg : 0);
   int rc = check_launch("wino_wgrad_kernel");
@@ -802,13 +802,13 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
     const long long total = (long long)groups * 16 * slab;
     int fb = (int)((total + 255) / 256);
     if (fb > 16384) fb = 16384;
-    hipLaunchKernelGGL(wino_wgrad_fold_kernel, dim3(fb), dim3(256), 0, stream, p.ws, folded, 16 * slab, splits);
+    DN_LAUNCH(wino_wgrad_fold_kernel, dim3(fb), dim3(256), 0, stream, p.ws, folded, 16 * slab, splits);
     src = folded;
     nsrc = groups;
   }
   int blocks = (int)(((slab >> 2) + 63) / 64);       // 64 quads (x 4 transform rows) per block
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc,
+  DN_LAUNCH(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc,
                      (reinterpret_cast<uintptr_t>(dw) & 15) == 0 ? 1 : 0);
   return check_launch("wino_wgrad_reduce_kernel");
 }

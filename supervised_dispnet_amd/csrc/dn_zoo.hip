@@ -231,7 +231,7 @@ int32_t dn_bn_stats_rows(int64_t rows) { return (int32_t)((rows + kTileRows - 1)
 int dn_bn_stats_partial(const float* x, int64_t rows, int32_t C, float* partial, dn_stream_t stream) {
   DN_REQUIRE(x && partial && rows > 0 && C > 0, DN_ERR_BAD_ARG, "dn_bn_stats_partial: bad argument");
   DN_REQUIRE((rows + kTileRows - 1) / kTileRows < 65536ll * 32768ll, DN_ERR_UNSUPPORTED, "dn_bn_stats_partial: too many rows");
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((unsigned)((rows + kTileRows - 1) / kTileRows), (C + 63) / 64), dim3(kZThreads), 0, as_stream(stream), x,
+  DN_LAUNCH(bn_stats_partial_kernel, dim3((unsigned)((rows + kTileRows - 1) / kTileRows), (C + 63) / 64), dim3(kZThreads), 0, as_stream(stream), x,
                      (long long)rows, C, partial);
   return check_launch("bn_stats_partial_kernel");
 }
@@ -239,13 +239,13 @@ int dn_bn_stats_partial(const float* x, int64_t rows, int32_t C, float* partial,
 int dn_bn_apply_fwd(const float* y, const float* scale, const float* shift, int64_t rows, int32_t C, float* out, dn_stream_t stream) {
   DN_REQUIRE(y && scale && shift && out && rows > 0 && C > 0, DN_ERR_BAD_ARG, "dn_bn_apply_fwd: bad argument");
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_apply_fwd: need C%%4==0");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(zblocks(rows * (C / 4))), dim3(kZThreads), 0, as_stream(stream), y, scale, shift, (long long)rows, C, out);
+  DN_LAUNCH(bn_apply_kernel, dim3(zblocks(rows * (C / 4))), dim3(kZThreads), 0, as_stream(stream), y, scale, shift, (long long)rows, C, out);
   return check_launch("bn_apply_kernel");
 }
 
 int dn_act_fwd(const float* x, int64_t n, int32_t act, float p0, float p1, float* out, dn_stream_t stream) {
   DN_REQUIRE(x && out && n > 0 && act >= DN_ACT_NONE && act <= DN_ACT_SIGMOID_AFFINE, DN_ERR_BAD_ARG, "dn_act_fwd: bad argument");
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(zblocks(n)), dim3(kZThreads), 0, as_stream(stream), x, (long long)n, act, p0, p1, out);
+  DN_LAUNCH(act_fwd_kernel, dim3(zblocks(n)), dim3(kZThreads), 0, as_stream(stream), x, (long long)n, act, p0, p1, out);
   return check_launch("act_fwd_kernel");
 }
 
@@ -253,7 +253,7 @@ int dn_act_fwd(const float* x, int64_t n, int32_t act, float p0, float p1, float
 int dn_phase_bias_add(float* x, int32_t N, int32_t H2, int32_t W2, int32_t C, const float* bias4, dn_stream_t stream) {
   DN_REQUIRE(x && bias4 && N > 0 && H2 > 0 && W2 > 0 && C > 0, DN_ERR_BAD_ARG, "dn_phase_bias_add: bad argument");
   DN_REQUIRE(C % 4 == 0 && H2 % 2 == 0 && W2 % 2 == 0, DN_ERR_UNSUPPORTED, "dn_phase_bias_add: need C%%4==0 and even extents");
-  hipLaunchKernelGGL(phase_bias_add_kernel, dim3(zblocks((long long)N * H2 * W2 * (C / 4))), dim3(kZThreads), 0, as_stream(stream), x, N, H2, W2, C, bias4);
+  DN_LAUNCH(phase_bias_add_kernel, dim3(zblocks((long long)N * H2 * W2 * (C / 4))), dim3(kZThreads), 0, as_stream(stream), x, N, H2, W2, C, bias4);
   return check_launch("phase_bias_add_kernel");
 }
 
@@ -261,10 +261,10 @@ size_t dn_phase_colsum_workspace_bytes(int32_t C) { return (size_t)kPhaseSlices 
 
 int dn_phase_colsum(const float* g, int32_t N, int32_t H, int32_t W, int32_t C, float* workspace, float* out4, dn_stream_t stream) {
   DN_REQUIRE(g && workspace && out4 && N > 0 && H > 0 && W > 0 && C > 0, DN_ERR_BAD_ARG, "dn_phase_colsum: bad argument");
-  hipLaunchKernelGGL(phase_colsum_kernel, dim3(4, (C + 63) / 64, kPhaseSlices), dim3(kZThreads), 0, as_stream(stream), g, N, H, W, C, workspace);
+  DN_LAUNCH(phase_colsum_kernel, dim3(4, (C + 63) / 64, kPhaseSlices), dim3(kZThreads), 0, as_stream(stream), g, N, H, W, C, workspace);
   int rc = check_launch("phase_colsum_kernel");
   if (rc != DN_OK) return rc;
-  hipLaunchKernelGGL(phase_colsum_finalize_kernel, dim3((4 * C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, C, out4);
+  DN_LAUNCH(phase_colsum_finalize_kernel, dim3((4 * C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, C, out4);
   return check_launch("phase_colsum_finalize_kernel");
 }
 
@@ -272,7 +272,7 @@ int dn_resize_bilinear_fwd(const float* in, int32_t N, int32_t IH, int32_t IW, i
                            dn_stream_t stream) {
   DN_REQUIRE(in && out && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, DN_ERR_BAD_ARG, "dn_resize_bilinear_fwd: bad argument");
   const LinMap my{lin_scale(IH, OH, align_corners), IH, align_corners ? 1 : 0}, mx{lin_scale(IW, OW, align_corners), IW, align_corners ? 1 : 0};
-  hipLaunchKernelGGL(resize_bilinear_fwd_kernel, dim3(zblocks((long long)N * OH * OW)), dim3(kZThreads), 0, as_stream(stream), in, N, IH, IW, OH, OW, my,
+  DN_LAUNCH(resize_bilinear_fwd_kernel, dim3(zblocks((long long)N * OH * OW)), dim3(kZThreads), 0, as_stream(stream), in, N, IH, IW, OH, OW, my,
                      mx, out);
   return check_launch("resize_bilinear_fwd_kernel");
 }
@@ -282,7 +282,7 @@ int dn_resize_bilinear_bwd(const float* dout, int32_t N, int32_t IH, int32_t IW,
   DN_REQUIRE(dout && din && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, DN_ERR_BAD_ARG, "dn_resize_bilinear_bwd: bad argument");
   const LinMap my{lin_scale(IH, OH, align_corners), IH, align_corners ? 1 : 0}, mx{lin_scale(IW, OW, align_corners), IW, align_corners ? 1 : 0};
   const float isy = my.scale > 0.f ? 1.f / my.scale : 0.f, isx = mx.scale > 0.f ? 1.f / mx.scale : 0.f;
-  hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(zblocks((long long)N * IH * IW)), dim3(kZThreads), 0, as_stream(stream), dout, N, IH, IW, OH, OW, my,
+  DN_LAUNCH(resize_bilinear_bwd_kernel, dim3(zblocks((long long)N * IH * IW)), dim3(kZThreads), 0, as_stream(stream), dout, N, IH, IW, OH, OW, my,
                      mx, isy, isx, din, accumulate);
   return check_launch("resize_bilinear_bwd_kernel");
 }

@@ -124,6 +124,14 @@ class GradReducer(object):
         self._handles = []
 
     def _launch(self, bi):
+        """Hand bucket bi to the communicator -- host work in the middle of the backward pass: under a launch tape
+        (graph.TapedStep) the tape is cut here and this runs live between the replayed segments."""
+        if self.arena.flat_g.is_cuda:
+            from . import engine
+            return engine.tape_host_call(lambda: self._launch_now(bi))
+        return self._launch_now(bi)
+
+    def _launch_now(self, bi):
         b = self.buckets[bi]
         _log("bucket", b["lo"], b["hi"])
         if self.comm is not None:
@@ -150,15 +158,22 @@ class GradReducer(object):
     def finish(self):
         """Launch whatever did not complete through grad_ready (e.g. parameters without gradient this step), wait for
         all buckets (stream-level wait, no host sync on the nccl backend) and return the 1/world factor for the optimizer."""
-        for bi, n in enumerate(self._pending):
-            if n > 0:
-                self._launch(bi)
+        leftover = [bi for bi, n in enumerate(self._pending) if n > 0]       # (decided once: a tape replay repeats THIS step's decisions)
+        if self.arena.flat_g.is_cuda:
+            from . import engine
+            engine.tape_host_call(lambda: self._finish_now(leftover))
+        else:
+            self._finish_now(leftover)
+        return 1.0 / self.world
+
+    def _finish_now(self, leftover):
+        for bi in leftover:
+            self._launch_now(bi)
         for h in self._handles:
             h.wait()
         if self.comm is not None:
             self.comm.join()                     # the optimizer (current stream) waits for the last bucket; no host sync
         self.reset()
-        return 1.0 / self.world
 
 
 def shard_slice(global_batch, rank, world):

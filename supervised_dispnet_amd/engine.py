@@ -102,12 +102,49 @@ def side_stream():
     return st
 
 
+# Launch tape being recorded (graph.TapedStep): {"handle": dn_tape_begin()'s, "keep": tensors kept alive until the recording ends}.
+# While it is set, every fence between two streams is also put on the tape (stream_wait), and tensors a second stream reads are kept
+# alive instead of relying on the caching allocator's event-guarded reuse (whose timing the replay cannot reproduce).
+TAPE = None
+
+
+def stream_wait(waiter, waitee):
+    """waiter.wait_stream(waitee), also recorded on the launch tape when one is being recorded."""
+    waiter.wait_stream(waitee)
+    if TAPE is not None and not TAPE.get("paused"):
+        _lib.call("dn_tape_fence", TAPE["handle"], waiter.cuda_stream, waitee.cuda_stream)
+
+
+def tape_host_call(fn):
+    """Run fn() now and -- when a launch tape is being recorded -- at this point of every replay too (graph.TapedStep): host work
+    that is not a launch of this library but belongs to the step (a gradient bucket handed to torch.distributed).  Launches and fences
+    fn makes itself are NOT recorded: they happen live at replay."""
+    if TAPE is None:
+        return fn()
+    _lib.load().dn_tape_mark(TAPE["handle"])
+    TAPE["host_calls"].append(fn)
+    _lib.call("dn_tape_pause", TAPE["handle"], 1)
+    TAPE["paused"] = True
+    try:
+        return fn()
+    finally:
+        TAPE["paused"] = False
+        _lib.call("dn_tape_pause", TAPE["handle"], 0)
+
+
+def cross_stream_use(t, stream):
+    """`t` is read / written by work enqueued on `stream`, which is not the stream it was allocated on."""
+    t.record_stream(stream)
+    if TAPE is not None:
+        TAPE["keep"].append(t)
+
+
 def join_side_stream():
     """Make the current stream wait for everything enqueued on the side stream (end of a backward pass)."""
     if WGRAD_STREAM and torch.cuda.is_available():
         st = _SIDE.get(torch.cuda.current_device())
         if st is not None:
-            torch.cuda.current_stream().wait_stream(st["side"])
+            stream_wait(torch.cuda.current_stream(), st["side"])
 
 
 def compute_streams():
@@ -134,32 +171,31 @@ def fence_streams():
         return
     cur = torch.cuda.current_stream()
     if cur != st["side"]:
-        cur.wait_stream(st["side"])
+        stream_wait(cur, st["side"])
     if st["main"] is not None and cur != st["main"]:
-        cur.wait_stream(st["main"])
+        stream_wait(cur, st["main"])
 
 
-_SPLITK = {}      # device index -> (zeroed workspace, bytes): dn_conv_desc.splitk_ws of the launches on the MAIN compute stream
+_SPLITK = {}      # device index -> (zeroed workspace, bytes, raw side-stream handle): dn_conv_desc.splitk_ws of the launches on the MAIN compute stream
+_SPLITK_BYTES = 80 << 20     # >= 4096 + 256 blocks x 8 splits x 32 KB of partial tiles: the largest workspace any launch asks for (dn_winograd.hip)
 
 
 def _splitk_workspace(d, device):
-    """Attach the input-channel-split workspace to a conv descriptor when the call would use one (small Winograd grids: a 4-image shard
-    of the metric's batch).  One zeroed buffer per device serves every launch of the main stream (the counters reset
-    themselves); launches on the weight-gradient side stream never split."""
+    """Attach the input-channel-split workspace to a conv descriptor (small Winograd grids: a 4-image shard of the metric's batch;
+    DESIGN.md section 6); the library decides per launch whether it splits (dn_conv_splitk_workspace_bytes).  One zeroed buffer per
+    device serves every launch of the main stream (the counters reset themselves); launches on the weight-gradient side stream never
+    split.  No torch calls on the hot path: the step makes ~80 of these and is launch-bound at 4 images."""
     if not SPLITK or device.type != "cuda":
         return
-    st = _SIDE.get(device.index if device.index is not None else torch.cuda.current_device())
-    if st is not None and torch.cuda.current_stream() == st["side"]:
+    cur = _SPLITK.get(device.index)
+    if cur is None:
+        with torch.cuda.device(device):
+            side = side_stream()["side"].cuda_stream
+        buf = torch.zeros(_SPLITK_BYTES // 4, dtype=torch.float32, device=device)
+        cur = _SPLITK[device.index] = (buf, _SPLITK_BYTES, side, buf.data_ptr())
+    if _stream() == cur[2]:
         return
-    need = _lib.load().dn_conv_splitk_workspace_bytes(C.byref(d))
-    if need <= 0:
-        return
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    cur = _SPLITK.get(key)
-    if cur is None or cur[1] < need:
-        size = max(int(need), 16 << 20)
-        cur = _SPLITK[key] = (torch.zeros(size // 4, dtype=torch.float32, device=device), size)
-    d.splitk_ws = cur[0].data_ptr()
+    d.splitk_ws = cur[3]
     d.splitk_ws_bytes = cur[1]
 
 
@@ -598,17 +634,17 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None):
     st = side_stream()
     main, side = torch.cuda.current_stream(), st["side"]
     st["main"] = main
-    side.wait_stream(main)                       # dy, the operands and the bias / BatchNorm gradients of this layer are ready
+    stream_wait(side, main)                      # dy, the operands and the bias / BatchNorm gradients of this layer are ready
     with stream_scope(side):
         dw = launch()
-    dy.record_stream(side)                       # the caching allocator must not hand these to the main stream while side reads them
+    cross_stream_use(dy, side)                   # the caching allocator must not hand these to the main stream while side reads them
     for p in pieces:
-        p.act.t.record_stream(side)
+        cross_stream_use(p.act.t, side)
         if p.act.scale is not None:
-            p.act.scale.record_stream(side)
-            p.act.shift.record_stream(side)
+            cross_stream_use(p.act.scale, side)
+            cross_stream_use(p.act.shift, side)
     if out is None:
-        dw.record_stream(main)
+        cross_stream_use(dw, main)
     return dw
 
 
@@ -758,6 +794,12 @@ class GradSink:
                 GradSink.reducer.grad_ready(param)
         else:
             self.grads[id(param)] = torch.zeros_like(param)
+
+    def put_none(self, param):
+        """No gradient reaches this parameter in this backward pass (its block's output was not used by the loss): autograd sees None;
+        an arena slice keeps its zeros and the reducer is told the slot is settled, so its bucket is not held back to the end."""
+        if getattr(param, "_dn_grad_view", None) is not None:
+            self.put_zero(param)
 
     def get(self, param):
         return self.grads.get(id(param))
@@ -928,7 +970,10 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
                   scratch[1].data_ptr(), scratch[2].data_ptr(), scratch[3].data_ptr(), _nbt_ptr(stat_bn), _stream())
 
     def backward():
-        if y.grad is None:
+        if y.grad is None:                   # an output no loss term reads (autograd hands None): no gradient, as in the reference
+            sink.put_none(layer.m.weight)
+            if layer.m.bias is not None:
+                sink.put_none(layer.m.bias)
             return
         g = y.grad
         db = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout, out=sink.dest(layer.m.bias) if layer.m.bias is not None else None)
@@ -942,6 +987,12 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
     return y
 
 
+def _not_on_tape(what):
+    """Framework-side device work the launch tape cannot see: refuse while one is being recorded (the replay would silently skip it)."""
+    if TAPE is not None and not TAPE.get("paused"):
+        raise RuntimeError("launch tape: %s runs outside libdispnet_hip and would be missing from the replay" % what)
+
+
 def seed_grad(act, g):
     """Seed an activation's gradient with one supplied by autograd (owned copy: the tape works in place)."""
     if act.planar:
@@ -952,8 +1003,14 @@ def seed_grad(act, g):
     else:
         g = g.reshape(act.N, act.H, act.W, act.C) if act.C == 1 else g.permute(0, 2, 3, 1)
     if act.grad is None:
-        act.grad = g.clone(memory_format=torch.contiguous_format)
+        if g.is_cuda and g.is_contiguous() and g.dtype == torch.float32:
+            act.grad = torch.empty_like(g)       # (this library's copy kernel: on the launch tape, which a framework clone would not be)
+            _lib.call("dn_copy", g.data_ptr(), act.grad.data_ptr(), g.numel(), _stream())
+        else:
+            _not_on_tape("seed_grad of a non-contiguous gradient")
+            act.grad = g.clone(memory_format=torch.contiguous_format)
     else:
+        _not_on_tape("seed_grad into an existing gradient")
         act.grad.add_(g)
 
 

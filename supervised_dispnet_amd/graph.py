@@ -57,3 +57,113 @@ class GraphedStep(object):
             self.capture()
         self.graph.replay()
         return self.out
+
+
+_ONES = {}
+
+
+def backward(loss):
+    """loss.backward() seeded from a persistent ones tensor: autograd's own seed is a fresh fill launched by the framework, which a
+    launch tape cannot see (a step handed to TapedStep must use this)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones_like(loss)
+    loss.backward(one)
+
+
+class TapedStep(object):
+    """Whole-step launch tape: forward + loss + backward + optimizer recorded ONCE as the list of this library's kernel launches and
+    stream fences (dn_tape_*, csrc/dn_tape.hip) and re-issued by one C call per step -- the device sees exactly the eager launch
+    sequence (two compute streams, same fences) while the host spends ~2 us per launch instead of ~20.  At the metric's 32 / 8 = 4
+    images per GPU the Python side of a step costs as much as the device side (tools/host_overhead.py); a hipGraph of the same step
+    replays slower on the device than the eager launches.
+
+    The recorded step is a REAL step (it runs eagerly and counts).  Requirements on `step` beyond GraphedStep's (no host
+    synchronisation, device-side optimizer counter, inputs in fixed buffers):
+      * every piece of device work is a launch of libdispnet_hip (no framework fills / copies / elementwise kernels: the engine
+        refuses the ones it knows about while a tape is recorded; seed the backward with graph.backward(loss));
+      * tensors are allocated under a private pool of the caching allocator while recording, so every pointer the tape holds stays
+        reserved; the result tensors `step` returns are the tape's static outputs.
+    Host work between launches that must ALSO happen at replay (a gradient bucket's all-reduce on torch.distributed) is registered
+    with engine.tape_host_call(fn): the tape is cut there and `fn` runs live between the segments, on the tape's stream."""
+
+    def __init__(self, step, optimizer=None, warmup=3, static_inputs=()):
+        self.step = step
+        self.inputs = tuple(static_inputs)
+        self.out = None
+        self.tape = None
+        self.host_calls = []
+        if optimizer is not None and hasattr(optimizer, "capturable"):
+            optimizer.capturable(True)
+        self._stream = torch.cuda.Stream()
+        self._warmup = warmup
+        self._pool = None
+        self._keep = None
+
+    def capture(self):
+        from . import _lib
+        lib = _lib.load()
+        s = self._stream
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self._warmup):
+                self.step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        dev = torch.cuda.current_device()
+        self._pool = torch.cuda.MemPool()
+        handle = lib.dn_tape_begin()
+        if not handle:
+            raise _lib.DispnetHipError("dn_tape_begin: " + _lib.last_error())
+        rec = {"handle": handle, "keep": [], "host_calls": self.host_calls, "paused": False}
+        engine.TAPE = rec
+        torch._C._cuda_beginAllocateToPool(dev, self._pool.id)          # every thread (the backward runs on autograd's)
+        try:
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.out = self.step()
+            torch.cuda.current_stream().wait_stream(s)
+        finally:
+            torch._C._cuda_endAllocateToPool(dev, self._pool.id)
+            engine.TAPE = None
+            _lib.call("dn_tape_end", handle)
+        torch.cuda.synchronize()
+        self._keep = rec["keep"]          # (cheap to hold; dropping them would only return the blocks to the private pool)
+        self.tape = handle
+        self._lib = lib
+        self.segments = lib.dn_tape_segments(handle)
+        self.launches, self.fences = lib.dn_tape_launches(handle), lib.dn_tape_fences(handle)
+        if self.segments != len(self.host_calls) + 1:
+            raise RuntimeError("launch tape: %d segments for %d host calls" % (self.segments, len(self.host_calls)))
+        return self
+
+    def __call__(self):
+        if self.tape is None:
+            self.capture()
+            return self.out
+        s = self._stream
+        cur = torch.cuda.current_stream()
+        s.wait_stream(cur)                # the caller's writes into the static inputs
+        if not self.host_calls:
+            rc = self._lib.dn_tape_replay(self.tape, -1)
+        else:
+            rc = 0
+            with torch.cuda.stream(s), engine.stream_scope():
+                for i in range(self.segments):
+                    rc = rc or self._lib.dn_tape_replay(self.tape, i)
+                    if i < len(self.host_calls):
+                        self.host_calls[i]()
+        if rc != 0:
+            from . import _lib
+            raise _lib.DispnetHipError("dn_tape_replay failed (%d): %s" % (rc, _lib.last_error()))
+        cur.wait_stream(s)
+        return self.out
+
+    def __del__(self):
+        try:
+            if self.tape is not None:
+                self._lib.dn_tape_free(self.tape)
+                self.tape = None
+        except Exception:                 # noqa: BLE001  (interpreter shutdown)
+            pass

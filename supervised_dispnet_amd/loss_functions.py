@@ -41,7 +41,8 @@ class _MaskedLoss(torch.autograd.Function):
         dev = preds[0].device
         loss = torch.empty((), dtype=torch.float32, device=dev)
         saved, cfg, work = [], [], []
-        all_stats = torch.zeros((sum(groups[:len(preds)]), _lib.LOSS_STATS), dtype=torch.float32, device=dev)
+        all_stats = torch.empty((sum(groups[:len(preds)]), _lib.LOSS_STATS), dtype=torch.float32, device=dev)
+        _lib.call("dn_fill", all_stats.data_ptr(), 0.0, all_stats.numel(), _stream())
         row = 0
         for i, (gt, pred) in enumerate(zip(gts, preds)):
             require_cuda(pred, "predicted depth")

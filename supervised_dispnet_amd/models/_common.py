@@ -73,6 +73,9 @@ class HipNetFunction(torch.autograd.Function):
         # needs_input_grad ignores torch.no_grad() (and grad mode is always off INSIDE forward): run_net passes the caller's mode,
         # so validation / test_disp forwards do not record the tape nor keep the activations alive
         recording = grad_mode and any(ctx.needs_input_grad[3:])
+        # outputs the loss never reads (l1_loss: scales 1-3) come back as None instead of zero maps autograd would have to fill and
+        # the tape to copy: the reference's autograd does not visit them either
+        ctx.set_materialize_grads(False)
         tape = engine.Tape(recording)
         sink = engine.GradSink()
         in_acts = [engine.Act.from_nchw(x, needs_grad=recording and ctx.needs_input_grad[3 + i]) for i, x in enumerate(inputs)]

@@ -105,3 +105,64 @@ def test_bn_backward_without_materialised_dz_is_bitwise_the_two_pass_form(monkey
         grads[mode] = (loss.item(), opt.arena.flat_g.clone())
     assert grads[False][0] == grads[True][0]
     assert torch.equal(grads[False][1], grads[True][1])
+
+
+@pytest.mark.parametrize("batch,h,w", [(4, 128, 416), (2, 64, 96)], ids=["b4_128x416", "b2_64x96"])
+def test_launch_tape_replay_is_bitwise_the_eager_step(batch, h, w):
+    """graph.TapedStep (dn_tape_*): the launches and stream fences of one recorded step, re-issued by one C call per step, are the same
+    arithmetic as the eager launch sequence -- losses, parameters, Adam moments and BatchNorm buffers after 7 steps on changing batches
+    (written into the static input buffers between replays).  A launch the tape missed (framework-side work) or a pointer that moved
+    would show up here as stale data."""
+    from supervised_dispnet_amd.graph import TapedStep, backward
+    batches = [bench.synthetic_batch(batch, h, w, DEV, seed) for seed in range(5)]
+    net_e, opt_e = _make()
+    sd0 = copy.deepcopy({k: v.detach().cpu().clone() for k, v in net_e.state_dict().items()})
+    net_t, opt_t = _make(sd0)
+    img, gt = batches[0][0].clone(), batches[0][1].clone()
+
+    def step_t():
+        depth = [reciprocal(d) for d in net_t(img)]
+        loss = LF.l1_loss(gt, depth, "kitti")
+        opt_t.zero_grad()
+        backward(loss)
+        opt_t.step()
+        return loss
+
+    def step_e(x, y):
+        depth = [reciprocal(d) for d in net_e(x)]
+        loss = LF.l1_loss(y, depth, "kitti")
+        opt_e.zero_grad()
+        loss.backward()
+        opt_e.step()
+        return loss
+
+    ts = TapedStep(step_t, optimizer=opt_t, warmup=2, static_inputs=(img, gt))
+    ts.capture()                       # 2 warm-up steps + the recorded one: three real steps on batch 0
+    for _ in range(3):
+        step_e(*batches[0])
+    assert ts.launches > 100 and ts.fences > 10 and ts.segments == 1
+    losses_t, losses_e = [], []
+    for x, y in batches[1:]:
+        img.copy_(x)
+        gt.copy_(y)
+        losses_t.append(ts().clone())
+        losses_e.append(step_e(x, y).clone())
+    # scribble over freed memory of the regular pool between replays: the tape's buffers live in their own pool
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]
+    del junk
+    img.copy_(batches[0][0])
+    gt.copy_(batches[0][1])
+    losses_t.append(ts().clone())
+    losses_e.append(step_e(*batches[0]).clone())
+    torch.cuda.synchronize()
+    assert int(opt_t._dev["step"].item()) == opt_e.step_count == 8
+    for lt, le in zip(losses_t, losses_e):
+        assert torch.isfinite(lt).all()
+        assert torch.allclose(lt, le, rtol=1e-5), (lt, le)
+    assert torch.equal(losses_t[0], losses_e[0])
+    # (device pow() vs host pow() in Adam's bias corrections: see the hipGraph test above)
+    assert torch.allclose(opt_t.arena.flat_p, opt_e.arena.flat_p, rtol=0, atol=2e-7)
+    assert torch.allclose(opt_t.exp_avg, opt_e.exp_avg, rtol=1e-4, atol=1e-9)
+    st, se = net_t.state_dict(), net_e.state_dict()
+    for k in st:
+        assert torch.allclose(st[k].float(), se[k].float(), rtol=1e-5, atol=2e-7), k
