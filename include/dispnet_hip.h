@@ -138,7 +138,7 @@ typedef struct dn_conv_desc {
   const float* bnb_mean;
   const float* bnb_invstd;
   float* bnb_partial;
-  /* Optional (round 3): workspace for the input-channel split of small Winograd grids.  A 4-image shard of the metric's batch leaves the
+  /* Optional (round 3): workspace for the K split of small grids (Winograd input channels; chunks of the three-piece direct kernel).  A 4-image shard of the metric's batch leaves the
    * deep layers 32-104 blocks for 256 CUs, each walking all 32-48 chunks of the K axis alone; with a workspace of at least
    * dn_conv_splitk_workspace_bytes(desc) bytes the three-piece Winograd forward / input gradient splits K over 2-8 blocks per tile; the
    * partial output tiles meet here and the block that arrives last sums them in index order (deterministic) and runs the epilogue.
@@ -173,7 +173,9 @@ int dn_pack_many(const void* entries_dev, int32_t n_direct, int32_t n_wino, int3
 int32_t dn_conv_weight_layout(const dn_conv_desc* d);
 /* Number of row tiles (first dimension of bn_partial) the launch of this descriptor uses. */
 int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d);
-/* Bytes of dn_conv_desc.splitk_ws this call would use (0: the call does not split; < 0: bad descriptor). */
+/* Bytes of dn_conv_desc.splitk_ws this call would use at most (0: the call does not split; < 0: bad descriptor).  Two kernel families
+ * split: the three-piece Winograd forward / input gradient (input channels) and the three-piece direct kernel with one scheduled operand
+ * (chunks of the K axis: the 4x13 / 8x26 transposed convolutions of the decoder). */
 int64_t dn_conv_splitk_workspace_bytes(const dn_conv_desc* d);
 /* 1 if dn_conv2d_dgrad(d) will write bnb_partial (see dn_conv_desc), 0 if it ignores the bnb_* fields, < 0 on a bad descriptor. */
 int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d);

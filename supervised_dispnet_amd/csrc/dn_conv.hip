@@ -877,6 +877,11 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_x3_kernel(const IgemmParams
   const KPhase ph = p.ph[blockIdx.z];
   const int ntaps = ph.ntaps;
   const int Kp = ph.nchunks * kChunk;
+  // K split of small grids (p.ksplit > 1: one scheduled operand, launch_conv_x3): blockIdx.y = kz takes the chunks [kz * cps, (kz + 1) * cps)
+  // of the phase; the partial accumulators meet in a workspace and the block that arrives last sums them in index order and runs the
+  // epilogue.  The 4x13 / 8x26 transposed convolutions of the decoder are 8-104 tiles with 64-256 chunks each.
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  const int kz = ksplit > 1 ? (int)blockIdx.y : 0;
 
   if (tid < 32) taps[tid] = tid < ntaps ? (((int)p.tdy[ph.tap0 + tid] & 0xffff) | ((int)p.tdx[ph.tap0 + tid] << 16)) : 0;
   for (int r = tid; r < BM; r += 256) {
@@ -998,8 +1003,12 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_x3_kernel(const IgemmParams
       bool aok[AR];
       // cursor = the chunk whose loads are issued next: index cn = (tap j, chunk-in-tap cc); its tap word is fetched from LDS
       // one iteration ahead and kept in a VGPR until decoded, so the scalar unit never waits inside the MFMA stream
-      int cn = 0, j = 0, cc = 0;          // UNI: j = tap, cc = chunk within the tap; !UNI: j = first tap of the chunk
-      int tapv = taps[UNI ? 0 : gt];
+      const int cps = (nch + ksplit - 1) / ksplit;
+      const int c_lo = kz * cps, c_hi = (c_lo + cps) < nch ? c_lo + cps : nch;      // this block's chunks (all of them without a split)
+      if (c_lo >= c_hi) return;
+      int cn = c_lo, j = UNI ? c_lo / cpt : c_lo * tpc, cc = UNI ? c_lo % cpt : 0;   // UNI: j = tap, cc = chunk within the tap; !UNI: j = first tap of the chunk
+      wrow += (size_t)c_lo * (kChunk * 4);
+      int tapv = taps[UNI ? j : (j + gt < 32 ? j + gt : 31)];
       unsigned soffB = 0, jbit = 0, coffB = 0;
       const char* wcur = wrow;
 
@@ -1013,7 +1022,7 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_x3_kernel(const IgemmParams
         wcur = wrow;
       };
       auto cursor_advance = [&]() {      // clamps at the last chunk (the final iteration re-fetches it into the idle buffer: no branch)
-        const bool more = cn + 1 < nch;
+        const bool more = cn + 1 < c_hi;
         cn += more ? 1 : 0;
         if constexpr (UNI) {
           const int cc1 = cc + 1;
@@ -1078,7 +1087,7 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_x3_kernel(const IgemmParams
       // (A variant with the store stage mid-iteration, the barrier right after the chunk's last fragment read and the next
       //  chunk's first K group fetched under the last MFMAs measured the same 127-128 TFLOP/s: with two waves per SIMD the
       //  partner wave already covers the LDS latency behind the barrier.  The simpler order is kept.)
-      for (int c = 0; c < nch; ++c) {
+      for (int c = c_lo; c < c_hi; ++c) {
         cursor_decode();                       // chunk min(c+1, nch-1); uses the tap word fetched during the previous iteration
 
         const char* Ab = AsB + buf * ABUF + frXA;
@@ -1233,6 +1242,53 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_x3_kernel(const IgemmParams
     } else {
       run_operand_generic();
     }
+  }
+  if (ksplit > 1) {
+    // partial accumulators -> lane-private float4 slots [tile][split][MI * NI * 4][thread]; the last arrival sums the splits in index
+    // order (deterministic).  Visibility as in wino_conv_kernel: every split of a tile runs on the same XCD (the linear block id is
+    // blockIdx.x + gridDim.x * (kz + ...) with gridDim.x a multiple of 8), so the partial tiles only have to reach that XCD's L2 --
+    // write-through stores waited for with vmcnt(0), an L2 atomic counter, reader loads that bypass the CU's L1 (glc).
+    __shared__ int ks_last;
+    constexpr int NQ = MI * NI * 4;
+    const int tile = (int)blockIdx.z * (MT * NT) + q;
+    int* cnt = reinterpret_cast<int*>(p.ks_ws);
+    f32x4* slots = reinterpret_cast<f32x4*>(p.ks_ws + p.ks_cnt_floats);
+    f32x4* mine = slots + ((size_t)(tile * ksplit + kz) * NQ) * 256 + tid;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          mine[(size_t)((i * NI + jn) * 4 + e) * 256] = f32x4{acc[i][jn][4 * e], acc[i][jn][4 * e + 1], acc[i][jn][4 * e + 2], acc[i][jn][4 * e + 3]};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ks_last = (atomicAdd(cnt + tile, 1) == ksplit - 1) ? 1 : 0;
+    __syncthreads();
+    if (!ks_last) return;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+    const __amdgpu_buffer_rsrc_t rws =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(slots + (size_t)tile * ksplit * NQ * 256), 0, 0x7fffffff, 0x00020000);
+    for (int z = 0; z < ksplit; ++z) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 vi = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(((z * NQ + (i * NI + jn) * 4 + e) * 256 + tid) * 16), 0, 1 /* glc */);
+            const f32x4 v = __builtin_bit_cast(f32x4, vi);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[i][jn][4 * e + u] += v[u];
+          }
+    }
+    if (tid == 0) cnt[tile] = 0;                          // (self-resetting: the workspace is reusable by the next launch on this stream)
   }
   conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
 }
@@ -1942,6 +1998,39 @@ static int launch_conv_u32(const IgemmParams& p, hipStream_t stream) {
   return check_launch("igemm_conv_u32_kernel");
 }
 
+// K split of the three-piece direct kernel for small grids (see the kernel): how many ways, and the workspace that takes.
+constexpr int kX3SplitKCounterBytes = 4096;      // int counters [phase][tile], zero between launches (self-resetting), in front of the partial tiles
+static int x3_splitk_choice(const IgemmParams& p, int tiles) {
+  if (knobs().no_x3_splitk || p.n_in != 1) return 1;
+  const KOperand& S = p.in[0];
+  if (!(S.vec && S.small && S.up == 0 && (S.C % 32 == 0 || S.C == 4 || S.C == 8 || S.C == 16))) return 1;   // the scheduled loaders only
+  const int blocks = tiles * p.nphases;
+  if (blocks > knobs().x3_splitk_maxblocks || blocks > (int)(kX3SplitKCounterBytes / sizeof(int))) return 1;
+  int nch = 1 << 30;                               // fewest chunks of a (non-empty) phase
+  for (int z = 0; z < p.nphases; ++z) {
+    const int nt = p.ph[z].ntaps;
+    if (nt == 0) continue;
+    const int c = S.C % 32 == 0 ? nt * (S.C >> 5) : (nt + 32 / S.C - 1) / (32 / S.C);
+    if (c < nch) nch = c;
+  }
+  if (nch == (1 << 30)) return 1;
+  int ks = knobs().x3_splitk_target / blocks;
+  if (ks > nch / knobs().x3_splitk_minch) ks = nch / knobs().x3_splitk_minch;
+  if (ks > 16) ks = 16;
+  return ks < 2 ? 1 : ks;
+}
+static size_t x3_splitk_workspace_bytes(int blocks, int ks, int tiles_per_wave) {
+  return kX3SplitKCounterBytes + (size_t)blocks * ks * tiles_per_wave * 4 * 256 * sizeof(float) * 4;
+}
+
+// upper bound over the tile shapes run_conv may pick (64-row tiles give the most blocks; two 32 x 32 tiles per wave at most)
+size_t conv_x3_splitk_workspace_upper_bytes(const IgemmParams& p) {
+  if (p.compute != DN_COMPUTE_F32X3 || !p.uni32 || p.BN < 64) return 0;
+  const int tiles = ((p.M + 63) / 64) * (p.Npad / p.BN);
+  const int ks = x3_splitk_choice(p, tiles);
+  return ks > 1 ? x3_splitk_workspace_bytes(tiles * p.nphases, ks, 2) : 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv_x3(const IgemmParams& p, hipStream_t stream) {
   const size_t lds = (size_t)(2 * BM + 2 * BN) * X3ROW + (32 + BM) * sizeof(int);
@@ -1949,8 +2038,18 @@ static int launch_conv_x3(const IgemmParams& p, hipStream_t stream) {
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
-  dim3 grid((tiles + 7) / 8 * 8, 1, p.nphases);
-  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, p);
+  IgemmParams q = p;
+  q.ksplit = 1;
+  {
+    // K split of small grids: one scheduled operand, few blocks, many chunks.  Needs the caller's zeroed workspace (dn_conv_desc.splitk_ws).
+    const int ks = x3_splitk_choice(p, tiles);
+    if (ks > 1 && p.ks_ws != nullptr && p.ks_ws_bytes >= x3_splitk_workspace_bytes(tiles * p.nphases, ks, (WM / 32) * (WN / 32))) {
+      q.ksplit = ks;
+      q.ks_cnt_floats = kX3SplitKCounterBytes / 4;
+    }
+  }
+  dim3 grid((tiles + 7) / 8 * 8, q.ksplit, p.nphases);
+  DN_LAUNCH(kernel, grid, dim3(256), lds, stream, q);
   set_last_kernel("dn::igemm_conv_x3_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);
   return check_launch("igemm_conv_x3_kernel");
 }

@@ -47,6 +47,9 @@ struct Knobs {
   int wino_splitk_target, wino_splitk_minch;   // DN_WINO_SPLITK_TARGET (256 blocks), DN_WINO_SPLITK_MINCH (8 chunks per block)
   int wino_splitk_maxblocks;                   // DN_WINO_SPLITK_MAXBLOCKS: 32-tile x 64-channel blocks at or below which the split is considered
   bool no_wino_splitk;      // DN_NO_WINO_SPLITK: no input-channel split of small Winograd grids
+  int reduce_rows_per_thread, reduce_max_blocks;   // DN_REDUCE_ROWS_PER_THREAD (2), DN_REDUCE_MAX_BLOCKS (1024): grid of the two-stage column reductions
+  bool no_x3_splitk;        // DN_NO_X3_SPLITK: no K split of small grids in the three-piece direct kernel
+  int x3_splitk_target, x3_splitk_minch, x3_splitk_maxblocks;   // DN_X3_SPLITK_TARGET (512 blocks) / _MINCH (8 chunks per block) / _MAXBLOCKS (208)
   bool no_bn_sums_fusion;   // DN_NO_BN_SUMS_FUSION: dn_conv_dgrad_fuses_bn_sums() answers 0 (the engine then runs the separate sums pass)
   int pack_blocks;          // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
   int wino8, wino8_min_k;   // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel; DN_WINO8_MIN_K: its rule's channel floor
@@ -186,6 +189,7 @@ long long wino_packed_elems(const IgemmParams& p);
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream);
 int launch_wino_conv(IgemmParams& p, hipStream_t stream);
 int wino_splitk_choice(const IgemmParams& p);
+size_t conv_x3_splitk_workspace_upper_bytes(const IgemmParams& p);   // dn_conv.hip: K split of the three-piece direct kernel
 size_t wino_splitk_workspace_bytes(const IgemmParams& p);
 // dn_winograd_wgrad.hip: Winograd weight gradient of the same layers (operands and output channels multiples of 64)
 bool wino_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);

@@ -46,7 +46,7 @@ constexpr int kStat = 8;
 constexpr int kSplitMax = 64;
 
 static inline int loss_splits(long long pixels) {
-  long long s = (pixels + 16383) / 16384;
+  long long s = (pixels + 2047) / 2048;       // 8 pixels per thread: a 4-image shard of the metric's batch is 104 blocks, not 16 (40 -> 10 us)
   return (int)(s < 1 ? 1 : (s > kSplitMax ? kSplitMax : s));
 }
 

@@ -104,6 +104,15 @@ static void read_knobs(Knobs* k) {
   k->wino_splitk_minch = num("DN_WINO_SPLITK_MINCH", 8);
   k->wino_splitk_maxblocks = num("DN_WINO_SPLITK_MAXBLOCKS", 128);
   if (k->wino_splitk_minch < 1) k->wino_splitk_minch = 1;
+  k->reduce_rows_per_thread = num("DN_REDUCE_ROWS_PER_THREAD", 2);
+  if (k->reduce_rows_per_thread < 1) k->reduce_rows_per_thread = 1;
+  k->reduce_max_blocks = num("DN_REDUCE_MAX_BLOCKS", 1024);
+  if (k->reduce_max_blocks < 1) k->reduce_max_blocks = 1;
+  k->no_x3_splitk = on("DN_NO_X3_SPLITK");
+  k->x3_splitk_target = num("DN_X3_SPLITK_TARGET", 512);
+  k->x3_splitk_minch = num("DN_X3_SPLITK_MINCH", 8);
+  if (k->x3_splitk_minch < 1) k->x3_splitk_minch = 1;
+  k->x3_splitk_maxblocks = num("DN_X3_SPLITK_MAXBLOCKS", 208);
   k->no_bn_sums_fusion = on("DN_NO_BN_SUMS_FUSION");
   k->pack_blocks = num("DN_PACK_BLOCKS", 512);
   if (k->pack_blocks < 1) k->pack_blocks = 1;
@@ -419,8 +428,9 @@ int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d) {
 int64_t dn_conv_splitk_workspace_bytes(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (d == nullptr || dn::build_plan(d, false, &p) != DN_OK) return -1;
-  if (dn::wino_layout(d, p) != 3) return 0;
-  return (int64_t)dn::wino_splitk_workspace_bytes(p);
+  if (dn::wino_layout(d, p) == 3) return (int64_t)dn::wino_splitk_workspace_bytes(p);
+  if (dn::wino_layout(d, p) != 0) return 0;
+  return (int64_t)dn::conv_x3_splitk_workspace_upper_bytes(p);
 }
 
 // Test/diagnostic hook (host only, no device work): dump the plan as int32s.

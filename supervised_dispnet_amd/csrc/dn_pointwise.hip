@@ -9,7 +9,7 @@ namespace dn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int kMaxReduceBlocks = 1024;
+constexpr int kMaxReduceBlocks = 4096;
 
 static inline int ew_blocks(long long n_items) {
   long long b = (n_items + kThreads - 1) / kThreads;
@@ -24,8 +24,10 @@ static inline int reduce_blocks(long long rows, int C) {
   int tpr = 1;
   while (tpr < groups && tpr < kThreads) tpr <<= 1;
   int rpi = kThreads / tpr;
-  long long b = (rows + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
-  if (b > kMaxReduceBlocks) b = kMaxReduceBlocks;
+  const int rpt = knobs().reduce_rows_per_thread;        // rows each thread walks (DN_REDUCE_ROWS_PER_THREAD, default 2: 8 left a 4-image shard 416 blocks of 8 dependent row visits each)
+  long long b = (rows + (long long)rpi * rpt - 1) / ((long long)rpi * rpt);
+  const int cap = knobs().reduce_max_blocks < kMaxReduceBlocks ? knobs().reduce_max_blocks : kMaxReduceBlocks;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }

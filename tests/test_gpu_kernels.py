@@ -4,6 +4,8 @@ against plain PyTorch-CPU fp32 references of the same op (F.conv2d & co).  Run o
 Tolerances: the MFMA fp32 path is an exact fp32 FMA chain with a different summation order than ATen's CPU kernels,
 so results agree to fp32 round-off: rtol 2e-4 / atol scaled to the magnitude of the result (stated per check).
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -549,5 +551,66 @@ def test_winograd_input_channel_split_for_small_grids(case):
         y3, _, _ = engine.conv_forward(layer, pieces, bn_stats=True)
         torch.cuda.synchronize()
         assert torch.equal(y2, ys) and torch.equal(y3, ys)           # deterministic: the partial tiles are summed in index order
+    finally:
+        engine.SPLITK = prev
+
+
+@pytest.mark.parametrize("case", ["upconv5_b4", "upconv4_b4", "res_1x1s2", "convT_leaky_affine"])
+def test_direct_three_piece_k_split_for_small_grids(case):
+    """dn_conv_desc.splitk_ws in the three-piece direct kernel: the 4x13 / 8x26 transposed convolutions of the decoder (and the small
+    strided convolutions of the ResNet encoders) are 8-104 tiles with 64-256 chunks of K each; blockIdx.y splits the chunks, the last
+    arrival sums the partial accumulators in index order.  Same results as the unsplit launch up to fp32 summation order, forward
+    (all four phases of the transposed convolution) and input gradient; deterministic; the workspace is reusable."""
+    torch.manual_seed(17)
+    if case == "upconv5_b4":
+        mod, N, H, W, tr = nn.ConvTranspose2d(512, 256, 4, 2, 1), 4, 4, 13, True
+    elif case == "upconv4_b4":
+        mod, N, H, W, tr = nn.ConvTranspose2d(256, 128, 4, 2, 1), 4, 8, 26, True
+    elif case == "res_1x1s2":
+        mod, N, H, W, tr = nn.Conv2d(512, 1024, 1, 2, 0), 2, 30, 40, False
+    else:
+        mod, N, H, W, tr = nn.ConvTranspose2d(128, 64, 4, 2, 1), 2, 8, 12, True
+    mod = mod.to(DEV)
+    layer = engine.ConvLayer(mod, transposed=tr)
+    cin = mod.in_channels
+    a = engine.Act(torch.randn(N, H, W, cin, device=DEV), N, H, W, cin)
+    if case == "convT_leaky_affine":
+        a.scale = torch.rand(cin, device=DEV) + 0.5
+        a.shift = torch.rand(cin, device=DEV) - 0.5
+    pieces = [engine.Piece(a, False)]
+    res = {}
+    prev = engine.SPLITK
+    try:
+        for split in (True, False):
+            engine.SPLITK = split
+            a.grad = None
+            y, _, _ = engine.conv_forward(layer, pieces, act=ACT_LEAKY, p0=0.1)
+            kf = _lib.load().dn_last_kernel().decode()
+            OH, OW = y.shape[1], y.shape[2]
+            dy = torch.randn(N, OH, OW, mod.out_channels, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            engine.conv_dgrad(layer, dy, N, OH, OW, pieces, (H, W))
+            kd = _lib.load().dn_last_kernel().decode()
+            torch.cuda.synchronize()
+            res[split] = (y.clone(), a.grad.clone(), kf, kd)
+    finally:
+        engine.SPLITK = prev
+    assert "igemm_conv_x3_kernel" in res[True][2] and res[True][2] == res[False][2], res[True][2]
+    assert "igemm_conv_x3_kernel" in res[True][3], res[True][3]
+    for i in (0, 1):
+        s_, n_ = res[True][i], res[False][i]
+        assert not torch.equal(s_, n_)                                  # the split really ran (different summation cuts)
+        assert float((s_ - n_).abs().max()) <= 2e-5 * float(n_.abs().max())
+    # against the framework's CPU fp32 convolution
+    x_cpu = a.t.permute(0, 3, 1, 2).cpu()
+    if a.scale is not None:
+        x_cpu = F.relu(x_cpu * a.scale.cpu().view(1, -1, 1, 1) + a.shift.cpu().view(1, -1, 1, 1))
+    y_ref = F.leaky_relu(copy.deepcopy(mod).cpu()(x_cpu), 0.1)
+    close(case + ":y", nchw(res[True][0]), y_ref)
+    engine.SPLITK = True
+    try:
+        y2, _, _ = engine.conv_forward(layer, pieces, act=ACT_LEAKY, p0=0.1)
+        y3, _, _ = engine.conv_forward(layer, pieces, act=ACT_LEAKY, p0=0.1)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, res[True][0]) and torch.equal(y3, res[True][0])
     finally:
         engine.SPLITK = prev

@@ -1,7 +1,2 @@
-python -m pytest tests/test_gpu_graph.py -x -q -m gpu 2>&1 | tail -15
-bash tools/_sweep.sh "4 8 32" "DN_BENCH=1"
-for l in eager tape; do for b in 4 8; do
-python bench.py --batch $b --steps 40 --warmup 8 --no-cpu-baseline --profile-steps 0 --alt-steps 0 --launch $l 2>/dev/null | python -c "
-import json,sys
-l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', $b, l['value'], l['ms_per_step'], l['ms_per_step_median'], l['config'].get('launch'), l['config'].get('graph_fallback'))"
-done; done
+python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "k_split or conv_family or input_channel_split" 2>&1 | tail -8
+bash tools/_sweep.sh "4 8 32" DN_X=1 DN_NO_X3_SPLITK=1 "DN_X3_SPLITK_TARGET=256" "DN_X3_SPLITK_TARGET=1024" "DN_X3_SPLITK_MINCH=4" "DN_REDUCE_ROWS_PER_THREAD=2 DN_REDUCE_MAX_BLOCKS=2048" "DN_REDUCE_ROWS_PER_THREAD=4 DN_REDUCE_MAX_BLOCKS=2048" "DN_REDUCE_ROWS_PER_THREAD=2"
