@@ -199,6 +199,9 @@ def exchange_loss_stats(stats, sum_cols, max_cols=(), process_group=None):
     gathered batch on GPU0: a handful of floats per step."""
     if data_parallel_world(process_group) <= 1:
         return stats
+    if stats.is_cuda:
+        from . import engine
+        engine._not_on_tape("the whole-batch loss statistics exchange (framework-side slicing + all-reduce in the forward pass)")
     if sum_cols:
         idx = list(sum_cols)
         part = stats[:, idx].contiguous()

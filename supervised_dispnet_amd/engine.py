@@ -132,6 +132,23 @@ def tape_host_call(fn):
         _lib.call("dn_tape_pause", TAPE["handle"], 0)
 
 
+class outside_tape_pool(object):
+    """Allocate (and initialise with framework ops) a PERSISTENT tensor while a launch tape is being recorded: the recording routes
+    every allocation to the tape's private pool, where a fresh block may be one that an earlier kernel of the same step wrote -- the
+    replay would repeat that write but not the framework-side initialisation.  Inside this block allocations come from the regular
+    pool again."""
+
+    def __enter__(self):
+        self.rec = TAPE
+        if self.rec is not None and self.rec.get("pool") is not None:
+            torch._C._cuda_endAllocateToPool(*self.rec["pool"])
+
+    def __exit__(self, *exc):
+        if self.rec is not None and self.rec.get("pool") is not None:
+            torch._C._cuda_beginAllocateToPool(*self.rec["pool"])
+        return False
+
+
 def cross_stream_use(t, stream):
     """`t` is read / written by work enqueued on `stream`, which is not the stream it was allocated on."""
     t.record_stream(stream)
@@ -191,7 +208,8 @@ def _splitk_workspace(d, device):
     if cur is None:
         with torch.cuda.device(device):
             side = side_stream()["side"].cuda_stream
-        buf = torch.zeros(_SPLITK_BYTES // 4, dtype=torch.float32, device=device)
+        with outside_tape_pool():
+            buf = torch.zeros(_SPLITK_BYTES // 4, dtype=torch.float32, device=device)
         cur = _SPLITK[device.index] = (buf, _SPLITK_BYTES, side, buf.data_ptr())
     if _stream() == cur[2]:
         return

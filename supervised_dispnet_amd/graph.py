@@ -68,7 +68,8 @@ def backward(loss):
     key = (loss.device, loss.dtype, tuple(loss.shape))
     one = _ONES.get(key)
     if one is None:
-        one = _ONES[key] = torch.ones_like(loss)
+        with engine.outside_tape_pool():      # (persistent + initialised by the framework: must not sit in a tape's private pool)
+            one = _ONES[key] = torch.ones_like(loss)
     loss.backward(one)
 
 
@@ -116,7 +117,7 @@ class TapedStep(object):
         handle = lib.dn_tape_begin()
         if not handle:
             raise _lib.DispnetHipError("dn_tape_begin: " + _lib.last_error())
-        rec = {"handle": handle, "keep": [], "host_calls": self.host_calls, "paused": False}
+        rec = {"handle": handle, "keep": [], "host_calls": self.host_calls, "paused": False, "pool": (dev, self._pool.id)}
         engine.TAPE = rec
         torch._C._cuda_beginAllocateToPool(dev, self._pool.id)          # every thread (the backward runs on autograd's)
         try:

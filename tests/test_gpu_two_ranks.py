@@ -61,7 +61,7 @@ def _loss(LF, name, gt, depth):
     return LF.l1_loss(gt, depth, "kitti") if name == "L1" else LF.Multiscale_L1_loss(gt, depth)
 
 
-def _worker(rank, world, port, loss_name, out_dir):
+def _worker(rank, world, port, loss_name, out_dir, taped=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DN_COMM="torch", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -80,7 +80,26 @@ def _worker(rank, world, port, loss_name, out_dir):
         sl = DD.shard_slice(img.shape[0], rank, world)
         img, gt = img[sl].to(dev), gt[sl].to(dev)
         losses, g1 = [], None
-        for it in range(STEPS):
+        if taped:
+            # the same steps through the launch tape: step 1 is recorded (a real step), steps 2.. are replays -- the tape is cut at
+            # every gradient bucket and the all-reduce runs live between the segments (engine.tape_host_call)
+            from supervised_dispnet_amd.graph import TapedStep, backward
+            scale = 0.5
+
+            def step():
+                depth = [reciprocal(d) for d in net(img)]
+                loss = _loss(LF, loss_name, gt, depth)
+                opt.zero_grad()
+                backward(loss)
+                opt.step(grad_scale=red.finish())
+                return loss
+
+            ts = TapedStep(step, optimizer=opt, warmup=0)
+            for it in range(STEPS):
+                losses.append(float(ts().item()))
+            assert ts.segments == len(red.buckets) + 2 and len(ts.host_calls) == len(red.buckets) + 1, (ts.segments, len(red.buckets))
+            g1 = opt.arena.flat_g.clone()            # (after the last step: only compared between the ranks)
+        for it in range(0 if taped else STEPS):
             depth = [reciprocal(d) for d in net(img)]
             loss = _loss(LF, loss_name, gt, depth)
             opt.zero_grad()
@@ -180,3 +199,32 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(loss_name, tmp_path)
         dp = (r0["p"] - p_ref).abs()
         assert float(dp.max()) <= 2.1e-4 * STEPS, float(dp.max())
         assert float((dp > 2e-6).float().mean()) <= 2e-3, float((dp > 2e-6).float().mean())
+
+
+def test_two_ranks_through_the_launch_tape_equal_the_eager_two_rank_run(tmp_path):
+    """graph.TapedStep under data parallelism: the recorded step is cut at every gradient bucket (engine.tape_host_call) and the
+    all-reduce is issued live between the replayed segments.  Two ranks on one GPU, l1_loss, three steps (one recorded + two replays):
+    same collective issue order as the eager run on both ranks, bit-identical parameters across the ranks, and the eager two-rank
+    result up to the last bit of Adam's step size (device-side vs host-side pow() of the bias corrections, as in the hipGraph test)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for taped in (False, True):
+        out = tmp_path / ("taped" if taped else "eager")
+        out.mkdir()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, "L1", str(out), taped)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+        assert all(p.exitcode == 0 for p in procs), (taped, [p.exitcode for p in procs])
+        res[taped] = [torch.load(os.path.join(str(out), "rank%d.pt" % r)) for r in range(2)]
+    t0, t1 = res[True]
+    e0 = res[False][0]
+    assert torch.equal(t0["p"], t1["p"]) and torch.equal(t0["g1"], t1["g1"])
+    assert t0["log"] == t1["log"] == e0["log"]                                   # same buckets, same order, every step
+    assert t0["losses"][0] == e0["losses"][0]
+    for lt, le in zip(t0["losses"], e0["losses"]):
+        assert lt == pytest.approx(le, rel=1e-5)
+    assert torch.allclose(t0["p"], e0["p"], rtol=0, atol=2e-7), float((t0["p"] - e0["p"]).abs().max())
