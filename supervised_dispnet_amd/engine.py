@@ -38,6 +38,8 @@ PROFILE = None
 
 # DN_BN_MATERIALIZE=1: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back) for A/B runs and the equivalence test
 SPLITK = os.environ.get("DN_NO_WINO_SPLITK") is None            # small Winograd grids split their input channels over several blocks
+PACK_ON_SIDE_STREAM = os.environ.get("DN_NO_PACK_SIDE") is None     # batched weight re-lay of the large layers under the first layers of the forward
+PACK_LATE_MIN_ELEMS = int(os.environ.get("DN_PACK_LATE_MIN_ELEMS", "400000"))
 BN_SUMS_FUSION = os.environ.get("DN_NO_BN_SUMS_FUSION") is None     # input-gradient kernels take the BatchNorm backward's column sums of the layer below
 BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
 
@@ -83,6 +85,18 @@ CAPTURING = False
 #   against the caching allocator.
 _WGRAD_STREAM_MODE = os.environ.get("DN_WGRAD_STREAM", "auto")
 WGRAD_STREAM = _WGRAD_STREAM_MODE != "0"
+# Number of side streams the weight gradients alternate between.  At the metric's b32 the device is full and one is as good as two; at
+# 4 images per GPU (b32 over 8 GPUs) no kernel fills the chip and the ONE side stream's queue (2.4 ms of weight-gradient launches that
+# cannot start before the loss) had become the critical path of the step.
+WGRAD_STREAMS = int(os.environ.get("DN_WGRAD_STREAMS", "2"))
+WGRAD_STREAMS_MAX_PIXELS = int(os.environ.get("DN_WGRAD_STREAMS_MAX_PIXELS", str(8 * 128 * 416)))   # measured: b4 -3.8 %, b8 -0.4 %, b32 +0.3 %
+SIDE_STREAMS_ACTIVE = 1
+
+
+def choose_side_streams(input_pixels):
+    """Called with N * H * W of a network's input at the start of its forward pass: how many side streams its weight gradients use."""
+    global SIDE_STREAMS_ACTIVE
+    SIDE_STREAMS_ACTIVE = WGRAD_STREAMS if input_pixels <= WGRAD_STREAMS_MAX_PIXELS else 1
 _SIDE = {}
 
 
@@ -98,7 +112,8 @@ def side_stream():
     dev = torch.cuda.current_device()
     st = _SIDE.get(dev)
     if st is None:
-        st = _SIDE[dev] = {"side": torch.cuda.Stream(device=dev), "main": None}
+        sides = [torch.cuda.Stream(device=dev) for _ in range(max(1, WGRAD_STREAMS))]
+        st = _SIDE[dev] = {"side": sides[0], "sides": sides, "handles": {x.cuda_stream for x in sides}, "main": None, "rr": 0}
     return st
 
 
@@ -161,7 +176,9 @@ def join_side_stream():
     if WGRAD_STREAM and torch.cuda.is_available():
         st = _SIDE.get(torch.cuda.current_device())
         if st is not None:
-            stream_wait(torch.cuda.current_stream(), st["side"])
+            cur = torch.cuda.current_stream()
+            for x in st["sides"]:
+                stream_wait(cur, x)
 
 
 def compute_streams():
@@ -171,9 +188,10 @@ def compute_streams():
     out = [cur]
     st = _SIDE.get(torch.cuda.current_device())
     if WGRAD_STREAM and st is not None:
-        if st["side"] != cur:
-            out.append(st["side"])
-        if st["main"] is not None and st["main"] != cur and st["main"] != st["side"]:
+        for x in st["sides"]:
+            if x != cur:
+                out.append(x)
+        if st["main"] is not None and st["main"] != cur and st["main"] not in st["sides"]:
             out.append(st["main"])
     return out
 
@@ -187,8 +205,9 @@ def fence_streams():
     if st is None:
         return
     cur = torch.cuda.current_stream()
-    if cur != st["side"]:
-        stream_wait(cur, st["side"])
+    for x in st["sides"]:
+        if cur != x:
+            stream_wait(cur, x)
     if st["main"] is not None and cur != st["main"]:
         stream_wait(cur, st["main"])
 
@@ -207,11 +226,11 @@ def _splitk_workspace(d, device):
     cur = _SPLITK.get(device.index)
     if cur is None:
         with torch.cuda.device(device):
-            side = side_stream()["side"].cuda_stream
+            side = side_stream()["handles"]
         with outside_tape_pool():
             buf = torch.zeros(_SPLITK_BYTES // 4, dtype=torch.float32, device=device)
         cur = _SPLITK[device.index] = (buf, _SPLITK_BYTES, side, buf.data_ptr())
-    if _stream() == cur[2]:
+    if _stream() in cur[2]:
         return
     d.splitk_ws = cur[3]
     d.splitk_ws_bytes = cur[1]
@@ -469,6 +488,8 @@ class ConvLayer:
         table = pack_table(w.device) if w.is_cuda else None
         if table is not None and hit is not None and hit[0][:2] + hit[0][3:] == key[:2] + key[3:] and table.fresh(hit[1], PARAM_EPOCH):
             self._packed[(kind, layout)] = (key, hit[1])      # re-laid by the batched launch of this epoch
+            if table.pending is not None:
+                table.consumer_wait(hit[1])
             return hit[1]
         n = lib.dn_conv_packed_weight_elems(C.byref(desc))
         if n < 0:
@@ -505,6 +526,14 @@ class PackTable(object):
         self.epoch = -1                 # PARAM_EPOCH whose weights the buffers of `covered` hold
         self.covered = set()
         self.esize = int(_lib.load().dn_pack_entry_bytes())
+        # The re-lay of the LARGE weights (the 256 / 512-channel layers: 95 % of the bytes) runs on the weight-gradient side stream, under
+        # the first layers of the forward pass, which do not need them; `pending` = (side stream, buffers it covers) until the first
+        # consumer of one of them has made its stream wait (consumer_wait).  0.15 ms off the critical path of every step.
+        self.late_table = None
+        self.late_counts = (0, 0, 0, 0)
+        self.late = set()
+        self.pending = None
+        self.split_mode = None
 
     def register(self, key, desc, w, buf, owner):
         if len(self.rows) >= self.MAX_ROWS:
@@ -539,16 +568,45 @@ class PackTable(object):
         self._prune()
         if not self.rows:
             return
-        if self.dirty:
-            kinds = [[r for r in self.rows.values() if r[1] == k] for k in (0, 1, 2, 3)]   # direct, Winograd fp32 / bf16 / 3 x bf16
-            ordered = kinds[0] + kinds[1] + kinds[2] + kinds[3]
-            blob = b"".join(r[0] for r in ordered)
-            self.dev_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
-            self.counts = tuple(len(k) for k in kinds)
-            self.covered = {r[5] for r in ordered}
+        split = PACK_ON_SIDE_STREAM and wgrad_stream_enabled()
+        if self.dirty or split != self.split_mode:
+            def upload(rows):
+                kinds = [[r for r in rows if r[1] == k] for k in (0, 1, 2, 3)]   # direct, Winograd fp32 / bf16 / 3 x bf16
+                ordered = kinds[0] + kinds[1] + kinds[2] + kinds[3]
+                if not ordered:
+                    return None, (0, 0, 0, 0)
+                blob = b"".join(r[0] for r in ordered)
+                with outside_tape_pool():
+                    return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device), tuple(len(k) for k in kinds)
+            rows = list(self.rows.values())
+            late = [r for r in rows if split and (r[2]() is not None and r[2]().numel() > PACK_LATE_MIN_ELEMS)]
+            early = [r for r in rows if not any(r is q for q in late)]
+            self.dev_table, self.counts = upload(early)
+            self.late_table, self.late_counts = upload(late)
+            self.late = {r[5] for r in late}
+            self.covered = {r[5] for r in rows}
             self.dirty = False
-        _lib.call("dn_pack_many", self.dev_table.data_ptr(), *self.counts, _stream())
+            self.split_mode = split
+        if self.dev_table is not None:
+            _lib.call("dn_pack_many", self.dev_table.data_ptr(), *self.counts, _stream())
+        if self.late_table is not None:
+            st = side_stream()
+            main, side = torch.cuda.current_stream(), st["side"]
+            stream_wait(side, main)                  # the optimizer step that produced these weights
+            _lib.call("dn_pack_many", self.late_table.data_ptr(), *self.late_counts, side.cuda_stream)
+            self.pending = (side, main)
         self.epoch = epoch
+
+    def consumer_wait(self, buf):
+        """First use of a buffer the side stream is re-laying: the consumer's stream waits for it (once per step)."""
+        if self.pending is None or buf.data_ptr() not in self.late:
+            return
+        side, main = self.pending
+        h = _stream()
+        if h == side.cuda_stream:
+            return                                   # (stream order; the main stream's first consumer still has to wait)
+        stream_wait(main if h == main.cuda_stream else torch.cuda.current_stream(), side)
+        self.pending = None
 
 
 _PACK_TABLES = {}
@@ -614,7 +672,7 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
     return y, partial, rows
 
 
-def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None):
+def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None, first=None):
     """Weight gradient in the framework layout (same shape as module.weight); written into `out` when given.  With `sink` the
     gradient is also handed to it here (inside the side-stream context when DN_WGRAD_STREAM=1, so that a data-parallel bucket
     launched by this gradient is fenced against the stream that computes it)."""
@@ -647,13 +705,24 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None):
             sink.put(layer.m.weight, dw)
         return dw
 
+    # `first` = (callable, tensor it reads): work only the optimizer waits for (the second stage of the bias gradient's column sums),
+    # run where the weight gradient runs
     if not (dy.is_cuda and wgrad_stream_enabled()):
+        if first is not None:
+            first[0]()
         return launch()
     st = side_stream()
-    main, side = torch.cuda.current_stream(), st["side"]
+    main = torch.cuda.current_stream()
+    side = st["sides"][st["rr"] % min(len(st["sides"]), max(1, SIDE_STREAMS_ACTIVE))]   # weight gradients of successive layers alternate between the side streams
+    st["rr"] += 1
     st["main"] = main
     stream_wait(side, main)                      # dy, the operands and the bias / BatchNorm gradients of this layer are ready
     with stream_scope(side):
+        if first is not None:
+            fresh = first[0]()
+            cross_stream_use(first[1], side)
+            if fresh is not None:
+                cross_stream_use(fresh, main)
         dw = launch()
     cross_stream_use(dy, side)                   # the caching allocator must not hand these to the main stream while side reads them
     for p in pieces:
@@ -765,12 +834,16 @@ def colsum(partial, rows, Cn, stride=1, offset=0, out=None):
     return out
 
 
-def act_bwd(g, y_post, act, p0, p1, rows, Cn, out=None):
-    """g <- g * act'(y_post) in place; returns the bias gradient (column sums of the result), written into `out` if given."""
+def act_bwd(g, y_post, act, p0, p1, rows, Cn, out=None, defer=False):
+    """g <- g * act'(y_post) in place; returns the bias gradient (column sums of the result), written into `out` if given.
+    `defer`: returns (finish, partial) instead -- finish() runs the second stage of the column sums and returns the bias gradient; only
+    the optimizer reads it, so conv_wgrad runs it on the weight-gradient side stream (a 5 us launch per layer off the critical path)."""
     nblk = _lib.load().dn_reduce_blocks(rows, Cn)
     partial = torch.empty((nblk, Cn), dtype=torch.float32, device=g.device)
     hbm_call("dn::colreduce_kernel<dn::ActBwdOp, %d>" % (4 if Cn % 4 == 0 else 1), rows * Cn * 12, "dn_act_bwd_reduce", g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn,
              partial.data_ptr(), _stream())
+    if defer:
+        return (lambda: colsum(partial, nblk, Cn, out=out)), partial
     return colsum(partial, nblk, Cn, out=out)
 
 
@@ -994,10 +1067,16 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
                 sink.put_none(layer.m.bias)
             return
         g = y.grad
-        db = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout, out=sink.dest(layer.m.bias) if layer.m.bias is not None else None)
-        if layer.m.bias is not None:
-            sink.put(layer.m.bias, db)
-        conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink)
+        finish_db, db_partial = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout,
+                                        out=sink.dest(layer.m.bias) if layer.m.bias is not None else None, defer=True)
+
+        def bias_grad():
+            db = finish_db()
+            if layer.m.bias is not None:
+                sink.put(layer.m.bias, db)
+            return db if (layer.m.bias is None or sink.dest(layer.m.bias) is None) else None      # (a fresh tensor the caller's stream will read)
+
+        conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink, first=(bias_grad, db_partial))
         conv_dgrad(layer, g, a0.N, OH, OW, pieces, in_hw)
         y.grad = None
 

@@ -81,6 +81,8 @@ class HipNetFunction(torch.autograd.Function):
         in_acts = [engine.Act.from_nchw(x, needs_grad=recording and ctx.needs_input_grad[3 + i]) for i, x in enumerate(inputs)]
         with engine.stream_scope():
             if inputs:
+                if recording:
+                    engine.choose_side_streams(inputs[0].shape[0] * inputs[0].shape[-2] * inputs[0].shape[-1])
                 engine.prepack_all(inputs[0].device)
             outs = net._hip_forward(tape, sink, *in_acts)     # list[Act]
         ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
