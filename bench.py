@@ -263,6 +263,10 @@ def main():
                          "and re-issued by one C call per step -- same kernels, streams and fences as eager, ~2 us of host time per launch "
                          "instead of ~20 (the step is launch-bound at 4 images per GPU); graph: hipGraph replay (= --graph 1); "
                          "auto: tape for the metric's config when the recording succeeds, else eager (config.launch says which ran)")
+    ap.add_argument("--adam-overlap", default="auto", choices=["auto", "0", "1"],
+                    help="1: the Adam update of a gradient bucket runs as soon as the bucket (and its all-reduce) is complete, on its own "
+                         "stream under the rest of the backward pass (FusedAdam.overlap_backward; bit-identical to the single update); "
+                         "auto: on for the metric's config")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only plumbing check of the N>1 path: build the net, the arena, the buckets, one fake all-reduce cycle, tear down")
     args = ap.parse_args()
@@ -313,7 +317,12 @@ def main():
     else:
         batch = args.batch or cfg_batch
     step, opt, state, desc = build_workload(args.config, batch, dev, rank, models, LF, U, reciprocal, FusedAdam)
-    reducer = GradReducer(opt.arena) if world > 1 else None
+    overlap_adam = args.adam_overlap == "1" or (args.adam_overlap == "auto" and args.config == "vggbn128")
+    # one rank: the reducer exchanges nothing (comm "torch" at world 1 = no collective) and only tells the optimizer when a bucket of
+    # gradients is complete
+    reducer = GradReducer(opt.arena, comm=(None if world > 1 else "torch")) if (world > 1 or overlap_adam) else None
+    if overlap_adam:
+        opt.overlap_backward(reducer)
     state["reducer"] = reducer
     engine.GradSink.reducer = reducer
 
@@ -539,7 +548,7 @@ def main():
                        "launch": ("one hipGraph replay per step" if graphed else
                                   ("launch tape: %d launches + %d stream fences of one recorded step re-issued by dn_tape_replay, %d segment(s)"
                                    % (taped.launches, taped.fences, taped.segments)) if taped is not None else "eager launches"),
-                       "graph_fallback": graph_note,
+                       "graph_fallback": graph_note, "adam": "per bucket, under the backward pass" if overlap_adam else "one pass after the backward",
                        "comm": reducer.path if reducer is not None else "none (one rank)",
                        "dist_backend": dist.get_backend() if world > 1 else None},
             "step_tflops_credited_per_gpu": (step_credited_flops / sec_step / 1e12) if step_credited_flops else None,

@@ -468,6 +468,10 @@ int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
  * the bias corrections on every replay and a scheduler changes lr by writing hyper[0]. */
 int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* hyper, double eps, double weight_decay,
                      int32_t* step, float* derived, double grad_scale, dn_stream_t stream);
+/* Ranges of one arena updated by several calls (a bucket at a time, as its gradients -- and their all-reduce -- complete, under the rest of
+ * the backward pass): dn_adam_tick advances the counter and the derived values ONCE per optimizer step, then every range is a
+ * dn_adam_step_dev with step = NULL (no tick; `derived` as the tick left it).  Element-wise arithmetic: the same result as one call. */
+int dn_adam_tick(const double* hyper, int32_t* step, float* derived, dn_stream_t stream);
 int dn_fill(float* p, float value, int64_t n, dn_stream_t stream);
 /* dst[i] = src[i], n floats (the owned copy engine.seed_grad takes of a gradient autograd hands over; on the launch tape like every
  * other kernel of this library, which a framework-side copy would not be). */

@@ -13,7 +13,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 # ABI version this binding was written against (include/dispnet_hip.h: dn_version(), bumped on any signature / struct change).
 # load() refuses a library that reports anything else: a stale .so (DISPNET_HIP_LIB, a build that did not re-run) would otherwise
 # read struct fields past the end of what this binding fills in and mis-marshal arguments -- silent memory corruption, not an error.
-EXPECTED_ABI = 10
+EXPECTED_ABI = 11
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
@@ -154,6 +154,7 @@ SIGNATURES = {
     "dn_channel_scale": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "dn_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i32, _d, _vp]),
     "dn_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _d, _d, _vp, _vp, _d, _vp]),
+    "dn_adam_tick": (C.c_int, [_vp, _vp, _vp, _vp]),
     "dn_fill": (C.c_int, [_vp, _f, _i64, _vp]),
     "dn_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "dn_tape_begin": (_vp, []),

@@ -1133,12 +1133,18 @@ int dn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double
 
 int dn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* hyper, double eps, double weight_decay,
                      int32_t* step, float* derived, double grad_scale, dn_stream_t stream) {
-  DN_REQUIRE(p && g && m && v && n > 0 && hyper && step && derived, DN_ERR_BAD_ARG, "dn_adam_step_dev: bad argument");
+  DN_REQUIRE(p && g && m && v && n > 0 && hyper && derived, DN_ERR_BAD_ARG, "dn_adam_step_dev: bad argument");
   hipStream_t s = as_stream(stream);
-  DN_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, s, step, hyper, derived);
+  if (step != nullptr) DN_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, s, step, hyper, derived);
   DN_LAUNCH(adam_dev_kernel, dim3(ew_blocks(n)), dim3(kThreads), 0, s, p, g, m, v, (long long)n, (float)eps, (float)weight_decay,
                      derived, (float)grad_scale);
   return check_launch("adam_dev_kernel");
+}
+
+int dn_adam_tick(const double* hyper, int32_t* step, float* derived, dn_stream_t stream) {
+  DN_REQUIRE(hyper && step && derived, DN_ERR_BAD_ARG, "dn_adam_tick: bad argument");
+  DN_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, as_stream(stream), step, hyper, derived);
+  return check_launch("adam_tick_kernel");
 }
 
 }  // extern "C"

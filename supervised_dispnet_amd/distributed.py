@@ -128,16 +128,49 @@ class GradReducer(object):
                 self._bucket_of[id(p)] = bi
         self._pending = None
         self._handles = []
+        self.optimizer = None           # FusedAdam.overlap_backward(): ranges of the update are applied as the buckets complete
+        self._opt_stream = None
+        self._applied = set()
+        self._step_applied = False
         self.reset()
 
     def reset(self):
         self._pending = [len(b["params"]) for b in self.buckets]
         self._handles = []
 
+    def take_step_applied(self):
+        """True once per finished backward pass whose buckets were all updated (consumed by FusedAdam.step)."""
+        done, self._step_applied = self._step_applied, False
+        return done
+
+    def _host_work(self):
+        """True when handing a bucket over involves work outside libdispnet_hip (a collective): under a launch tape such a call is a
+        cut with a live host call; with one rank and no communicator everything a bucket triggers is launches and fences of this
+        library and goes on the tape."""
+        return self.world > 1 or self.comm is not None
+
+    def _apply(self, bi, handle):
+        """The optimizer's update of bucket bi, on its own stream, once the bucket's gradients are final (optimizer.overlap_backward)."""
+        from . import engine
+        b = self.buckets[bi]
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.arena.flat_g.device)
+        O = self._opt_stream
+        if self.comm is not None:
+            engine.stream_wait(O, self.comm.stream)                  # behind the ncclAllReduce just enqueued on the library's stream
+        elif handle is not None:
+            with torch.cuda.stream(O):
+                handle.wait()                                        # O waits for this bucket's collective only
+        else:
+            engine.stream_wait(O, torch.cuda.current_stream())       # (fence_streams() has made it wait for every compute stream)
+        with engine.stream_scope(O):
+            self.optimizer.apply_range(b["lo"], b["hi"], 1.0 / self.world, tick=not self._applied)
+        self._applied.add(bi)
+
     def _launch(self, bi):
         """Hand bucket bi to the communicator -- host work in the middle of the backward pass: under a launch tape
         (graph.TapedStep) the tape is cut here and this runs live between the replayed segments."""
-        if self.arena.flat_g.is_cuda:
+        if self.arena.flat_g.is_cuda and self._host_work():
             from . import engine
             return engine.tape_host_call(lambda: self._launch_now(bi))
         return self._launch_now(bi)
@@ -145,17 +178,23 @@ class GradReducer(object):
     def _launch_now(self, bi):
         b = self.buckets[bi]
         _log("bucket", b["lo"], b["hi"])
+        overlap = self.optimizer is not None and self.arena.flat_g.is_cuda
         if self.comm is not None:
             from . import engine                 # gradients of one bucket come from two HIP streams (engine.WGRAD_STREAM)
             self.comm.all_reduce_sum_(self.arena.flat_g[b["lo"]:b["hi"]], engine.compute_streams())
             self._used_comm = True
+            if overlap:
+                self._apply(bi, None)
             return
         if self.arena.flat_g.is_cuda:
             from . import engine
             engine.fence_streams()
+        handle = None
         if self.world > 1:
-            self._handles.append(dist.all_reduce(self.arena.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM,
-                                                 group=self.group, async_op=True))
+            handle = dist.all_reduce(self.arena.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._handles.append(handle)
+        if overlap:
+            self._apply(bi, handle)
 
     def grad_ready(self, param):
         """Engine hook: the gradient of `param` has been written into its arena view."""
@@ -170,11 +209,14 @@ class GradReducer(object):
         """Launch whatever did not complete through grad_ready (e.g. parameters without gradient this step), wait for
         all buckets (stream-level wait, no host sync on the nccl backend) and return the 1/world factor for the optimizer."""
         leftover = [bi for bi, n in enumerate(self._pending) if n > 0]       # (decided once: a tape replay repeats THIS step's decisions)
-        if self.arena.flat_g.is_cuda:
+        if self.arena.flat_g.is_cuda and self._host_work():
             from . import engine
             engine.tape_host_call(lambda: self._finish_now(leftover))
         else:
             self._finish_now(leftover)
+        if self.optimizer is not None and self._opt_stream is not None:
+            from . import engine
+            engine.stream_wait(torch.cuda.current_stream(), self._opt_stream)     # (recorded on a launch tape: outside the host call)
         return 1.0 / self.world
 
     def _finish_now(self, leftover):
@@ -184,6 +226,11 @@ class GradReducer(object):
             h.wait()
         if self.comm is not None:
             self.comm.join()                     # the optimizer (current stream) waits for the last bucket; no host sync
+        if self.optimizer is not None and self.arena.flat_g.is_cuda:
+            if len(self._applied) != len(self.buckets):
+                raise RuntimeError("GradReducer: %d of %d buckets updated" % (len(self._applied), len(self.buckets)))
+            self._applied = set()                # (here, not in the optimizer: a launch tape replays this call, not optimizer.step())
+            self._step_applied = True
         self.reset()
 
 

@@ -55,6 +55,7 @@ class FusedAdam(object):
         self.param_groups = [{"params": self.arena.params, "lr": self.lr, "betas": self.betas, "eps": self.eps,
                               "weight_decay": self.weight_decay}]
         self._dev = None          # capturable(): device-resident step counter / hyper-parameters for hipGraph replay
+        self._overlap = None      # overlap_backward(): the bucket watcher that applies ranges of the update as their gradients complete
 
     def capturable(self, on=True):
         """Keep the step counter and (lr, beta1, beta2) on the DEVICE (dn_adam_step_dev) so that a captured hipGraph of the
@@ -85,9 +86,51 @@ class FusedAdam(object):
         for p in self.arena.params:
             p.grad = None
 
+    def overlap_backward(self, reducer):
+        """Apply the update a gradient bucket at a time, as soon as the bucket's gradients (and, under data parallelism, their
+        all-reduce) are complete, on a stream of its own under the rest of the backward pass (distributed.GradReducer drives it; with
+        one rank the reducer exchanges nothing and only watches the buckets).  Element-wise arithmetic: bit-identical to one update
+        of the whole arena.  What is left at step() is bookkeeping; the unoverlappable tail of a step shrinks from the whole
+        arena's 0.09 ms pass to the last ~1 MB bucket's.  Contract: exactly one backward pass per step(), through the engine (no
+        gradient accumulation, no stray autograd .grad on the arena's parameters)."""
+        self._overlap = reducer
+        if reducer is not None:
+            reducer.optimizer = self
+        return self
+
+    @torch.no_grad()
+    def apply_range(self, lo, hi, grad_scale=1.0, tick=True):
+        """Adam update of arena elements [lo, hi) on the current stream (engine.stream_scope); `tick`: this is the first range of the
+        optimizer step (the device-side counter and bias corrections advance once per step)."""
+        a = self.arena
+        g = self.param_groups[0]
+        n = hi - lo
+        ptr = lambda t: t.data_ptr() + 4 * lo
+        if self._dev is not None:
+            d = self._dev
+            if d["lr"] != float(g["lr"]):
+                self.set_lr(g["lr"])
+            if tick:
+                _lib.call("dn_adam_tick", d["hyper"].data_ptr(), d["step"].data_ptr(), d["derived"].data_ptr(), engine._stream())
+            engine.hbm_call("dn::adam_dev_kernel", n * 28, "dn_adam_step_dev", ptr(a.flat_p), ptr(a.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                            n, d["hyper"].data_ptr(), self.eps, self.weight_decay, None, d["derived"].data_ptr(), float(grad_scale), engine._stream())
+        else:
+            engine.hbm_call("dn::adam_kernel", n * 28, "dn_adam_step", ptr(a.flat_p), ptr(a.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq), n,
+                            float(g["lr"]), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count + 1, float(grad_scale),
+                            engine._stream())
+
     @torch.no_grad()
     def step(self, grad_scale=1.0):
         a = self.arena
+        if self._overlap is not None:
+            # every range was applied as its bucket completed (GradReducer.finish() has applied the stragglers and joined the stream)
+            if not self._overlap.take_step_applied():
+                raise RuntimeError("FusedAdam.overlap_backward: step() without a backward pass + GradReducer.finish() before it")
+            if any(p.grad is not None for p in a.params):
+                raise RuntimeError("FusedAdam.overlap_backward: a parameter received its gradient through autograd (.grad), not the engine")
+            self.step_count += 1
+            engine.bump_param_epoch()
+            return
         a.gather_stray_grads()
         self.step_count += 1
         g = self.param_groups[0]

@@ -166,3 +166,61 @@ def test_launch_tape_replay_is_bitwise_the_eager_step(batch, h, w):
     st, se = net_t.state_dict(), net_e.state_dict()
     for k in st:
         assert torch.allclose(st[k].float(), se[k].float(), rtol=1e-5, atol=2e-7), k
+
+
+@pytest.mark.parametrize("taped", [False, True], ids=["eager", "taped"])
+def test_adam_per_bucket_under_the_backward_pass_is_bitwise_the_single_update(taped):
+    """FusedAdam.overlap_backward: the update of a gradient bucket is enqueued on the optimizer's own stream as soon as the bucket's
+    gradients are complete (distributed.GradReducer watches the buckets; one rank: nothing is exchanged) and runs under the rest of
+    the backward pass.  Element-wise arithmetic: parameters, moments and losses equal the single whole-arena update bit for bit --
+    eagerly, and with the whole step (ranges, tick, fences against both compute streams) on a launch tape."""
+    from supervised_dispnet_amd import engine
+    from supervised_dispnet_amd.distributed import GradReducer
+    from supervised_dispnet_amd.graph import TapedStep, backward
+    batches = [bench.synthetic_batch(4, 64, 96, DEV, seed) for seed in range(4)]
+    net_a, opt_a = _make()
+    sd0 = copy.deepcopy({k: v.detach().cpu().clone() for k, v in net_a.state_dict().items()})
+    net_b, opt_b = _make(sd0)
+    opt_a.capturable(True)
+    opt_b.capturable(True)
+    red = GradReducer(opt_b.arena, bucket_bytes=8 << 20, comm="torch")
+    assert red.path == "none" and len(red.buckets) >= 4
+    opt_b.overlap_backward(red)
+    img, gt = batches[0][0].clone(), batches[0][1].clone()
+
+    def step_a(x, y):
+        depth = [reciprocal(d) for d in net_a(x)]
+        loss = LF.l1_loss(y, depth, "kitti")
+        opt_a.zero_grad()
+        backward(loss)
+        opt_a.step()
+        return loss
+
+    def step_b():
+        engine.GradSink.reducer = red
+        try:
+            depth = [reciprocal(d) for d in net_b(img)]
+            loss = LF.l1_loss(gt, depth, "kitti")
+            opt_b.zero_grad()
+            backward(loss)
+            opt_b.step(grad_scale=red.finish())
+        finally:
+            engine.GradSink.reducer = None
+        return loss
+
+    f = TapedStep(step_b, optimizer=opt_b, warmup=1, static_inputs=(img, gt)) if taped else step_b
+    if taped:
+        f.capture()                    # one warm-up + the recorded step on batch 0
+        for _ in range(2):
+            step_a(*batches[0])
+        assert f.segments == 1
+    for x, y in batches:
+        img.copy_(x)
+        gt.copy_(y)
+        lb = f().clone()
+        la = step_a(x, y).clone()
+        assert torch.equal(la, lb)
+    torch.cuda.synchronize()
+    assert int(opt_a._dev["step"].item()) == int(opt_b._dev["step"].item()) == (6 if taped else 4)
+    assert torch.equal(opt_a.arena.flat_p, opt_b.arena.flat_p)
+    assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)

