@@ -8,6 +8,8 @@ encoder backward.  RCCL runs on its own HIP stream; torch.distributed inserts th
 stream.  The 1/world factor is folded into the Adam kernel.  BatchNorm statistics stay per-replica, exactly like the
 reference's DataParallel (no SyncBN).  Device-agnostic on purpose: the same code runs over gloo on CPU in the tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -131,6 +133,8 @@ class GradReducer(object):
         self.optimizer = None           # FusedAdam.overlap_backward(): ranges of the update are applied as the buckets complete
         self._opt_stream = None
         self._applied = set()
+        self._lagging = None
+        self._opt_used = set()
         self._step_applied = False
         self.reset()
 
@@ -153,19 +157,40 @@ class GradReducer(object):
         """The optimizer's update of bucket bi, on its own stream, once the bucket's gradients are final (optimizer.overlap_backward)."""
         from . import engine
         b = self.buckets[bi]
-        if self._opt_stream is None:
-            self._opt_stream = torch.cuda.Stream(device=self.arena.flat_g.device)
-        O = self._opt_stream
+        # Which stream: the weight-gradient side stream this event comes from (or the first one).  A stream of the optimizer's own
+        # was measured SLOWER (b4 4.01 -> 4.18 ms, b32 +0.07 ms): a fourth concurrent queue costs more than the update's overlap gains,
+        # like a third weight-gradient stream (engine.WGRAD_STREAMS).  DN_ADAM_STREAM=own keeps the dedicated stream for measurements.
+        cur = torch.cuda.current_stream()
+        sides = engine.side_stream()["sides"] if engine.wgrad_stream_enabled() else []
+        if os.environ.get("DN_ADAM_STREAM") == "own" or not sides:
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream(device=self.arena.flat_g.device)
+            O = self._opt_stream
+        else:
+            O = cur if cur in sides else sides[0]
+        self._opt_used.add(O)
         if self.comm is not None:
-            engine.stream_wait(O, self.comm.stream)                  # behind the ncclAllReduce just enqueued on the library's stream
+            engine.stream_wait(O, self.comm.stream)                  # behind the ncclAllReduce enqueued on the library's stream
         elif handle is not None:
             with torch.cuda.stream(O):
-                handle.wait()                                        # O waits for this bucket's collective only
-        else:
-            engine.stream_wait(O, torch.cuda.current_stream())       # (fence_streams() has made it wait for every compute stream)
+                handle.wait()                                        # O waits for this bucket's collective
+        # ... and for everything enqueued so far on the compute streams: the gradients of the bucket (one rank: nothing else orders
+        # them) and every kernel that still READS the bucket's parameters (see _bucket_ready).  Only O waits; no compute stream stalls.
+        for st in engine.compute_streams():
+            if st != O:
+                engine.stream_wait(O, st)
         with engine.stream_scope(O):
             self.optimizer.apply_range(b["lo"], b["hi"], 1.0 / self.world, tick=not self._applied)
         self._applied.add(bi)
+
+    def _bucket_ready(self, bi, handle):
+        """Bucket bi is complete (and its collective enqueued).  Its update is applied ONE EVENT LATE -- when the next bucket completes,
+        or in finish(): the layer whose weight gradient completed the bucket enqueues its input gradient right after, and that call
+        may still re-lay the layer's weights from the arena (engine.ConvLayer.packed: first step, a new geometry); by the next event
+        that read is enqueued, and the optimizer's stream waits for it."""
+        if self._lagging is not None:
+            self._apply(*self._lagging)
+        self._lagging = (bi, handle)
 
     def _launch(self, bi):
         """Hand bucket bi to the communicator -- host work in the middle of the backward pass: under a launch tape
@@ -184,17 +209,17 @@ class GradReducer(object):
             self.comm.all_reduce_sum_(self.arena.flat_g[b["lo"]:b["hi"]], engine.compute_streams())
             self._used_comm = True
             if overlap:
-                self._apply(bi, None)
+                self._bucket_ready(bi, None)
             return
-        if self.arena.flat_g.is_cuda:
-            from . import engine
-            engine.fence_streams()
         handle = None
         if self.world > 1:
+            if self.arena.flat_g.is_cuda:
+                from . import engine
+                engine.fence_streams()
             handle = dist.all_reduce(self.arena.flat_g[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._handles.append(handle)
         if overlap:
-            self._apply(bi, handle)
+            self._bucket_ready(bi, handle)
 
     def grad_ready(self, param):
         """Engine hook: the gradient of `param` has been written into its arena view."""
@@ -214,9 +239,13 @@ class GradReducer(object):
             engine.tape_host_call(lambda: self._finish_now(leftover))
         else:
             self._finish_now(leftover)
-        if self.optimizer is not None and self._opt_stream is not None:
+        if self.optimizer is not None and self._opt_used:
             from . import engine
-            engine.stream_wait(torch.cuda.current_stream(), self._opt_stream)     # (recorded on a launch tape: outside the host call)
+            cur = torch.cuda.current_stream()
+            for st in self._opt_used:
+                if st != cur:
+                    engine.stream_wait(cur, st)                                   # (recorded on a launch tape: outside the host call)
+            self._opt_used = set()
         return 1.0 / self.world
 
     def _finish_now(self, leftover):
@@ -227,6 +256,9 @@ class GradReducer(object):
         if self.comm is not None:
             self.comm.join()                     # the optimizer (current stream) waits for the last bucket; no host sync
         if self.optimizer is not None and self.arena.flat_g.is_cuda:
+            if self._lagging is not None:
+                self._apply(*self._lagging)
+                self._lagging = None
             if len(self._applied) != len(self.buckets):
                 raise RuntimeError("GradReducer: %d of %d buckets updated" % (len(self._applied), len(self.buckets)))
             self._applied = set()                # (here, not in the optimizer: a launch tape replays this call, not optimizer.step())
