@@ -367,14 +367,16 @@ __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __res
   if (lane == 0) out[c] = (float)s;
 }
 
-// both BatchNorm-backward sums of a channel in one launch: out0[c] = sum_r partial[r][c][offset], out1[c] = sum_r partial[r][c][offset + 1]
+// both BatchNorm-backward sums of a channel in one launch: out0[c] = sum_r partial[r][c][offset], out1[c] = sum_r partial[r][c][offset + 1].
+// One block of 256 threads per channel (was: one wave per channel, four channels per block): at 32 images the input-gradient epilogues
+// leave up to 13 312 partial rows per channel, and 16 blocks of strided 8-byte reads took 22-40 us per layer.  The rows meet in double
+// precision in a fixed order (thread-strided partial sums, then a tree over the 256 threads): deterministic.
 __global__ void __launch_bounds__(256) colsum2_finalize_kernel(const float* __restrict__ partial, int rows, int C, int stride, int offset,
                                                                float* __restrict__ out0, float* __restrict__ out1) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int r = lane; r < rows; r += 64) {
+#pragma unroll 4
+  for (int r = threadIdx.x; r < rows; r += 256) {
     const float* q = partial + ((long long)r * C + c) * stride + offset;
     s0 += (double)q[0];
     s1 += (double)q[1];
@@ -384,9 +386,15 @@ __global__ void __launch_bounds__(256) colsum2_finalize_kernel(const float* __re
     s0 += __shfl_xor(s0, o);
     s1 += __shfl_xor(s1, o);
   }
-  if (lane == 0) {
-    out0[c] = (float)s0;
-    out1[c] = (float)s1;
+  __shared__ double red[2][4];
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s0;
+    red[1][threadIdx.x >> 6] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out0[c] = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    out1[c] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
   }
 }
 
@@ -929,7 +937,7 @@ static int bn_bwd_sums_to_params(const float* partial, int32_t partial_rows, int
   DN_REQUIRE(partial && dgamma && dbeta && partial_rows > 0, DN_ERR_BAD_ARG, "%s: bad argument", who);
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "%s: need C%%4==0", who);
   DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "%s: partial layout", who);
-  DN_LAUNCH(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
+  DN_LAUNCH(colsum2_finalize_kernel, dim3(C), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
                      dgamma);
   return DN_OK;
 }
@@ -967,7 +975,7 @@ int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply: need C%%4==0");
   DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: partial layout");
   hipStream_t s = as_stream(stream);
-  DN_LAUNCH(colsum2_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
+  DN_LAUNCH(colsum2_finalize_kernel, dim3(C), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
                      dgamma);
   DN_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, dz_dy, y, mean, invstd, gamma, dgamma, dbeta,
                      (long long)rows, C, (float)(1.0 / (double)rows));
