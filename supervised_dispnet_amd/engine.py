@@ -137,7 +137,9 @@ def tape_host_call(fn):
     if TAPE is None:
         return fn()
     _lib.load().dn_tape_mark(TAPE["handle"])
-    TAPE["host_calls"].append(fn)
+    # (with the stream it is issued on: a gradient bucket completed by a weight gradient is handed over from the SIDE stream's context,
+    #  and its fences make THAT stream wait for the others -- replayed on the main stream they would stall the input-gradient chain)
+    TAPE["host_calls"].append((fn, torch.cuda.current_stream()))
     _lib.call("dn_tape_pause", TAPE["handle"], 1)
     TAPE["paused"] = True
     try:

@@ -150,11 +150,12 @@ class TapedStep(object):
             rc = self._lib.dn_tape_replay(self.tape, -1)
         else:
             rc = 0
-            with torch.cuda.stream(s), engine.stream_scope():
-                for i in range(self.segments):
-                    rc = rc or self._lib.dn_tape_replay(self.tape, i)
-                    if i < len(self.host_calls):
-                        self.host_calls[i]()
+            for i in range(self.segments):
+                rc = rc or self._lib.dn_tape_replay(self.tape, i)
+                if i < len(self.host_calls):
+                    fn, st = self.host_calls[i]
+                    with torch.cuda.stream(st), engine.stream_scope():      # the stream the call was issued on when recorded
+                        fn()
         if rc != 0:
             from . import _lib
             raise _lib.DispnetHipError("dn_tape_replay failed (%d): %s" % (rc, _lib.last_error()))
