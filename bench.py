@@ -189,7 +189,7 @@ def build_workload(cfg, batch, dev, seed, models, LF, U, reciprocal, FusedAdam):
         params += list(pose_net._hot_parameters())
     opt = FusedAdam(params, lr=1e-4, betas=(0.9, 0.999), production_order=order)
     img, gt = synthetic_batch(batch, H, W, dev, seed, ds)
-    state = {"reducer": None}
+    state = {"reducer": None, "nets": [n_ for n_ in (net, pose_net) if n_ is not None]}
 
     def finish_step(loss):
         opt.zero_grad()
@@ -263,6 +263,9 @@ def main():
                          "and re-issued by one C call per step -- same kernels, streams and fences as eager, ~2 us of host time per launch "
                          "instead of ~20 (the step is launch-bound at 4 images per GPU); graph: hipGraph replay (= --graph 1); "
                          "auto: tape for the metric's config when the recording succeeds, else eager (config.launch says which ran)")
+    ap.add_argument("--tape-verify", default="1", choices=["0", "1"],
+                    help="--launch tape: before the timed region, one replay and one eager step from the same state must agree bit for bit "
+                         "(parameters, Adam moments, counters, BatchNorm buffers, loss): config.tape_verified")
     ap.add_argument("--adam-overlap", default="auto", choices=["auto", "0", "1"],
                     help="1: the Adam update of a gradient bucket runs as soon as the bucket (and its all-reduce) is complete, on its own "
                          "stream under the rest of the backward pass (FusedAdam.overlap_backward; bit-identical to the single update); "
@@ -337,7 +340,7 @@ def main():
     launch_mode = "graph" if args.graph == "1" else args.launch
     if launch_mode == "auto":
         launch_mode = "tape" if args.config == "vggbn128" else "eager"
-    taped = None
+    taped, tape_verified = None, None
     if launch_mode == "tape":
         from supervised_dispnet_amd.graph import TapedStep
         for _ in range(2):
@@ -345,6 +348,14 @@ def main():
         try:
             taped = TapedStep(eager_step, optimizer=opt, warmup=2).capture()
             step = taped
+            if args.tape_verify == "1":
+                # one replay against one eager step from the same parameters / moments / counters / BatchNorm buffers, bit for bit
+                st = [opt.arena.flat_p, opt.exp_avg, opt.exp_avg_sq, opt._dev["step"], opt._dev["derived"]]
+                st += [b for n_ in state.get("nets", ()) for b in n_.buffers() if b.is_cuda]
+                tape_verified = taped.verify(st)
+                if not tape_verified[0]:               # never time a replay that is not the eager step
+                    graph_note = "launch tape refused: replay differs from the eager step (max |diff| %.3g)" % tape_verified[1]
+                    step, taped = eager_step, None
         except Exception as e:                        # noqa: BLE001 -- the eager path is the same kernels; say why it was used
             graph_note = "%s: %s" % (type(e).__name__, str(e)[:200])
             taped = None
@@ -550,6 +561,8 @@ def main():
                        "launch": ("one hipGraph replay per step" if graphed else
                                   ("launch tape: %d launches + %d stream fences of one recorded step re-issued by dn_tape_replay, %d segment(s)"
                                    % (taped.launches, taped.fences, taped.segments)) if taped is not None else "eager launches"),
+                       "tape_verified": (None if tape_verified is None else
+                                         ("replay == eager step, bit for bit" if tape_verified[0] else "MISMATCH: max |diff| %.3g" % tape_verified[1])),
                        "graph_fallback": graph_note, "adam": "per bucket, under the backward pass" if overlap_adam else "one pass after the backward",
                        "comm": reducer.path if reducer is not None else "none (one rank)",
                        "dist_backend": dist.get_backend() if world > 1 else None},

@@ -162,6 +162,36 @@ class TapedStep(object):
         cur.wait_stream(s)
         return self.out
 
+    def verify(self, state):
+        """Replay once and run the SAME step eagerly once from the same state (`state`: the tensors the step reads and updates --
+        parameters, optimizer moments and counters, BatchNorm buffers), and compare the resulting state and outputs bit for bit.
+        Leaves the state one step further (the eager result).  Returns (identical, largest absolute difference).  What the unit tests
+        pin at small sizes, checked on the caller's own workload and size (bench.py reports it in config.tape_verified)."""
+        if self.tape is None:
+            self.capture()
+        torch.cuda.synchronize()
+        before = [t.clone() for t in state]
+        out = self()
+        outs_r = [o.clone() for o in (out if isinstance(out, (tuple, list)) else (out,))]
+        torch.cuda.synchronize()
+        after_r = [t.clone() for t in state]
+        with torch.no_grad():
+            for t, b in zip(state, before):
+                t.copy_(b)
+        s = self._stream
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            out_e = self.step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        outs_e = list(out_e if isinstance(out_e, (tuple, list)) else (out_e,))
+        worst, same = 0.0, True
+        for a, b in list(zip(after_r, state)) + list(zip(outs_r, outs_e)):
+            if not torch.equal(a, b):
+                same = False
+                worst = max(worst, float((a.double() - b.double()).abs().max()))
+        return same, worst
+
     def __del__(self):
         try:
             if self.tape is not None:
