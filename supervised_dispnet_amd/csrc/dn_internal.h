@@ -48,6 +48,8 @@ struct Knobs {
   int wino_splitk_maxblocks;                   // DN_WINO_SPLITK_MAXBLOCKS: 32-tile x 64-channel blocks at or below which the split is considered
   bool no_wino_splitk;      // DN_NO_WINO_SPLITK: no input-channel split of small Winograd grids
   int reduce_rows_per_thread, reduce_max_blocks;   // DN_REDUCE_ROWS_PER_THREAD (2), DN_REDUCE_MAX_BLOCKS (1024): grid of the two-stage column reductions
+  bool no_wino8_tail;       // DN_NO_WINO8_TAIL: no K split of the last partial round of the 8-wave Winograd kernel
+  int wino8_tail_max, wino8_tail_minch;   // DN_WINO8_TAIL_MAX (64 tiles), DN_WINO8_TAIL_MINCH (8 chunks per split)
   bool no_x3_splitk;        // DN_NO_X3_SPLITK: no K split of small grids in the three-piece direct kernel
   int x3_splitk_target, x3_splitk_minch, x3_splitk_maxblocks;   // DN_X3_SPLITK_TARGET (512 blocks) / _MINCH (8 chunks per block) / _MAXBLOCKS (208)
   bool no_bn_sums_fusion;   // DN_NO_BN_SUMS_FUSION: dn_conv_dgrad_fuses_bn_sums() answers 0 (the engine then runs the separate sums pass)
@@ -137,6 +139,7 @@ struct IgemmParams {
   const float *bnb_y, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
   float* bnb_partial;
   int ksplit, ks_chunks, ks_cnt_floats;   // input-channel split of small grids (dn_winograd.hip): splits, chunks of the K axis, float offset of the partial tiles
+  int ks_reg, ks_tail;                    // 8-wave kernel: tiles [0, ks_reg) run whole, the ks_tail tiles after them are split (dn_winograd8.hip)
   float* ks_ws;                  // caller workspace (dn_conv_desc.splitk_ws): zeroed int counters, then the partial tiles
   size_t ks_ws_bytes;
   int T, TH, TW;                 // 2x2 output tiles: total, per image column / row

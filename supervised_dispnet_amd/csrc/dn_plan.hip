@@ -108,6 +108,10 @@ static void read_knobs(Knobs* k) {
   if (k->reduce_rows_per_thread < 1) k->reduce_rows_per_thread = 1;
   k->reduce_max_blocks = num("DN_REDUCE_MAX_BLOCKS", 1024);
   if (k->reduce_max_blocks < 1) k->reduce_max_blocks = 1;
+  k->no_wino8_tail = on("DN_NO_WINO8_TAIL");
+  k->wino8_tail_max = num("DN_WINO8_TAIL_MAX", 64);
+  k->wino8_tail_minch = num("DN_WINO8_TAIL_MINCH", 8);
+  if (k->wino8_tail_minch < 1) k->wino8_tail_minch = 1;
   k->no_x3_splitk = on("DN_NO_X3_SPLITK");
   k->x3_splitk_target = num("DN_X3_SPLITK_TARGET", 512);
   k->x3_splitk_minch = num("DN_X3_SPLITK_MINCH", 8);

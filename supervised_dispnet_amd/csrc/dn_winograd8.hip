@@ -49,9 +49,27 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
   // transforms + stores early in c what it loaded late in c - 1 (two chunks ahead of its use).
   // XCD-aware tile order (see igemm_conv_u32_kernel): contiguous logical tile ranges per XCD, N tile fastest
   const int MT = (p.T + BT - 1) / BT, NT = p.Npad / WBN;
-  const int per = (MT * NT + 7) >> 3;
-  const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;
+  // Tail split (p.ksplit > 1, launch_wino8_variant): one block per CU means a grid of R + tail blocks (R a multiple of 256) runs R / 256
+  // full rounds and then a round with only `tail` CUs busy -- 832 blocks = 3.25 rounds cost 4.  The tiles of that last partial round
+  // are split `ksplit` ways along the input channels instead (block ids R + kz * tail + t: dispatched after the full rounds, all
+  // splits of a tile on XCD t % 8); the partial accumulators meet in the caller's workspace, the last arrival sums them in index order
+  // and runs the epilogue (the same scheme as the small-grid split of the 4-wave kernel).
+  int q, kz = 0, g0 = 0, g1 = 0x7fffffff;
+  if (p.ksplit > 1 && (int)blockIdx.x >= p.ks_reg) {
+    const int r = (int)blockIdx.x - p.ks_reg;
+    kz = r / p.ks_tail;
+    if (kz >= p.ksplit) return;
+    q = p.ks_reg + r % p.ks_tail;
+    const int cps = (p.ks_chunks + p.ksplit - 1) / p.ksplit;
+    g0 = kz * cps;
+    g1 = g0 + cps < p.ks_chunks ? g0 + cps : p.ks_chunks;
+  } else {
+    const int nreg = p.ksplit > 1 ? p.ks_reg : MT * NT;
+    const int per = (nreg + 7) >> 3;
+    q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || q >= nreg) return;
+  }
+  const bool split_tile = g1 != 0x7fffffff;
   const int mb = q / NT, nb = q % NT;
   long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, te1 = 0, te2 = 0;
   if (DBG & 4) t0 = clock64();
@@ -84,6 +102,7 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
   const int NS = p.Npad / 32;
   const char* wcur16 = reinterpret_cast<const char*>(p.w) + ((size_t)(4 * wi + 2 * jh) * NS + 2 * nb) * 3072 + lane * 16;
   const size_t wchunk16B = (size_t)16 * NS * 3072, wj16B = (size_t)NS * 3072;
+  wcur16 += (size_t)g0 * wchunk16B;                     // (tail split: the stream starts at this block's first chunk)
   // stream index g (relative to the current chunk): chunk g / 12, k = g % 12 = 6 posl + 3 nn + (2 - piece); register g % 6
   constexpr int WRING = 6;
   bf16x8 bq[WRING];
@@ -99,12 +118,16 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
   // fragment read: lane (tile, g) takes k 8g .. 8g+7 = 8-k group g, both 4-k planes
   const int frA3 = (4 * wi + 2 * jh) * POSB + (lane >> 5) * SUBB + (lane & 31) * 16;
 
-  int buf = 0;
+  int buf = 0, gbase = 0;
+  bool first_op = true;
   for (int s = 0; s < p.n_in; ++s) {
     const KOperand& S = p.in[s];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
     const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
-    const int nch = (S.C + WKC - 1) / WKC;
+    const int nch_all = (S.C + WKC - 1) / WKC;
+    const int c_lo = g0 > gbase ? g0 - gbase : 0, nch = (g1 - gbase) < nch_all ? (g1 - gbase) : nch_all;    // this block's chunks [c_lo, nch) of the operand
+    gbase += nch_all;
+    if (c_lo >= nch) continue;
     const bool scalar1 = S.C == 1;         // 1-channel piece: dword gathers (with the nearest-x2 upsample), live in channel 0 only
     const int off0 = (pn * (int)S.sn + py * (int)S.sh + px * (int)S.sw + k0) * 4;
     const bool op_aff = S.scale != nullptr;
@@ -112,7 +135,7 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     const char* shp = reinterpret_cast<const char*>(op_aff ? S.shift : S.p) + (op_aff ? k0 * 4 : 0);
     fV v[16], sc4, sh4;
     float relu_floor = 0.f;
-    int cnB = 0;                       // byte offset (channels) of the chunk whose loads are issued next
+    int cnB = c_lo * (WKC * 4);        // byte offset (channels) of the chunk whose loads are issued next
 
     auto load_v_t = [&](int i, auto sc_tag, unsigned mask) __attribute__((always_inline)) {
       constexpr bool SC1 = decltype(sc_tag)::value;
@@ -181,7 +204,8 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
 #pragma unroll
       for (int i = 0; i < 16; ++i) load_v(i);
       load_aff();
-      if (s == 0) {
+      if (first_op) {
+        first_op = false;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -232,7 +256,7 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     };
     // (a 1-channel piece is a single chunk: what the loop "re-fetches" for it is never used, so its loads are masked off)
     const unsigned lmask = scalar1 ? 0u : pmask;
-    for (int c = 0; c < nch; ++c) {
+    for (int c = c_lo; c < nch; ++c) {
       const bool more = c + 1 < nch;
       cnB = (more ? c + 1 : c) * (WKC * 4);            // the last chunk re-fetches itself into the idle buffer: no branch
       const char* Ab = smemB + buf * BUFB + frA3;
@@ -295,6 +319,59 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     }
   }
 
+  if (split_tile) {
+    // partial accumulators -> lane-private float4 slots [tail tile][split][32][thread]; the last arrival sums the splits in index order.
+    // Visibility without an agent-scope fence as in wino_conv_kernel: the splits of a tile share an XCD (its L2): write-through stores
+    // waited for with vmcnt(0), an L2 atomic counter, reader loads that bypass the CU's L1 (glc).
+    __shared__ int ks_last;
+    const int t = q - p.ks_reg;
+    int* cnt = reinterpret_cast<int*>(p.ks_ws);
+    f32x4* slots = reinterpret_cast<f32x4*>(p.ks_ws + p.ks_cnt_floats);
+    f32x4* mine = slots + ((size_t)(t * p.ksplit + kz) * 32) * 512 + tid;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x16 v16 = acc[a][m][nn];
+            mine[(size_t)((((a * 2 + m) * 2 + nn) * 4) + e) * 512] = f32x4{v16[4 * e], v16[4 * e + 1], v16[4 * e + 2], v16[4 * e + 3]};
+          }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ks_last = (atomicAdd(cnt + t, 1) == p.ksplit - 1) ? 1 : 0;
+    __syncthreads();
+    if (!ks_last) return;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][m][nn][e] = 0.f;
+    const __amdgpu_buffer_rsrc_t rws =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(slots + (size_t)t * p.ksplit * 32 * 512), 0, 0x7fffffff, 0x00020000);
+    for (int z = 0; z < p.ksplit; ++z) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              typedef int i32x4 __attribute__((ext_vector_type(4)));
+              const i32x4 vi = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(((z * 32 + ((a * 2 + m) * 2 + nn) * 4 + e) * 512 + tid) * 16), 0, 1 /* glc */);
+              const f32x4 v = __builtin_bit_cast(f32x4, vi);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[a][m][nn][4 * e + u] += v[u];
+            }
+    }
+    if (tid == 0) cnt[t] = 0;                            // (self-resetting: the workspace is reusable by the next launch on this stream)
+  }
   if (DBG & 4) t2 = clock64();
   // ---- output transform along j: Z[b] = sum_j A^T[b][j] M[i][j], A^T = (1 1 1 0 / 0 1 -1 -1).  This wave holds j = 2 jh, 2 jh + 1 and
   //      completes Z[b = jh]; in place: acc[0] = its partial of Z[jh] (kept), acc[1] = its partial of Z[1 - jh] (sent to the partner):
@@ -558,8 +635,32 @@ static int launch_wino8_variant(const IgemmParams& p, hipStream_t stream) {
     return DN_ERR_LAUNCH;
   }
   const int tiles = ((p.T + BT8 - 1) / BT8) * (p.Npad / WBN);
-  dim3 grid((tiles + 7) / 8 * 8);
-  DN_LAUNCH(kernel, grid, dim3(512), kLds8, stream, p);
+  IgemmParams q = p;
+  q.ksplit = 1;
+  int blocks = (tiles + 7) / 8 * 8;
+  if (DBG == 0 && !knobs().no_wino8_tail && p.ks_ws != nullptr) {
+    // tail split (see the kernel): the last partial round of one-block-per-CU rounds
+    const int cus = 256, reg = tiles / cus * cus, tail = tiles - reg;
+    int chunks = 0;
+    for (int i = 0; i < p.n_in; ++i) chunks += (p.in[i].C + WKC - 1) / WKC;
+    int ks = tail > 0 ? cus / tail : 1;
+    if (ks > chunks / knobs().wino8_tail_minch) ks = chunks / knobs().wino8_tail_minch;
+    if (ks > 8) ks = 8;
+    const size_t need = 4096 + (size_t)tail * ks * 32 * 512 * 16;
+    // (measured at 32 images, tools/conv_microbench.py: 512 -> 512 @16x52 = 832 blocks = 3 rounds + 64: forward 0.428 -> 0.413 ms, input
+    //  gradient 0.395 -> 0.371; 256 -> 256 @32x104 = 6 rounds + 128: +3..5 % SLOWER -- the rounds are not in lock step, so the partial
+    //  round costs less than a round, and 128 tiles x 2 x 256 KB of partial accumulators cost more than it: few rounds, small tails only)
+    if (reg > 0 && reg <= 3 * cus && tail > 0 && tail % 8 == 0 && tail <= knobs().wino8_tail_max && ks >= 2 && p.ks_ws_bytes >= need) {
+      q.ksplit = ks;
+      q.ks_chunks = chunks;
+      q.ks_cnt_floats = 4096 / 4;
+      q.ks_reg = reg;
+      q.ks_tail = tail;
+      blocks = reg + tail * ks;
+    }
+  }
+  dim3 grid(blocks);
+  DN_LAUNCH(kernel, grid, dim3(512), kLds8, stream, q);
   set_last_kernel("dn::wino_conv8_kernel<%s, %d>", HA ? "true" : "false", DBG);
   return check_launch("wino_conv8_kernel");
 }

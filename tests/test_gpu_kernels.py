@@ -614,3 +614,57 @@ def test_direct_three_piece_k_split_for_small_grids(case):
         assert torch.equal(y2, res[True][0]) and torch.equal(y3, res[True][0])
     finally:
         engine.SPLITK = prev
+
+
+@pytest.mark.parametrize("case", ["256_256_ks2", "512_256_ks4_bn"])
+def test_winograd8_tail_split_of_the_last_partial_round(case):
+    """8-wave Winograd kernel (one block per CU): a grid of 256 k + tail blocks costs k + 1 rounds; the tiles of the partial round are
+    split along the input channels instead (dn_winograd8.hip, dn_conv_desc.splitk_ws).  320 blocks = 256 + 64: the 64 tail tiles are
+    split 2 / 4 ways.  Same results as the unsplit launch up to fp32 summation order in the tail tiles and bit-identical elsewhere;
+    against the framework's CPU convolution; deterministic; input gradient too."""
+    torch.manual_seed(23)
+    N, H, W = 4, 32, 160                             # 4 x 16 x 80 = 5120 tiles = 80 blocks of 64 tiles x 4 blocks of 64 channels
+    cin, cout, bn = (256, 256, False) if case == "256_256_ks2" else (512, 256, True)
+    mod = nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+    layer = engine.ConvLayer(mod)
+    a = engine.Act(torch.randn(N, H, W, cin, device=DEV), N, H, W, cin)
+    if bn:
+        a.scale = torch.rand(cin, device=DEV) + 0.5
+        a.shift = torch.rand(cin, device=DEV) - 0.5
+    pieces = [engine.Piece(a, False)]
+    dy = torch.randn(N, H, W, cout, device=DEV)
+    res = {}
+    prev = engine.SPLITK
+    try:
+        for split in (True, False):
+            engine.SPLITK = split
+            a.grad = None
+            y, partial, _ = engine.conv_forward(layer, pieces, bn_stats=True)
+            kf = _lib.load().dn_last_kernel().decode()
+            if cin == cout:
+                engine.conv_dgrad(layer, dy, N, H, W, pieces, (H, W))
+            torch.cuda.synchronize()
+            res[split] = (y.clone(), partial.clone(), a.grad.clone() if a.grad is not None else None, kf)
+    finally:
+        engine.SPLITK = prev
+    assert "wino_conv8_kernel" in res[True][3] and res[True][3] == res[False][3], res[True][3]
+    ys, yn = res[True][0], res[False][0]
+    differs = (ys != yn).reshape(N * H * W, cout).any(dim=1)
+    frac = float(differs.float().mean())
+    assert 0.05 < frac <= 0.21, frac                 # only the tail (64 of 320 blocks = 20 % of the output) sees other summation cuts
+    assert float((ys - yn).abs().max()) <= 2e-5 * float(yn.abs().max())
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-4 * float(res[False][1].abs().max())
+    if res[True][2] is not None:
+        assert float((res[True][2] - res[False][2]).abs().max()) <= 2e-5 * float(res[False][2].abs().max())
+    x_cpu = a.t.permute(0, 3, 1, 2).cpu()
+    if bn:
+        x_cpu = F.relu(x_cpu * a.scale.cpu().view(1, -1, 1, 1) + a.shift.cpu().view(1, -1, 1, 1))
+    close(case + ":y", nchw(ys), copy.deepcopy(mod).cpu()(x_cpu))
+    engine.SPLITK = True
+    try:
+        y2, _, _ = engine.conv_forward(layer, pieces, bn_stats=True)
+        y3, _, _ = engine.conv_forward(layer, pieces, bn_stats=True)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, ys) and torch.equal(y3, ys)
+    finally:
+        engine.SPLITK = prev
