@@ -2,7 +2,7 @@ out=gpurun_out/r03f
 mkdir -p $out
 B=${1:-4}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_b4 -- python $GRAFT_REPO_ROOT/bench.py --batch $B --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0 --alt-steps 0 > /tmp/b4.json 2>/tmp/b4.err
+rm -rf /tmp/prof_b4; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_b4 -- python $GRAFT_REPO_ROOT/bench.py --batch $B --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0 --alt-steps 0 > /tmp/b4.json 2>/tmp/b4.err
 cd $GRAFT_REPO_ROOT
 f=$(find /tmp/prof_b4 -name '*kernel_trace.csv' | head -1)
 python tools/trace_gaps.py $f 0.5 > $out/b${B}_trace_summary.txt
