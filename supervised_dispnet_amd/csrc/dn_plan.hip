@@ -112,6 +112,7 @@ static void read_knobs(Knobs* k) {
   k->wino8_tail_max = num("DN_WINO8_TAIL_MAX", 64);
   k->wino8_tail_minch = num("DN_WINO8_TAIL_MINCH", 8);
   if (k->wino8_tail_minch < 1) k->wino8_tail_minch = 1;
+  k->no_bn_hoist = on("DN_NO_BN_HOIST");
   k->no_x3_splitk = on("DN_NO_X3_SPLITK");
   k->x3_splitk_target = num("DN_X3_SPLITK_TARGET", 512);
   k->x3_splitk_minch = num("DN_X3_SPLITK_MINCH", 8);

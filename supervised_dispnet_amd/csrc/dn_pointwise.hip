@@ -398,6 +398,17 @@ __global__ void __launch_bounds__(256) colsum2_finalize_kernel(const float* __re
   }
 }
 
+// dy = gamma * invstd * (dz - sum(dz) / n - xhat * sum(dz * xhat) / n), written with explicit fused steps: the four kernels below must
+// produce the SAME bits for the same element whatever the compiler hoists out of their loops (two of them keep the per-channel
+// factors in registers across iterations), tests/test_gpu_graph.py::test_bn_backward_without_materialised_dz_is_bitwise_the_two_pass_form
+__device__ __forceinline__ float bn_bwd_value(float z, float yv, float mu, float is, float ga, float dg, float db, float inv_count) {
+#pragma clang fp contract(off)
+  const float xhat = (yv - mu) * is;
+  float t = __builtin_fmaf(-db, inv_count, z);
+  t = __builtin_fmaf(-(xhat * dg), inv_count, t);
+  return (ga * is) * t;
+}
+
 __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(float* __restrict__ dz_dy, const float* __restrict__ y,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ dgamma,
@@ -414,8 +425,7 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(float* __restric
                 db = *reinterpret_cast<const f32x4*>(dbeta + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float xhat = (yv[e] - mu[e]) * is[e];
-      dz[e] = ga[e] * is[e] * (dz[e] - db[e] * inv_count - xhat * dg[e] * inv_count);
+      dz[e] = bn_bwd_value(dz[e], yv[e], mu[e], is[e], ga[e], dg[e], db[e], inv_count);
     }
     *reinterpret_cast<f32x4*>(dz_dy + o) = dz;
   }
@@ -444,10 +454,50 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_relu_kernel(float* __re
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float z = (yv[e] * sc[e] + sh[e] > 0.f) ? dz[e] : 0.f;
-      const float xhat = (yv[e] - mu[e]) * is[e];
-      dz[e] = ga[e] * is[e] * (z - db[e] * inv_count - xhat * dg[e] * inv_count);
+      dz[e] = bn_bwd_value(z, yv[e], mu[e], is[e], ga[e], dg[e], db[e], inv_count);
     }
     *reinterpret_cast<f32x4*>(da_dy + o) = dz;
+  }
+}
+
+// The same pass when C / 4 divides the block size (every layer of the nets here): a thread's channel group is the same in every
+// iteration of its grid-stride loop, so the seven per-channel vectors are loaded ONCE (the plain kernel re-reads them and takes a 64-bit
+// remainder per element group), and four element groups are in flight per thread.  Same arithmetic, same bits.
+__global__ void __launch_bounds__(kThreads) bn_bwd_apply_relu_hoisted_kernel(float* __restrict__ da_dy, const float* __restrict__ y,
+                                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                             const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                                             const float* __restrict__ dbeta, long long rows, int C, float inv_count) {
+  const int G = C / 4;
+  const long long total = rows * G;
+  const int c = (int)(threadIdx.x % (unsigned)G) * 4;      // (blockIdx.x * 256 and the grid stride are multiples of G)
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), dg = *reinterpret_cast<const f32x4*>(dgamma + c),
+              db = *reinterpret_cast<const f32x4*>(dbeta + c);
+  const long long step = (long long)gridDim.x * kThreads;
+  for (long long i0 = blockIdx.x * (long long)kThreads + threadIdx.x; i0 < total; i0 += 4 * step) {
+    f32x4 dz[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * step;
+      if (i < total) {
+        dz[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da_dy + i * 4));
+        yv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + i * 4));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * step;
+      if (i < total) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = (yv[u][e] * sc[e] + sh[e] > 0.f) ? dz[u][e] : 0.f;
+          dz[u][e] = bn_bwd_value(z, yv[u][e], mu[e], is[e], ga[e], dg[e], db[e], inv_count);
+        }
+        *reinterpret_cast<f32x4*>(da_dy + i * 4) = dz[u];
+      }
+    }
   }
 }
 
@@ -480,8 +530,7 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_pool_kernel(const float
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float z = ((cd[e] & 4) && (cd[e] & 3) == q) ? dp[e] : 0.f;
-        const float xhat = (yv[e] - mu[e]) * is[e];
-        out[e] = ga[e] * is[e] * (z - db[e] * inv_count - xhat * dg[e] * inv_count);
+        out[e] = bn_bwd_value(z, yv[e], mu[e], is[e], ga[e], dg[e], db[e], inv_count);
       }
       *reinterpret_cast<f32x4*>(dy + o) = out;
     }
@@ -949,7 +998,11 @@ int dn_bn_bwd_apply_relu(float* da_dy, const float* y, const float* scale, const
   hipStream_t s = as_stream(stream);
   int rc = bn_bwd_sums_to_params(partial, partial_rows, partial_stride, partial_offset, C, dgamma, dbeta, s, "dn_bn_bwd_apply_relu");
   if (rc != DN_OK) return rc;
-  DN_LAUNCH(bn_bwd_apply_relu_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean, invstd, gamma,
+  if (C % 4 == 0 && kThreads % (C / 4) == 0 && !knobs().no_bn_hoist)
+    DN_LAUNCH(bn_bwd_apply_relu_hoisted_kernel, dim3(ew_blocks((rows * (C / 4) + 3) / 4)), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean,
+              invstd, gamma, dgamma, dbeta, (long long)rows, C, (float)(1.0 / (double)rows));
+  else
+    DN_LAUNCH(bn_bwd_apply_relu_kernel, dim3(ew_blocks(rows * (C / 4))), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean, invstd, gamma,
                      dgamma, dbeta, (long long)rows, C, (float)(1.0 / (double)rows));
   return check_launch("bn_bwd_apply_relu");
 }

@@ -1,1 +1,1 @@
-for e in DN_X=1 DN_NO_WINO8_TAIL=1 DN_X=2 DN_NO_WINO8_TAIL=1; do echo "== $e"; env $e python tools/conv_microbench.py --layers c512_512_16x52,c256_256_32x104 --what fwd,dgrad --reps 30 2>&1 | grep -v amdgpu | tail -6; done
+python -m pytest tests/test_gpu_graph.py tests/test_gpu_kernels.py tests/test_gpu_models.py -x -q -m gpu 2>&1 | tail -3
