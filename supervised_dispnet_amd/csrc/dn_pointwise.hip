@@ -273,13 +273,18 @@ struct PoolBwdOp {
       for (int e = 0; e < V; ++e) out[q].v[e] = 0.f;
     unsigned codes = 0;                                   // the V routing bytes of this thread in one load when they form a dword
     if constexpr (V == 4) codes = *reinterpret_cast<const unsigned*>(idx + row * C + c0);
+    // the four window pixels as whole vectors, all in flight at once (the arg-max positions of a thread's channels touch nearly every
+    // 32-byte sector of the window anyway; four coalesced 16-byte loads replace four dependent, divergent 4-byte gathers)
+    Vec<V> yq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) yq[q] = ldv<V>(y + base + ((long long)(q >> 1) * W + (q & 1)) * C);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const int code = V == 4 ? (int)((codes >> (8 * e)) & 0xffu) : (int)idx[row * C + c0 + e];
       if (code & 4) {
         const int q = code & 3;
         const float g = dp.v[e];
-        const float yv = y[base + ((long long)(q >> 1) * W + (q & 1)) * C + e];
+        const float yv = q == 0 ? yq[0].v[e] : (q == 1 ? yq[1].v[e] : (q == 2 ? yq[2].v[e] : yq[3].v[e]));
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
           if (qq == q) out[qq].v[e] = g;
