@@ -248,6 +248,30 @@ def test_bad_descriptors_are_rejected_not_crashing(lib):
     assert lib.dn_conv2d_fwd(None, None) != 0       # null descriptor -> status, no crash
 
 
+def test_launch_tape_host_logic(lib):
+    """dn_tape_*: the bookkeeping that needs no device -- one tape at a time, marks cut segments, pause / resume, a tape being recorded
+    cannot be replayed, errors are statuses with a message (no launch happens here: an empty tape replays as a no-op)."""
+    t = lib.dn_tape_begin()
+    assert t
+    assert not lib.dn_tape_begin() and b"another tape" in lib.dn_last_error()       # one at a time
+    assert lib.dn_tape_segments(t) == 1 and lib.dn_tape_launches(t) == 0 and lib.dn_tape_fences(t) == 0
+    assert lib.dn_tape_mark(t) == 1 and lib.dn_tape_mark(t) == 2
+    assert lib.dn_tape_segments(t) == 3
+    assert lib.dn_tape_replay(t, -1) != 0 and b"still being recorded" in lib.dn_last_error()
+    assert lib.dn_tape_pause(t, 1) == 0
+    assert lib.dn_tape_pause(t, 1) != 0                                             # already paused
+    assert lib.dn_tape_fence(t, None, None) != 0                                    # not recording while paused
+    assert lib.dn_tape_pause(t, 0) == 0
+    assert lib.dn_tape_end(t) == 0
+    assert lib.dn_tape_end(t) != 0                                                  # not being recorded any more
+    assert lib.dn_tape_replay(t, 3) != 0 and b"segment" in lib.dn_last_error()
+    t2 = lib.dn_tape_begin()                                                        # the slot is free again
+    assert t2 and lib.dn_tape_end(t2) == 0
+    lib.dn_tape_free(t2)
+    lib.dn_tape_free(t)
+    assert lib.dn_tape_segments(None) == -1 and lib.dn_tape_mark(None) == -1
+
+
 def test_product_never_touches_the_oracle_and_has_no_cpu_path():
     pkg = ROOT / "supervised_dispnet_amd"
     for f in list(pkg.rglob("*.py")) + [ROOT / "train.py", ROOT / "test_disp.py"]:

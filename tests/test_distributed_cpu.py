@@ -324,3 +324,33 @@ def test_comm_choice_is_collective_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_last_gradient_bucket_is_cut_short():
+    """GradReducer: contiguous buckets covering the arena exactly once, in arena (= production) order, each at least bucket_bytes except
+    the last one, which is only the final ~tail_bytes of the arena -- the one all-reduce nothing can overlap starts when the first
+    layer's gradient lands."""
+    import torch
+    from supervised_dispnet_amd.distributed import GradReducer
+
+    class Arena(object):
+        pass
+
+    sizes = [1, 1152, 16, 4608, 32, 27648, 64, 110592, 128, 442368, 1769472, 2097152, 512, 2359296, 512, 2359296, 2359296, 1179648,
+             589824, 589824, 294912, 147456, 73728, 36864, 1728]
+    a = Arena()
+    a.params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    a.offsets, t = [], 0
+    for n in sizes:
+        a.offsets.append(t)
+        t += (n + 3) // 4 * 4
+    a.numel, a.flat_g = t, torch.zeros(t)
+    for tail in (1 << 20, 0):
+        r = GradReducer(a, bucket_bytes=8 << 20, tail_bytes=tail)
+        b = r.buckets
+        assert b[0]["lo"] == 0 and b[-1]["hi"] == t and all(b[i]["hi"] == b[i + 1]["lo"] for i in range(len(b) - 1))
+        assert sum(len(x["params"]) for x in b) == len(sizes)
+        assert all((x["hi"] - x["lo"]) * 4 >= (8 << 20) for x in b[:-2])          # (the bucket in front of the tail is whatever is left)
+        if tail:
+            assert (1 << 20) <= (b[-1]["hi"] - b[-1]["lo"]) * 4 <= (4 << 20)          # ~1 MB: until the next parameter boundary
+    assert len(GradReducer(a, bucket_bytes=8 << 20, tail_bytes=1 << 20).buckets) >= len(GradReducer(a, bucket_bytes=8 << 20, tail_bytes=0).buckets)
