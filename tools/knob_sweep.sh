@@ -1,4 +1,6 @@
-# usage: bash tools/_sweep.sh "<batches>" "ENV1=a ENV2=b" "ENV1=c" ...   (one bench line per batch x setting)
+#!/bin/bash
+# One bench line per (batch, environment setting): A/B of DN_* knobs on ONE box (box-to-box spread of a build is +-2 %).
+# usage: bash tools/knob_sweep.sh "<batches>" "ENV1=a ENV2=b" "ENV1=c" ...   (one bench line per batch x setting)
 bs=$1; shift
 for e in "$@"; do for b in $bs; do
   env $e python bench.py --batch $b --steps 40 --warmup 8 --no-cpu-baseline --profile-steps 0 --alt-steps 0 2>/dev/null | python -c "

@@ -1,4 +1,6 @@
-out=gpurun_out/r03f
+#!/bin/bash
+# rocprofv3 kernel trace of a bench run at batch $1 -> per-kernel totals + one step as a timeline with queue ids (tools/step_timeline.py).
+out=${2:-gpurun_out/timeline}
 mkdir -p $out
 B=${1:-4}
 cd /tmp && export TMPDIR=/tmp
