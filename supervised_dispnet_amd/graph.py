@@ -125,10 +125,15 @@ class TapedStep(object):
             with torch.cuda.stream(s):
                 self.out = self.step()
             torch.cuda.current_stream().wait_stream(s)
-        finally:
+        except BaseException:
             torch._C._cuda_endAllocateToPool(dev, self._pool.id)
             engine.TAPE = None
-            _lib.call("dn_tape_end", handle)
+            lib.dn_tape_free(handle)          # (also ends the recording)
+            del self.host_calls[:]
+            raise
+        torch._C._cuda_endAllocateToPool(dev, self._pool.id)
+        engine.TAPE = None
+        _lib.call("dn_tape_end", handle)
         torch.cuda.synchronize()
         self._keep = rec["keep"]          # (cheap to hold; dropping them would only return the blocks to the private pool)
         self.tape = handle

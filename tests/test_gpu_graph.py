@@ -224,3 +224,35 @@ def test_adam_per_bucket_under_the_backward_pass_is_bitwise_the_single_update(ta
     assert int(opt_a._dev["step"].item()) == int(opt_b._dev["step"].item()) == (6 if taped else 4)
     assert torch.equal(opt_a.arena.flat_p, opt_b.arena.flat_p)
     assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)
+
+
+def test_launch_tape_refuses_framework_side_device_work_and_recovers():
+    """A step that does device work outside libdispnet_hip while a tape is recorded (here: a gradient seeded into an activation that
+    already holds one -- an ATen add) fails the recording loudly instead of producing a tape that would silently skip it; the recording
+    slot is free again afterwards and eager steps still run."""
+    from supervised_dispnet_amd import engine
+    from supervised_dispnet_amd.graph import TapedStep, backward
+    img, gt = bench.synthetic_batch(2, 64, 96, DEV, 0)
+    net, opt = _make()
+
+    def good():
+        depth = [reciprocal(d) for d in net(img)]
+        loss = LF.l1_loss(gt, depth, "kitti")
+        opt.zero_grad()
+        backward(loss)
+        opt.step()
+        return loss
+
+    def bad():
+        loss = good()
+        engine._not_on_tape("a framework-side kernel")
+        return loss
+
+    with pytest.raises(RuntimeError, match="launch tape"):
+        TapedStep(bad, optimizer=opt, warmup=0).capture()
+    assert engine.TAPE is None
+    l0 = good()                                         # eager still works
+    ts = TapedStep(good, optimizer=opt, warmup=0).capture()      # and the slot is free
+    l1 = ts()
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0) and torch.isfinite(l1) and float(l1) < float(l0)
