@@ -34,7 +34,7 @@ Besides the contract fields the line carries
   step_executed_frac  all conv-family launches' fp32-equivalent executed FLOPs (each fp32 multiply-accumulate once) over the step time, / 157.3.
   f32_mfma_path the same step timed with --compute f32 semantics (fp32 matrix instruction everywhere) after the headline region.
   cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU restatement pinned to the reference's golden vectors; kind "port")
-                running the same training step on this box's host cores per SURVEY 8d: batch 8, 2 warm-up + 5 timed steps.
+                running the same training step on this box's host cores per SURVEY 8d: batch 8, 2 warm-up + 10 timed steps (~11 s of CPU work).
 """
 import argparse
 import json
@@ -103,7 +103,7 @@ def host_description():
 
 
 def cpu_baseline(h, w, batch, steps, warmup, threads=None):
-    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (b8, 2 warm-up + 5 timed)."""
+    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (b8, 2 warm-up + 10 timed by default)."""
     from oracle import losses as OL, nets as ON
     model, physical, logical = host_description()
     # oneDNN/OpenMP with every logical CPU of this 2-socket host oversubscribes badly at this problem size (measured in round 1:
@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print the per-layer launch table to stderr")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--compute", default="f32x3", choices=["f32", "f32x3", "bf16"],
                     help="arithmetic of the Winograd forward / input-gradient kernels (tensors and every other kernel are fp32 in all modes). "
