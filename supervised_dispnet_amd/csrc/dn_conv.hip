@@ -156,7 +156,10 @@ __device__ __forceinline__ void conv_epilogue(const IgemmParams& p, f32x16 (&acc
   bool tile_store = false;
   if constexpr (STORE) {
     const KResult& R0 = p.out[0];
-    tile_store = p.n_out == 1 && R0.linear && !R0.accumulate && (R0.sw & 3) == 0 && (p.Ntot & 3) == 0 &&
+    // (also when the result ACCUMULATES -- the second writer of a gradient, e.g. the input gradient of a ResNet bottleneck's first 1x1
+    //  convolution landing on the residual path's: one float4 read-add-write per thread instead of 16-32 scalar ones.  Config 4's
+    //  1x1 input gradients ran at 19-35 TFLOP/s through the scalar path, 2-3x slower than their forward.)
+    tile_store = p.n_out == 1 && R0.linear && (R0.sw & 3) == 0 && (p.Ntot & 3) == 0 &&
                  (reinterpret_cast<uintptr_t>(R0.p) & 15) == 0 && p.tile_store != 0;
     if (tile_store) {
       constexpr int TLD = BN + 4;
@@ -179,8 +182,12 @@ __device__ __forceinline__ void conv_epilogue(const IgemmParams& p, f32x16 (&acc
       for (int it = tid; it < BM * C4; it += 256) {
         const int row = it / C4, c4 = it - row * C4;
         const int pix = rowpix[row];
-        if (pix >= 0 && n0 + 4 * c4 < p.Ntot)
-          *reinterpret_cast<f32x4*>(R0.p + (long long)pix * R0.sw + n0 + 4 * c4) = *reinterpret_cast<const f32x4*>(Ts + row * TLD + 4 * c4);
+        if (pix >= 0 && n0 + 4 * c4 < p.Ntot) {
+          f32x4* dst = reinterpret_cast<f32x4*>(R0.p + (long long)pix * R0.sw + n0 + 4 * c4);
+          f32x4 v = *reinterpret_cast<const f32x4*>(Ts + row * TLD + 4 * c4);
+          if (R0.accumulate) v += *dst;
+          *dst = v;
+        }
       }
     }
   }
