@@ -142,6 +142,10 @@ __device__ __forceinline__ AGroup gather4(const KOperand& S, int kl, int ntaps, 
   return r;
 }
 
+// p.tile_store: 0 = never, 1 = dense un-phased results only (the round-2 rule, DN_TILE_STORE_LINEAR_ONLY), 2 = every pixel-dense result
+// (run_conv requires pixel-dense results; the tile path addresses pixels through rowpix[], which is phase-aware)
+__device__ __forceinline__ bool knobs_dev_linear_only(const IgemmParams& p) { return p.tile_store == 1; }
+
 // ---- shared epilogue: bias, activation, channel-split store; optional batch-statistic partials
 // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 template <int BM, int BN, int WM, int WN, bool STORE = true>
@@ -159,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmParams& p, f32x16 (&acc
     // (also when the result ACCUMULATES -- the second writer of a gradient, e.g. the input gradient of a ResNet bottleneck's first 1x1
     //  convolution landing on the residual path's: one float4 read-add-write per thread instead of 16-32 scalar ones.  Config 4's
     //  1x1 input gradients ran at 19-35 TFLOP/s through the scalar path, 2-3x slower than their forward.)
-    tile_store = p.n_out == 1 && R0.linear && (R0.sw & 3) == 0 && (p.Ntot & 3) == 0 &&
+    tile_store = p.n_out == 1 && (R0.linear || !knobs_dev_linear_only(p)) && (R0.sw & 3) == 0 && (p.Ntot & 3) == 0 &&
                  (reinterpret_cast<uintptr_t>(R0.p) & 15) == 0 && p.tile_store != 0;
     if (tile_store) {
       constexpr int TLD = BN + 4;

@@ -50,6 +50,7 @@ struct Knobs {
   int reduce_rows_per_thread, reduce_max_blocks;   // DN_REDUCE_ROWS_PER_THREAD (2), DN_REDUCE_MAX_BLOCKS (1024): grid of the two-stage column reductions
   bool no_wino8_tail;       // DN_NO_WINO8_TAIL: no K split of the last partial round of the 8-wave Winograd kernel
   int wino8_tail_max, wino8_tail_minch;   // DN_WINO8_TAIL_MAX (64 tiles), DN_WINO8_TAIL_MINCH (8 chunks per split)
+  bool tile_store_linear_only;   // DN_TILE_STORE_LINEAR_ONLY: whole-pixel tile stores for dense un-phased results only (A/B)
   bool no_bn_hoist;         // DN_NO_BN_HOIST: the plain BatchNorm-backward apply kernel (A/B)
   bool no_x3_splitk;        // DN_NO_X3_SPLITK: no K split of small grids in the three-piece direct kernel
   int x3_splitk_target, x3_splitk_minch, x3_splitk_maxblocks;   // DN_X3_SPLITK_TARGET (512 blocks) / _MINCH (8 chunks per block) / _MAXBLOCKS (208)

@@ -90,6 +90,7 @@ static void read_knobs(Knobs* k) {
   k->no_thin = on("DN_NO_THIN");
   k->no_thin_conv = on("DN_NO_THIN_CONV");
   k->no_tile_store = on("DN_NO_TILE_STORE");
+  k->tile_store_linear_only = on("DN_TILE_STORE_LINEAR_ONLY");
   k->no_splitk = on("DN_NO_SPLITK");
   k->no_head2 = on("DN_NO_HEAD2");
   k->extra_lds = num("DN_DEBUG_EXTRA_LDS", 0);
@@ -354,7 +355,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     if (!o.small || (!o.vec && o.scale != nullptr) || o.C >= 32768) p->wg_uniform = 0;
   }
   (void)n_uniform;
-  p->tile_store = knobs().no_tile_store ? 0 : 1;
+  p->tile_store = knobs().no_tile_store ? 0 : (knobs().tile_store_linear_only ? 1 : 2);
   p->compute = (d->compute == DN_COMPUTE_BF16 || d->compute == DN_COMPUTE_F32X3) ? d->compute : DN_COMPUTE_F32;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
