@@ -2182,6 +2182,82 @@ static void choose_splits(IgemmParams* p) {
 
 using namespace dn;
 
+// The tiled weight-gradient kernels + their fixed-order split sum (every layer the Winograd / thin / head kernels do not take).
+static int generic_wgrad(const dn_conv_desc* fwd, IgemmParams& p, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                         hipStream_t s) {
+  int rc = DN_OK;
+  choose_splits(&p);
+  const size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
+  DN_REQUIRE(workspace_bytes >= need, DN_ERR_WORKSPACE, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);
+  p.ws = reinterpret_cast<float*>(workspace);
+  if (fwd->kind == DN_CONV_FWD) {
+    p.g = dy;  // [N*OH*OW][Cout]
+    for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
+  } else {
+    // conv-transpose: G = forward input x [N*IH*IW][Cin] (dense NHWC), gathered operand = dy [N][OH][OW][Cout]
+    const dn_operand& x = fwd->in[0];
+    DN_REQUIRE(x.data != nullptr && x.stride_c == 1 && x.stride_w == x.C && x.stride_h == (int64_t)fwd->IW * x.C &&
+                   x.stride_n == (int64_t)fwd->IH * fwd->IW * x.C,
+               DN_ERR_UNSUPPORTED, "conv-transpose wgrad needs a dense NHWC input");
+    p.g = x.data;
+    KOperand& o = p.in[0];
+    const int co = o.C;
+    o.p = dy;
+    o.scale = o.shift = nullptr;
+    o.sc = 1;
+    o.sw = co;
+    o.sh = (long long)fwd->OW * co;
+    o.sn = (long long)fwd->OH * fwd->OW * co;
+    o.up = 0;
+    o.vec = (co % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) ? 1 : 0;
+    o.mC = fastdiv_magic((unsigned)co);
+    o.small = ((long long)fwd->N * o.sn < (1ll << 31)) ? 1 : 0;
+    p.allvec = (o.vec && o.small) ? 1 : 0;
+    p.any_affine = 0;
+    p.wg_uniform = (p.allvec && co % 32 == 0 && p.ph[0].ntaps <= 32 && (long long)fwd->N * o.sn * 4 + 64 < (1ll << 31)) ? 1 : 0;
+  }
+  // the G operand must be float4-addressable with int32 offsets too
+  if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0 && (long long)p.M * p.Ntot < (1ll << 31))) p.allvec = 0;
+  // the G operand must be float4-addressable with 32-bit BYTE offsets for the fast kernel
+  if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0) || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.wg_uniform = 0;
+  switch (p.BN) {
+    case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;
+    case 64: rc = launch_wgrad<64, 64, 32>(p, s); break;
+    default: rc = launch_wgrad<32, 32, 32>(p, s); break;
+  }
+  if (rc != DN_OK) return rc;
+  const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 8192) blocks = 8192;
+  DN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, dw);
+  return check_launch("wgrad_reduce_kernel");
+}
+
+// A concatenated input whose LAST piece is a 1-channel map (the upsampled disparity of the iconv layers: 64 + 128 + 1, 64 + 256 + 1):
+// the 1-channel piece is what keeps the layer off the Winograd weight-gradient kernel (operands in multiples of 64).  Split the
+// gradient instead: Winograd for the pieces in front (rows of dw written with the full layer's channel stride), the tiled kernel for
+// the one trailing channel (9 columns of dw).  iconv2 at 32 images: 0.272 -> 0.15 ms; config 4's 321 -> 64 @120x160: 1.25 -> 0.5 ms.
+static bool wgrad_split_plans(const dn_conv_desc* fwd, dn_conv_desc* d1, dn_conv_desc* d2, IgemmParams* p1, IgemmParams* p2, size_t* w1,
+                              size_t* w2) {
+  if (knobs().no_wgrad_split || fwd->kind != DN_CONV_FWD || fwd->n_in < 2 || fwd->in[fwd->n_in - 1].C != 1) return false;
+  *d1 = *fwd;
+  d1->n_in = fwd->n_in - 1;
+  *d2 = *fwd;
+  d2->n_in = 1;
+  d2->in[0] = fwd->in[fwd->n_in - 1];
+  if (build_plan(d1, true, p1) != DN_OK || build_plan(d2, true, p2) != DN_OK) return false;
+  if (!wino_wgrad_eligible(d1, *p1)) return false;
+  int cin_total = 0;
+  for (int i = 0; i < fwd->n_in; ++i) cin_total += fwd->in[i].C;
+  p1->dw_cin_total = cin_total;
+  p2->in[0].ch_off = cin_total - 1;              // (packed_to_framework: the column block of this channel in the full weight tensor)
+  p2->D1 = cin_total;
+  choose_splits(p2);
+  *w1 = (wino_wgrad_workspace_bytes(*p1) + 255) / 256 * 256;
+  *w2 = (size_t)p2->splits * p2->Npad * p2->ph[0].nchunks * kChunk * sizeof(float);
+  return true;
+}
+
 extern "C" {
 
 int64_t dn_pack_entry_bytes(void) { return (int64_t)sizeof(PackEntry); }
@@ -2256,6 +2332,12 @@ size_t dn_conv_wgrad_workspace_bytes(const dn_conv_desc* fwd) {
   if (head_wgrad_eligible(fwd, p) && head_wgrad_workspace_bytes(p) > need) need = head_wgrad_workspace_bytes(p);
   if (wino_wgrad_eligible(fwd, p) && wino_wgrad_workspace_bytes(p) > need) need = wino_wgrad_workspace_bytes(p);
   if (thin_wgrad_eligible(fwd, p) && thin_wgrad_workspace_bytes(p) > need) need = thin_wgrad_workspace_bytes(p);
+  {
+    dn_conv_desc d1, d2;
+    IgemmParams p1, p2;
+    size_t w1 = 0, w2 = 0;
+    if (wgrad_split_plans(fwd, &d1, &d2, &p1, &p2, &w1, &w2) && w1 + w2 > need) need = w1 + w2;
+  }
   return need;
 }
 
@@ -2282,52 +2364,20 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     p.ws = reinterpret_cast<float*>(workspace);
     return launch_thin_wgrad(p, dw, as_stream(stream));
   }
-  choose_splits(&p);
-  const size_t need = (size_t)p.splits * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
-  DN_REQUIRE(workspace_bytes >= need, DN_ERR_WORKSPACE, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);
-  p.ws = reinterpret_cast<float*>(workspace);
-  if (fwd->kind == DN_CONV_FWD) {
-    p.g = dy;  // [N*OH*OW][Cout]
-    for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
-  } else {
-    // conv-transpose: G = forward input x [N*IH*IW][Cin] (dense NHWC), gathered operand = dy [N][OH][OW][Cout]
-    const dn_operand& x = fwd->in[0];
-    DN_REQUIRE(x.data != nullptr && x.stride_c == 1 && x.stride_w == x.C && x.stride_h == (int64_t)fwd->IW * x.C &&
-                   x.stride_n == (int64_t)fwd->IH * fwd->IW * x.C,
-               DN_ERR_UNSUPPORTED, "conv-transpose wgrad needs a dense NHWC input");
-    p.g = x.data;
-    KOperand& o = p.in[0];
-    const int co = o.C;
-    o.p = dy;
-    o.scale = o.shift = nullptr;
-    o.sc = 1;
-    o.sw = co;
-    o.sh = (long long)fwd->OW * co;
-    o.sn = (long long)fwd->OH * fwd->OW * co;
-    o.up = 0;
-    o.vec = (co % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) ? 1 : 0;
-    o.mC = fastdiv_magic((unsigned)co);
-    o.small = ((long long)fwd->N * o.sn < (1ll << 31)) ? 1 : 0;
-    p.allvec = (o.vec && o.small) ? 1 : 0;
-    p.any_affine = 0;
-    p.wg_uniform = (p.allvec && co % 32 == 0 && p.ph[0].ntaps <= 32 && (long long)fwd->N * o.sn * 4 + 64 < (1ll << 31)) ? 1 : 0;
+  {
+    dn_conv_desc d1, d2;
+    IgemmParams p1, p2;
+    size_t w1 = 0, w2 = 0;
+    if (wgrad_split_plans(fwd, &d1, &d2, &p1, &p2, &w1, &w2) && workspace_bytes >= w1 + w2) {
+      for (int i = 0; i < fwd->n_in; ++i) DN_REQUIRE(fwd->in[i].data != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
+      p1.g = dy;
+      p1.ws = reinterpret_cast<float*>(workspace);
+      rc = launch_wino_wgrad(p1, dw, as_stream(stream));
+      if (rc != DN_OK) return rc;
+      return generic_wgrad(&d2, p2, dy, dw, reinterpret_cast<char*>(workspace) + w1, w2, as_stream(stream));
+    }
   }
-  // the G operand must be float4-addressable with int32 offsets too
-  if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0 && (long long)p.M * p.Ntot < (1ll << 31))) p.allvec = 0;
-  // the G operand must be float4-addressable with 32-bit BYTE offsets for the fast kernel
-  if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0) || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.wg_uniform = 0;
-  hipStream_t s = as_stream(stream);
-  switch (p.BN) {
-    case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;
-    case 64: rc = launch_wgrad<64, 64, 32>(p, s); break;
-    default: rc = launch_wgrad<32, 32, 32>(p, s); break;
-  }
-  if (rc != DN_OK) return rc;
-  const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;
-  int blocks = (int)((total + 63) / 64);
-  if (blocks > 8192) blocks = 8192;
-  DN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, dw);
-  return check_launch("wgrad_reduce_kernel");
+  return generic_wgrad(fwd, p, dy, dw, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

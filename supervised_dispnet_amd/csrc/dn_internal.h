@@ -50,6 +50,7 @@ struct Knobs {
   int reduce_rows_per_thread, reduce_max_blocks;   // DN_REDUCE_ROWS_PER_THREAD (2), DN_REDUCE_MAX_BLOCKS (1024): grid of the two-stage column reductions
   bool no_wino8_tail;       // DN_NO_WINO8_TAIL: no K split of the last partial round of the 8-wave Winograd kernel
   int wino8_tail_max, wino8_tail_minch;   // DN_WINO8_TAIL_MAX (64 tiles), DN_WINO8_TAIL_MINCH (8 chunks per split)
+  bool no_wgrad_split;      // DN_NO_WGRAD_SPLIT: no Winograd + tiled split of a weight gradient with a trailing 1-channel piece
   bool tile_store_linear_only;   // DN_TILE_STORE_LINEAR_ONLY: whole-pixel tile stores for dense un-phased results only (A/B)
   bool no_bn_hoist;         // DN_NO_BN_HOIST: the plain BatchNorm-backward apply kernel (A/B)
   bool no_x3_splitk;        // DN_NO_X3_SPLITK: no K split of small grids in the three-piece direct kernel
@@ -141,6 +142,7 @@ struct IgemmParams {
   const float *bnb_y, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
   float* bnb_partial;
   int ksplit, ks_chunks, ks_cnt_floats;   // input-channel split of small grids (dn_winograd.hip): splits, chunks of the K axis, float offset of the partial tiles
+  int dw_cin_total;                       // weight gradient of the LEADING operands of a wider layer: channels per row of dw (0: this plan's own)
   int ks_reg, ks_tail;                    // 8-wave kernel: tiles [0, ks_reg) run whole, the ks_tail tiles after them are split (dn_winograd8.hip)
   float* ks_ws;                  // caller workspace (dn_conv_desc.splitk_ws): zeroed int counters, then the partial tiles
   size_t ks_ws_bytes;

@@ -692,7 +692,8 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
 // Four threads per 4 consecutive ci, one per transform row i: each sums its 4 positions over the splits (the 16 positions x splits
 // reads are independent float4 streams; with one thread per quad the big layers ran 256 blocks of 64 dependent-free but serial loads
 // at 1.1 TB/s), applies G along j, and the rows meet through LDS for G along i.  Fixed summation order: deterministic.
-__global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits, int dw_vec) {
+__global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits, int dw_vec,
+                                                                int cin_total) {
   __shared__ f32x4 wl[64][4][3];
   const long long slab = (long long)Cout * Ktot, quads = slab >> 2;
   const int ql = threadIdx.x >> 2, i = threadIdx.x & 3;
@@ -728,7 +729,10 @@ __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const float* __r
           o[e][2 * 3 + c] = o2[e];
         }
       }
-      float* dst = dw + idx * 9;
+      // (cin_total > Ktot: these are the leading channels of a wider layer -- dn_conv2d_wgrad's split for a trailing 1-channel piece --
+      //  and a row of dw is cin_total * 9 floats; the quad's 4 channels never straddle a row, Ktot being a multiple of 64)
+      const long long co = idx / Ktot, ci = idx - co * Ktot;
+      float* dst = dw + (co * cin_total + ci) * 9;
 #pragma unroll
       for (int v = 0; v < 9; ++v) {
         if ((v & 3) != i) continue;
@@ -808,8 +812,9 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
   }
   int blocks = (int)(((slab >> 2) + 63) / 64);       // 64 quads (x 4 transform rows) per block
   if (blocks > 8192) blocks = 8192;
+  const int cin_total = p.dw_cin_total > Ktot ? p.dw_cin_total : Ktot;
   DN_LAUNCH(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc,
-                     (reinterpret_cast<uintptr_t>(dw) & 15) == 0 ? 1 : 0);
+                     ((reinterpret_cast<uintptr_t>(dw) & 15) == 0 && cin_total == Ktot) ? 1 : 0, cin_total);
   return check_launch("wino_wgrad_reduce_kernel");
 }
 
