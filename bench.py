@@ -322,7 +322,7 @@ def main():
     step, opt, state, desc = build_workload(args.config, batch, dev, rank, models, LF, U, reciprocal, FusedAdam)
     # (measured on one box, tape launches: b32 17.83 -> 17.72 ms with it; b8 5.83 -> 5.88 and b4 4.00 -> 4.04 -- at small batches the
     #  weight-gradient side streams the ranges run on are themselves close to critical -- so "auto" follows the per-GPU batch)
-    overlap_adam = args.adam_overlap == "1" or (args.adam_overlap == "auto" and args.config == "vggbn128" and batch * H * W > 8 * 128 * 416)
+    overlap_adam = args.adam_overlap == "1" or (args.adam_overlap == "auto" and args.config == "vggbn128" and batch * H * W > 16 * 128 * 416)
     # one rank: the reducer exchanges nothing (comm "torch" at world 1 = no collective) and only tells the optimizer when a bucket of
     # gradients is complete
     reducer = GradReducer(opt.arena, comm=(None if world > 1 else "torch")) if (world > 1 or overlap_adam) else None
