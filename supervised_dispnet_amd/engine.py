@@ -91,6 +91,7 @@ WGRAD_STREAM = _WGRAD_STREAM_MODE != "0"
 WGRAD_STREAMS = int(os.environ.get("DN_WGRAD_STREAMS", "2"))
 WGRAD_STREAMS_MAX_PIXELS = int(os.environ.get("DN_WGRAD_STREAMS_MAX_PIXELS", str(16 * 128 * 416)))   # measured: b4 -3.8 %, b8 -0.4 %, b16 -1.3 %, b32 +-0
 SIDE_STREAMS_ACTIVE = 1
+BIAS_FINALIZE_ON_MAIN = os.environ.get("DN_BIAS_FINALIZE_MAIN") is not None      # (A/B: second stage of the bias-gradient sums on the main stream)
 
 
 def choose_side_streams(input_pixels):
@@ -1078,7 +1079,11 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
                 sink.put(layer.m.bias, db)
             return db if (layer.m.bias is None or sink.dest(layer.m.bias) is None) else None      # (a fresh tensor the caller's stream will read)
 
-        conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink, first=(bias_grad, db_partial))
+        if BIAS_FINALIZE_ON_MAIN:
+            bias_grad()
+            conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink)
+        else:
+            conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink, first=(bias_grad, db_partial))
         conv_dgrad(layer, g, a0.N, OH, OW, pieces, in_hw)
         y.grad = None
 
