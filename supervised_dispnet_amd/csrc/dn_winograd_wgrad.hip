@@ -694,27 +694,39 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
 // at 1.1 TB/s), applies G along j, and the rows meet through LDS for G along i.  Fixed summation order: deterministic.
 __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Ktot, int splits, int dw_vec,
                                                                 int cin_total) {
-  __shared__ f32x4 wl[64][4][3];
+  // 16 quads per block; thread = (quad ql, transform row i, split slice zs): the splits z = zs, zs + 4, ... of the row's 4 positions
+  // are summed by the thread, the four slices meet through LDS in slice order (fixed order: deterministic).  (One thread per (quad,
+  // row) walking all splits ran the 64-channel layers as 16 blocks of 192 serial loads: 54 us at the very end of the backward pass.)
+  __shared__ f32x4 zl[16][4][4][4];      // [quad][row i][j][slice]
+  __shared__ f32x4 wl[16][4][3];
   const long long slab = (long long)Cout * Ktot, quads = slab >> 2;
-  const int ql = threadIdx.x >> 2, i = threadIdx.x & 3;
-  for (long long q0 = blockIdx.x * 64ll; q0 < quads; q0 += (long long)gridDim.x * 64) {
+  const int zs = threadIdx.x & 3, i = (threadIdx.x >> 2) & 3, ql = threadIdx.x >> 4;
+  for (long long q0 = blockIdx.x * 16ll; q0 < quads; q0 += (long long)gridDim.x * 16) {
     const long long qd = q0 + ql;
     const bool live = qd < quads;
     const long long idx = (live ? qd : 0) << 2;
-    f32x4 u[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
       const int pos = 4 * i + j;
-      for (int z = 0; z < splits; ++z) sacc += *reinterpret_cast<const f32x4*>(ws + ((long long)z * 16 + pos) * slab + idx);
-      u[j] = ((i == 3) != (j == 3)) ? -sacc : sacc;
+      for (int z = zs; z < splits; z += 4) sacc += *reinterpret_cast<const f32x4*>(ws + ((long long)z * 16 + pos) * slab + idx);
+      zl[ql][i][j][zs] = sacc;
     }
-    // along j:  w[c] = sum_j u[j] G[j][c],  G = (1 0 0 / .5 .5 .5 / .5 -.5 .5 / 0 0 1)
-    wl[ql][i][0] = u[0] + 0.5f * (u[1] + u[2]);
-    wl[ql][i][1] = 0.5f * (u[1] - u[2]);
-    wl[ql][i][2] = 0.5f * (u[1] + u[2]) + u[3];
     __syncthreads();
-    if (live) {
+    if (zs == 0) {
+      f32x4 u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 sacc = ((zl[ql][i][j][0] + zl[ql][i][j][1]) + zl[ql][i][j][2]) + zl[ql][i][j][3];
+        u[j] = ((i == 3) != (j == 3)) ? -sacc : sacc;
+      }
+      // along j:  w[c] = sum_j u[j] G[j][c],  G = (1 0 0 / .5 .5 .5 / .5 -.5 .5 / 0 0 1)
+      wl[ql][i][0] = u[0] + 0.5f * (u[1] + u[2]);
+      wl[ql][i][1] = 0.5f * (u[1] - u[2]);
+      wl[ql][i][2] = 0.5f * (u[1] + u[2]) + u[3];
+    }
+    __syncthreads();
+    if (live && zs == 0) {
       // along i:  o[r][c] = sum_i G[i][r] w_i[c]; the 4 x 9 results are 36 consecutive floats of dw (idx * 9 is a multiple of 4 floats);
       // thread i stores the float4s i, i + 4 (and 8 for i == 0)
       float o[4][9];
@@ -810,8 +822,8 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
     src = folded;
     nsrc = groups;
   }
-  int blocks = (int)(((slab >> 2) + 63) / 64);       // 64 quads (x 4 transform rows) per block
-  if (blocks > 8192) blocks = 8192;
+  int blocks = (int)(((slab >> 2) + 15) / 16);       // 16 quads (x 4 transform rows x 4 split slices) per block
+  if (blocks > 16384) blocks = 16384;
   const int cin_total = p.dw_cin_total > Ktot ? p.dw_cin_total : Ktot;
   DN_LAUNCH(wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, dw, p.Ntot, Ktot, nsrc,
                      ((reinterpret_cast<uintptr_t>(dw) & 15) == 0 && cin_total == Ktot) ? 1 : 0, cin_total);
