@@ -122,37 +122,44 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __re
                                                                float* shift, long long* num_batches_tracked) {
   const int c = blockIdx.x;
   if (num_batches_tracked != nullptr && c == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;   // nn.BatchNorm2d's step counter
-  __shared__ double red[kThreads];
-  __shared__ double s_mean;
-  double s1 = 0.0;
+  // One pass over the partial rows (was two: the sums for the mean, then the M2 merge about it): per row t the pair (s_t, M2_t about the
+  // tile's own mean) is read once and three sums are kept in fp64 -- S = sum s_t, Q = sum M2_t, P = sum s_t^2 / n_t -- from which
+  //   mean = S / N,   M2 = Q + sum_t n_t (s_t / n_t - mean)^2 = Q + P - N mean^2      (Chan et al., expanded).
+  // The expansion is taken in fp64 on TILE-centred second moments, so what cancels is only the between-tile part (a relative 1e-16
+  // of P against a result that is at least Q): nothing like the fp32 E[x^2] - mean^2 this layout was introduced to avoid.
+  __shared__ double red[3][4];
+  double s1 = 0.0, q = 0.0, pp = 0.0;
 #pragma unroll 8
-  for (int r = threadIdx.x; r < rows; r += kThreads) s1 += (double)partial[((long long)r * C + c) * 2 + 0];   // (8 strided loads in flight)
-  red[threadIdx.x] = s1;
-  __syncthreads();
-  for (int o = kThreads / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) s_mean = red[0] / count;
-  __syncthreads();
-  const double macc = s_mean;
-  double m2 = 0.0;
-#pragma unroll 8
-  for (int r = threadIdx.x; r < rows; r += kThreads) {
+  for (int r = threadIdx.x; r < rows; r += kThreads) {      // (8 strided 8-byte loads in flight)
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)r * C + c) * 2);
     const double left = count - (double)r * kBnTileRows;
     const double nt = left < (double)kBnTileRows ? left : (double)kBnTileRows;
-    const double d = (double)partial[((long long)r * C + c) * 2 + 0] / nt - macc;
-    m2 += (double)partial[((long long)r * C + c) * 2 + 1] + nt * d * d;
+    s1 += (double)v.x;
+    q += (double)v.y;
+    pp += (double)v.x * (double)v.x / nt;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    q += __shfl_xor(q, o);
+    pp += __shfl_xor(pp, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = q;
+    red[2][threadIdx.x >> 6] = pp;
   }
   __syncthreads();
-  red[threadIdx.x] = m2;
-  __syncthreads();
-  for (int o = kThreads / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  double macc = 0.0, m2tot = 0.0;
+  if (threadIdx.x == 0) {
+    const double S = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double Q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double P = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    macc = S / count;
+    m2tot = Q + (P - count * macc * macc);
   }
   if (threadIdx.x == 0) {
-    double var = red[0] / count;   // biased; the conv bias shifts the mean only
+    double var = m2tot / count;   // biased; the conv bias shifts the mean only
     if (var < 0.0) var = 0.0;
     const float mean = (float)(macc + (conv_bias ? (double)conv_bias[c] : 0.0));
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
