@@ -2100,7 +2100,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
   // bn_partial layout is per 128-row tile.
   const long long blocks128 = (long long)((p.M + 127) / 128) * (p.Npad / p.BN) * p.nphases;
   const bool small_m = p.uni32 && p.bn_partial == nullptr && blocks128 <= 208 && !knobs().no_bm64;
-  if (p.compute == DN_COMPUTE_F32X3 && p.uni32 && !knobs().no_u32 && !knobs().no_x3_direct && p.BN >= 64) {
+  if (p.compute == DN_COMPUTE_F32X3 && p.uni32 && !knobs().no_u32 && !knobs().no_x3_direct && (p.BN >= 64 || knobs().x3_bn32)) {
     // (the 32-wide N tile -- one 32 x 32 tile per wave, 12 matrix instructions per chunk against five split-and-store items -- measured
     //  4-17 % slower than the fp32 instruction: it stays on that)
     // fp32 products on the bf16 matrix cores (wave tiles of at most 2 x 32 x 32: the 128-wide N tile runs as 64-row blocks)

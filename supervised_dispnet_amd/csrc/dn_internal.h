@@ -50,6 +50,7 @@ struct Knobs {
   int reduce_rows_per_thread, reduce_max_blocks;   // DN_REDUCE_ROWS_PER_THREAD (2), DN_REDUCE_MAX_BLOCKS (1024): grid of the two-stage column reductions
   bool no_wino8_tail;       // DN_NO_WINO8_TAIL: no K split of the last partial round of the 8-wave Winograd kernel
   int wino8_tail_max, wino8_tail_minch;   // DN_WINO8_TAIL_MAX (64 tiles), DN_WINO8_TAIL_MINCH (8 chunks per split)
+  bool x3_bn32;             // DN_X3_BN32: three-piece direct kernel also for 32-wide N tiles (measured slower; A/B)
   bool no_wgrad_split;      // DN_NO_WGRAD_SPLIT: no Winograd + tiled split of a weight gradient with a trailing 1-channel piece
   bool tile_store_linear_only;   // DN_TILE_STORE_LINEAR_ONLY: whole-pixel tile stores for dense un-phased results only (A/B)
   bool no_bn_hoist;         // DN_NO_BN_HOIST: the plain BatchNorm-backward apply kernel (A/B)

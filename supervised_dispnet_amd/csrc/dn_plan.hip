@@ -92,6 +92,7 @@ static void read_knobs(Knobs* k) {
   k->no_tile_store = on("DN_NO_TILE_STORE");
   k->tile_store_linear_only = on("DN_TILE_STORE_LINEAR_ONLY");
   k->no_wgrad_split = on("DN_NO_WGRAD_SPLIT");
+  k->x3_bn32 = on("DN_X3_BN32");
   k->no_splitk = on("DN_NO_SPLITK");
   k->no_head2 = on("DN_NO_HEAD2");
   k->extra_lds = num("DN_DEBUG_EXTRA_LDS", 0);
