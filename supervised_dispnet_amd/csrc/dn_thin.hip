@@ -409,22 +409,28 @@ __global__ void __launch_bounds__(256) thin_conv_kernel(const IgemmParams p, int
         int base[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) base[mt] = (pn[mt] * (int)S.sn + pby[mt] * (int)S.sh + pbx[mt] * (int)S.sw + 4 * kk) * 4;
-        for (int j = 0; j < ntaps; ++j) {
+        // (tap, channel block) steps in one flat sequence, the NEXT step's four patch loads in flight under this step's 16 matrix
+        // instructions (the plain nest issued them right before their first use: every step paid a full memory latency)
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto load_step = [&](int st, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+          const int j = st / nblk, cb = st - j * nblk;
           const int tp = tapl[j];
           const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
-          const int toff = (dy * (int)S.sh + dx * (int)S.sw) * 4;
-          bool ok[4];
+          const int toff = (dy * (int)S.sh + dx * (int)S.sw) * 4 + cb * 64;
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            ok[mt] = plive[mt] && (unsigned)(pby[mt] + dy) < (unsigned)p.IH && (unsigned)(pbx[mt] + dx) < (unsigned)p.IW;
-          for (int cb = 0; cb < nblk; ++cb) {
-            f32x4 a4[4];
+          for (int mt = 0; mt < 4; ++mt) {
+            const bool ok = plive[mt] && (unsigned)(pby[mt] + dy) < (unsigned)p.IH && (unsigned)(pbx[mt] + dx) < (unsigned)p.IW;
+            dst[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? base[mt] + toff : -1, 0, 0));
+          }
+        };
+        const int nst = ntaps * nblk;
+        f32x4 a4[2][4];
+        load_step(0, a4[0]);
+        for (int st = 0; st < nst; st += 2) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-              const int off = ok[mt] ? base[mt] + toff + cb * 64 : -1;
-              typedef int i32x4 __attribute__((ext_vector_type(4)));
-              a4[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-            }
+          for (int h = 0; h < 2; ++h) {
+            if (st + h >= nst) break;
+            if (st + h + 1 < nst) load_step(st + h + 1, a4[h ^ 1]);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
               float b[NT];
@@ -433,7 +439,7 @@ __global__ void __launch_bounds__(256) thin_conv_kernel(const IgemmParams p, int
 #pragma unroll
               for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][s4], b[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[h][mt][s4], b[nt], acc[mt][nt], 0, 0, 0);
             }
             k4 += 4;
           }
