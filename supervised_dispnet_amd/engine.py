@@ -215,25 +215,30 @@ def fence_streams():
         stream_wait(cur, st["main"])
 
 
-_SPLITK = {}      # device index -> (zeroed workspace, bytes, raw side-stream handle): dn_conv_desc.splitk_ws of the launches on the MAIN compute stream
+_SPLITK = {}      # (device index, raw stream handle) -> (zeroed workspace, bytes, -, pointer): dn_conv_desc.splitk_ws of that stream's launches
 _SPLITK_BYTES = 80 << 20     # >= 4096 + 256 blocks x 8 splits x 32 KB of partial tiles: the largest workspace any launch asks for (dn_winograd.hip)
 
 
 def _splitk_workspace(d, device):
-    """Attach the input-channel-split workspace to a conv descriptor (small Winograd grids: a 4-image shard of the metric's batch;
-    DESIGN.md section 6); the library decides per launch whether it splits (dn_conv_splitk_workspace_bytes).  One zeroed buffer per
-    device serves every launch of the main stream (the counters reset themselves); launches on the weight-gradient side stream never
-    split.  No torch calls on the hot path: the step makes ~80 of these and is launch-bound at 4 images."""
+    """Attach the K-split workspace to a conv descriptor (small grids: a 4-image shard of the metric's batch); the
+    library decides per launch whether it splits (dn_conv_splitk_workspace_bytes).  One zeroed buffer per (device, stream) serves every
+    launch of that stream (the counters reset themselves; launches on different streams must not share one); launches on the
+    weight-gradient side streams never split.  No torch calls on the hot path: the step makes ~80 of these and is launch-bound at 4
+    images."""
     if not SPLITK or device.type != "cuda":
         return
-    cur = _SPLITK.get(device.index)
+    h = _stream()
+    cur = _SPLITK.get((device.index, h))
     if cur is None:
         with torch.cuda.device(device):
-            side = side_stream()["handles"]
-        with outside_tape_pool():
-            buf = torch.zeros(_SPLITK_BYTES // 4, dtype=torch.float32, device=device)
-        cur = _SPLITK[device.index] = (buf, _SPLITK_BYTES, side, buf.data_ptr())
-    if _stream() in cur[2]:
+            sides = side_stream()["handles"]
+        if h in sides:
+            _SPLITK[(device.index, h)] = cur = (None, 0, None, None)
+        else:
+            with outside_tape_pool():
+                buf = torch.zeros(_SPLITK_BYTES // 4, dtype=torch.float32, device=device)
+            cur = _SPLITK[(device.index, h)] = (buf, _SPLITK_BYTES, None, buf.data_ptr())
+    if cur[0] is None:
         return
     d.splitk_ws = cur[3]
     d.splitk_ws_bytes = cur[1]
