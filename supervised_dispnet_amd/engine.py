@@ -164,6 +164,7 @@ class outside_tape_pool(object):
     def __exit__(self, *exc):
         if self.rec is not None and self.rec.get("pool") is not None:
             torch._C._cuda_beginAllocateToPool(*self.rec["pool"])
+            torch._C._cuda_releasePool(*self.rec["pool"])        # (begin takes a reference of its own each time; keep the count at the recorder's)
         return False
 
 
@@ -595,6 +596,13 @@ class PackTable(object):
             self.covered = {r[5] for r in rows}
             self.dirty = False
             self.split_mode = split
+        if TAPE is not None and not TAPE.get("paused"):
+            # the launches below go on a launch tape: everything they point at must live as long as the tape does -- the device tables
+            # (replaced whenever a row changes), and the weights / packed buffers of EVERY row, also those of another model that
+            # happens to be alive now and is deleted later (its rows are re-laid needlessly at replay, never into freed memory)
+            TAPE["keep"] += [t for t in (self.dev_table, self.late_table) if t is not None]
+            for r in self.rows.values():
+                TAPE["keep"] += [x for x in (r[2](), r[3]()) if x is not None]
         if self.dev_table is not None:
             _lib.call("dn_pack_many", self.dev_table.data_ptr(), *self.counts, _stream())
         if self.late_table is not None:

@@ -17,6 +17,8 @@ Requirements on the step callable (all met by the engine):
 Multi-rank: the gradient all-reduce (RCCL via torch.distributed) is capturable by ProcessGroupNCCL but that path cannot be
 exercised on this one-GPU pool, so callers decide (bench.py: --graph auto = single-rank only).
 """
+import os
+
 import torch
 
 from . import engine
@@ -101,6 +103,7 @@ class TapedStep(object):
         self._warmup = warmup
         self._pool = None
         self._keep = None
+        self._pid = os.getpid()
 
     def capture(self):
         from . import _lib
@@ -113,6 +116,12 @@ class TapedStep(object):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         dev = torch.cuda.current_device()
+        # models of earlier runs that are garbage but not collected yet still have rows in the batched weight re-lay: drop them before
+        # the recording takes a snapshot of that table (it keeps what it snapshots alive, see engine.PackTable.run)
+        import gc
+        gc.collect()
+        for t in engine._PACK_TABLES.values():
+            t._prune()
         self._pool = torch.cuda.MemPool()
         handle = lib.dn_tape_begin()
         if not handle:
@@ -127,12 +136,14 @@ class TapedStep(object):
             torch.cuda.current_stream().wait_stream(s)
         except BaseException:
             torch._C._cuda_endAllocateToPool(dev, self._pool.id)
+            torch._C._cuda_releasePool(dev, self._pool.id)
             engine.TAPE = None
             lib.dn_tape_free(handle)          # (also ends the recording)
             del self.host_calls[:]
             raise
         torch._C._cuda_endAllocateToPool(dev, self._pool.id)
-        engine.TAPE = None
+        torch._C._cuda_releasePool(dev, self._pool.id)       # (the begin's reference; the MemPool object keeps the pool -- and every
+        engine.TAPE = None                                    #  block the tape points into -- alive for as long as this TapedStep lives)
         _lib.call("dn_tape_end", handle)
         torch.cuda.synchronize()
         self._keep = rec["keep"]          # (cheap to hold; dropping them would only return the blocks to the private pool)
@@ -165,13 +176,16 @@ class TapedStep(object):
             from . import _lib
             raise _lib.DispnetHipError("dn_tape_replay failed (%d): %s" % (rc, _lib.last_error()))
         cur.wait_stream(s)
+        engine.bump_param_epoch()         # the replayed optimizer changed the weights: eager code that follows re-lays its packed copies
         return self.out
 
     def verify(self, state):
         """Replay once and run the SAME step eagerly once from the same state (`state`: the tensors the step reads and updates --
         parameters, optimizer moments and counters, BatchNorm buffers), and compare the resulting state and outputs bit for bit.
         Leaves the state one step further (the eager result).  Returns (identical, largest absolute difference).  What the unit tests
-        pin at small sizes, checked on the caller's own workload and size (bench.py reports it in config.tape_verified)."""
+        pin at small sizes, checked on the caller's own workload and size (bench.py reports it in config.tape_verified).
+        A caller whose inputs change from step to step writes a batch DIFFERENT from the recorded one into the static inputs first:
+        framework-side work the tape missed then shows up as stale data (train.py --tape does)."""
         if self.tape is None:
             self.capture()
         torch.cuda.synchronize()
@@ -190,6 +204,7 @@ class TapedStep(object):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         outs_e = list(out_e if isinstance(out_e, (tuple, list)) else (out_e,))
+        self.last_eager_out = outs_e
         worst, same = 0.0, True
         for a, b in list(zip(after_r, state)) + list(zip(outs_r, outs_e)):
             if not torch.equal(a, b):
@@ -197,10 +212,23 @@ class TapedStep(object):
                 worst = max(worst, float((a.double() - b.double()).abs().max()))
         return same, worst
 
+    def close(self):
+        """Free the tape and the private pool now (idempotent).  Call it when the taped training is over rather than leaving it to the
+        garbage collector: the step closure usually refers back to its owner (a cycle), and a process forked in the meantime -- a
+        DataLoader worker -- would inherit the garbage and run this destructor without the HIP context behind it."""
+        if self._pid != os.getpid():
+            return
+        if self.tape is not None:
+            self._lib.dn_tape_free(self.tape)
+            self.tape = None
+        self.host_calls = []
+        self.step = None
+        self._keep = None
+        self.out = None
+        self._pool = None
+
     def __del__(self):
         try:
-            if self.tape is not None:
-                self._lib.dn_tape_free(self.tape)
-                self.tape = None
+            self.close()
         except Exception:                 # noqa: BLE001  (interpreter shutdown)
             pass

@@ -144,3 +144,21 @@ def test_train_cli_from_uint8_shards(tmp_path):
     assert len(rows) == 1 + 2 * 3                                      # 12 samples / batch 4, two epochs
     vals = np.array([[float(v) for v in r] for r in rows[1:]])
     assert np.isfinite(vals).all() and (vals[:, 0] > 0).all()
+
+
+@pytest.mark.parametrize("loss", ["L1", "Multi_L1"])
+def test_train_cli_launch_tape_equals_the_eager_run(tmp_path, capsys, loss):
+    """train.py --tape: the supervised step through the launch tape (recorded on the first batch, checked bit for bit against the eager
+    step on the second, replayed from the third on) logs the same per-step losses and ends with the same weights as the eager run of the
+    same command line -- up to the last bit of Adam's step size (device-side vs host-side pow() of the bias corrections)."""
+    args = ["--network", "disp_vgg_BN", "--with-gt", "--loss", loss, "--seed", "3"]
+    ve, sde, _ = _run_train(tmp_path / "eager", args, epochs=2, n=16, b=4)
+    vt, sdt, _ = _run_train(tmp_path / "tape", args + ["--tape"], epochs=2, n=16, b=4)
+    out = capsys.readouterr().out
+    assert "--tape:" in out and "bit for bit" in out, out[-600:]
+    assert "eager launches (" not in out
+    assert vt.shape == ve.shape
+    assert np.allclose(vt[:, 0], ve[:, 0], rtol=2e-5), (vt[:, 0], ve[:, 0])
+    for k, v in sde["state_dict"].items():
+        if torch.is_floating_point(v):
+            assert torch.allclose(sdt["state_dict"][k], v, rtol=1e-4, atol=2e-6), k

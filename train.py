@@ -87,6 +87,10 @@ def build_parser():
     p.add_argument("--img-height", type=int, default=128, help="synthetic image height")
     p.add_argument("--img-width", type=int, default=416, help="synthetic image width")
     p.add_argument("--train-pose", action="store_true", help="also optimise PoseExpNet (the reference never does, appendix C-3)")
+    p.add_argument("--tape", action="store_true",
+                   help="supervised per-sample / multi-scale losses with the fused Adam: record the launches of one training step and re-issue "
+                        "them with one call per step (supervised_dispnet_amd.graph.TapedStep); the second batch checks the replay against "
+                        "the eager step bit for bit, a mismatch or an unsupported setting falls back to eager launches with a message")
     p.add_argument("--save-root", default="checkpoints", help="directory under which the run folder is created")
     return p
 
@@ -323,6 +327,8 @@ def main(argv=None):
 
     ctx = dict(args=args, device=device, LF=LF, U=U, reciprocal=reciprocal, rank=rank, world=world, reducer=reducer, save_path=save_path,
                plain_params=plain_params)
+    if args.tape:
+        ctx["tape"] = TapedTrainer(args, LF, reciprocal, disp_net, optimizer, reducer, rank)
 
     def run_validation(epoch):
         if args.with_gt:
@@ -353,6 +359,8 @@ def main(argv=None):
                             {"epoch": epoch + 1, "state_dict": pose_exp_net.state_dict()}, is_best, epoch, record=args.record)
             with open(os.path.join(save_path, args.log_summary), "a") as f:
                 csv.writer(f, delimiter="\t").writerow([train_loss, decisive])
+    if ctx.get("tape") is not None:
+        ctx["tape"].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -367,6 +375,89 @@ def _to_device_batch(batch, device, unsupervised):
     return tgt.to(device, non_blocking=True), None, None, None, gt.to(device, non_blocking=True)
 
 
+class TapedTrainer(object):
+    """--tape: the supervised training step (forward, 1/disp, loss, backward, gradient exchange, Adam) through a launch tape.
+    The first full-size batch is recorded (a real step); the second one is written into the tape's static input buffers and the replay
+    is checked against the same step issued eagerly from the same state, bit for bit -- on a batch the tape has not seen, so work it
+    missed would show up as stale data; only then are further batches replayed.  Batches of another shape (the last one of an epoch),
+    a failed recording or a failed check run eagerly."""
+
+    def __init__(self, args, LF, reciprocal, disp_net, optimizer, reducer, rank):
+        self.args, self.LF, self.reciprocal = args, LF, reciprocal
+        self.net, self.opt, self.reducer, self.rank = disp_net, optimizer, reducer, rank
+        self.ts = None
+        self.state = "new"            # new -> recorded -> verified | off
+        self.img = self.gt = None
+        why = None
+        if args.unsupervised or args.loss == "DORN" or args.monodepth2:
+            why = "only the supervised depth losses are taped"
+        elif args.photo_loss_weight != 1 or args.mask_loss_weight != 0 or args.smooth_loss_weight != 0:
+            why = "needs -p 1 -m 0 -s 0 (the weighted sum of loss terms is framework-side arithmetic)"
+        elif not hasattr(optimizer, "arena"):
+            why = "needs the fused Adam (not --sgd / --diff-lr)"
+        if why is not None:
+            self._off(why)
+
+    def close(self):
+        """End of training: free the tape now (graph.TapedStep.close -- a DataLoader worker forked later must not inherit it as garbage)."""
+        if self.ts is not None:
+            self.ts.close()
+            self.ts = None
+        self.state = "off"
+
+    def _off(self, why):
+        self.state = "off"
+        if self.rank == 0:
+            print("=> --tape: eager launches ({})".format(why))
+
+    def usable(self, img, gt):
+        if self.state == "off":
+            return False
+        return self.img is None or (img.shape == self.img.shape and gt.shape == self.gt.shape)
+
+    def _step(self):
+        from supervised_dispnet_amd.graph import backward
+        depth = [self.reciprocal(d) for d in self.net(self.img)]
+        loss = supervised_loss(self.args, self.LF, self.gt, depth)
+        self.opt.zero_grad()
+        backward(loss)
+        self.opt.step(grad_scale=self.reducer.finish() if self.reducer is not None else 1.0)
+        return loss
+
+    def step(self, img, gt):
+        """One training step on (img, gt); returns the loss value, or None when the caller has to run the step eagerly."""
+        from supervised_dispnet_amd.graph import TapedStep
+        if self.img is None:
+            self.img, self.gt = img.clone(), gt.clone()
+        else:
+            self.img.copy_(img)
+            self.gt.copy_(gt)
+        try:
+            if self.state == "new":
+                self.ts = TapedStep(self._step, optimizer=self.opt, warmup=0, static_inputs=(self.img, self.gt))
+                loss = self.ts()                                   # recorded = executed
+                self.state = "recorded"
+                return float(loss.item())
+            if self.state == "recorded":
+                st = [self.opt.arena.flat_p, self.opt.exp_avg, self.opt.exp_avg_sq, self.opt._dev["step"], self.opt._dev["derived"]]
+                st += [b for b in self.net.buffers() if b.is_cuda]
+                same, worst = self.ts.verify(st)                   # (leaves the state one step further: this batch's eager step)
+                if same:
+                    self.state = "verified"
+                    if self.rank == 0:
+                        print("=> --tape: {} launches + {} stream fences per step, {} segment(s); replay == eager step on the second "
+                              "batch, bit for bit".format(self.ts.launches, self.ts.fences, self.ts.segments))
+                else:
+                    self._off("replay differs from the eager step on the second batch, max |diff| {:.3g}".format(worst))
+                return float(self.ts.last_eager_out[0].item())     # (either way this batch's step was taken: the check's eager one)
+            return float(self.ts().item())
+        except Exception as e:          # noqa: BLE001 -- a setting the tape refuses (e.g. whole-batch loss statistics under data parallelism)
+            if self.state == "verified":
+                raise
+            self._off("{}: {}".format(type(e).__name__, str(e)[:160]))
+            return None
+
+
 def train(ctx, loader, disp_net, pose_exp_net, optimizer, epoch_size, n_iter):
     args, device, LF, U, reciprocal = ctx["args"], ctx["device"], ctx["LF"], ctx["U"], ctx["reciprocal"]
     rank, reducer = ctx["rank"], ctx["reducer"]
@@ -379,9 +470,26 @@ def train(ctx, loader, disp_net, pose_exp_net, optimizer, epoch_size, n_iter):
                 m.eval()
     losses, batch_time, data_time = Meter(), Meter(), Meter()
     end = time.time()
+    tape = ctx.get("tape") if args.tape else None
     for i, batch in enumerate(loader):
         data_time.update(time.time() - end)
         tgt_img, ref_imgs, intrinsics, intrinsics_inv, gt_depth = _to_device_batch(batch, device, args.unsupervised)
+        if tape is not None and tape.usable(tgt_img, gt_depth):
+            lv = tape.step(tgt_img, gt_depth)
+            if lv is not None:
+                losses.update(lv, args.batch_size)
+                batch_time.update(time.time() - end)
+                end = time.time()
+                if rank == 0:
+                    with open(os.path.join(ctx["save_path"], args.log_full), "a") as f:
+                        csv.writer(f, delimiter="\t").writerow([lv, lv, 0, 0])
+                    if i % args.print_freq == 0:
+                        print("Train: [{}/{}] Time {:.3f} ({:.3f}) Data {:.3f} Loss {:.4f} ({:.4f})".format(
+                            i, min(len(loader), epoch_size), batch_time.val[0], batch_time.avg[0], data_time.avg[0], lv, losses.avg[0]))
+                if i >= epoch_size - 1:
+                    break
+                n_iter += 1
+                continue
         explainability_mask, pose = (None, None)
         if args.unsupervised:
             explainability_mask, pose = pose_exp_net(tgt_img, ref_imgs)
