@@ -256,3 +256,59 @@ def test_launch_tape_refuses_framework_side_device_work_and_recovers():
     l1 = ts()
     torch.cuda.synchronize()
     assert torch.isfinite(l0) and torch.isfinite(l1) and float(l1) < float(l0)
+
+
+def test_launch_tape_outlives_other_models_in_the_weight_relay_table():
+    """The batched weight re-lay (engine.PackTable) is per device, not per model: a step recorded while ANOTHER model is alive re-lays
+    that model's rows too.  The tape keeps what it recorded alive (device tables, weights, packed buffers), so deleting the other model
+    -- and letting the allocator hand its memory out again -- must neither fault nor change the taped model's results."""
+    import gc
+    from supervised_dispnet_amd.graph import TapedStep, backward
+    batches = [bench.synthetic_batch(2, 64, 96, DEV, seed) for seed in range(4)]
+    net_o, opt_o = _make()                                   # the "other" model: two eager steps register its rows
+    for _ in range(2):
+        depth = [reciprocal(d) for d in net_o(batches[0][0])]
+        loss = LF.l1_loss(batches[0][1], depth, "kitti")
+        opt_o.zero_grad()
+        loss.backward()
+        opt_o.step()
+    net_e, opt_e = _make()
+    sd0 = copy.deepcopy({k: v.detach().cpu().clone() for k, v in net_e.state_dict().items()})
+    net_t, opt_t = _make(sd0)
+    opt_e.capturable(True)
+    img, gt = batches[0][0].clone(), batches[0][1].clone()
+
+    def step_t():
+        depth = [reciprocal(d) for d in net_t(img)]
+        loss = LF.l1_loss(gt, depth, "kitti")
+        opt_t.zero_grad()
+        backward(loss)
+        opt_t.step()
+        return loss
+
+    def step_e(x, y):
+        depth = [reciprocal(d) for d in net_e(x)]
+        loss = LF.l1_loss(y, depth, "kitti")
+        opt_e.zero_grad()
+        backward(loss)
+        opt_e.step()
+        return loss
+
+    ts = TapedStep(step_t, optimizer=opt_t, warmup=1, static_inputs=(img, gt)).capture()     # net_o's rows are in the recorded re-lay
+    for _ in range(2):
+        step_e(*batches[0])
+    del net_o, opt_o, depth, loss
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(16)]             # reuse whatever was released
+    for x, y in batches[1:]:
+        img.copy_(x)
+        gt.copy_(y)
+        lt = ts().clone()
+        le = step_e(x, y).clone()
+        torch.cuda.synchronize()
+        assert torch.isfinite(lt) and torch.equal(lt, le)
+    del junk
+    assert torch.equal(opt_t.arena.flat_p, opt_e.arena.flat_p)
+    ts.close()
+    ts.close()                                                # idempotent
