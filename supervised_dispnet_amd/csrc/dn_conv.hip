@@ -1336,24 +1336,29 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
   const int ntiles = (p.M + 127) / 128;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * 128;
-    if (tid < 128) rowpix[tid] = (m0 + tid) < p.M ? m0 + tid : -1;
-    const int m = m0 + 32 * wave + (lane & 31);
-    const bool live = m < p.M;
+  // the gathers of the NEXT tile are issued before this tile's epilogue (LDS tile, statistics, stores: three barriers during which
+  // nothing else of this block was in flight)
+  auto gather = [&](int tile, float (&dst)[NS]) __attribute__((always_inline)) {
+    const int m = tile * 128 + 32 * wave + (lane & 31);
+    const bool live = tile < ntiles && m < p.M;
     unsigned gx, gy;
     const unsigned t = fastdiv_dev(live ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
     const int n = (int)fastdiv_dev(t, (unsigned)p.GH, p.mGH, &gy);
     const int base = n * (int)S.sn + (int)gy * (int)S.sh + (int)gx * (int)S.sw;
-    float a[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int iy = (int)gy + kdy[s], ix = (int)gx + kdx[s];
       const bool ok = live && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
       int off = (base + kdy[s] * (int)S.sh + kdx[s] * (int)S.sw + kco[s]) * 4;
       off = ok ? off : -1;
-      a[s] = s < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0)) : 0.f;
+      dst[s] = s < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0)) : 0.f;
     }
+  };
+  float a[NS], an[NS];
+  gather((int)blockIdx.x, a);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    if (tid < 128) rowpix[tid] = (m0 + tid) < p.M ? m0 + tid : -1;
     f32x16 acc[1][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1366,6 +1371,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[s][1], acc[0][1], 0, 0, 0);
       }
     }
+    gather(tile + (int)gridDim.x, an);
     __syncthreads();
     // bias + activation into the LDS tile (C/D layout: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)), then
     // float4 stores of whole pixels: a wave writes 1 KiB contiguous per instruction instead of 2 x 128 bytes (this kernel is bound
@@ -1392,6 +1398,8 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
           *reinterpret_cast<f32x4*>(R.p + (long long)(m0 + row) * R.sw + 4 * c4) = *reinterpret_cast<const f32x4*>(Ts + row * 68 + 4 * c4);
       }
     }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = an[s];
     __syncthreads();
   }
 }
