@@ -21,6 +21,16 @@ Rank 0 prints ONE JSON line.
                     (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64, tools/ubench/bf16x3.hip); every default run also times the
                     same step with the fp32 matrix instruction (`f32_mfma_path`), so both numbers come from one run on one box.
 
+  --launch          auto (default) | tape | eager | graph: how the host issues the step.  tape: the kernel launches and stream fences of ONE
+                    real step are recorded inside libdispnet_hip (dn_tape_*, graph.TapedStep) and re-issued by one C call per step -- the
+                    same kernels on the same streams as the eager launches, ~2 us of host time each instead of ~20 (at 32 / 8 = 4 images
+                    per GPU the Python side of a step costs as much as the device side); under data parallelism the tape is cut at every
+                    gradient bucket and the all-reduce is issued live in between.  Before the timed region one replay and one eager step
+                    from the same state must agree bit for bit (config.tape_verified), else the run uses eager launches and says so.
+                    auto = tape for the metric's config.  graph = hipGraph replay (slower on the device than eager on ROCm 7.2).
+  --adam-overlap    auto (default) | 0 | 1: the Adam update of a gradient bucket right behind the bucket's completion / all-reduce, under
+                    the rest of the backward pass (bit-identical to one update); auto = above 16 images per GPU.
+
 Besides the contract fields the line carries
   roofline      the dominant matrix-pipe kernel (by time).  `achieved` = multiply-accumulates the kernel EXECUTES on its matrix pipe x 2
                 divided by its launch durations (HIP events on the launch stream, instrumented steps after the timed region); `peak` =
