@@ -4,6 +4,7 @@ KITTI-like data resident in HBM (BASELINE.json metric / configs[1]; SURVEY.md se
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...          (no launcher: spawns the N ranks itself through torch.distributed.run on a free port)
 
 One rank per GPU (RCCL over xGMI); the only exchange is the bucketed gradient all-reduce overlapped with the encoder backward.
 Rank 0 prints ONE JSON line.
@@ -44,7 +45,8 @@ Besides the contract fields the line carries
   step_executed_frac  all conv-family launches' fp32-equivalent executed FLOPs (each fp32 multiply-accumulate once) over the step time, / 157.3.
   f32_mfma_path the same step timed with --compute f32 semantics (fp32 matrix instruction everywhere) after the headline region.
   cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU restatement pinned to the reference's golden vectors; kind "port")
-                running the same training step on this box's host cores per SURVEY 8d: batch 8, 2 warm-up + 10 timed steps (~11 s of CPU work).
+                running the same training step on this box's host cores per SURVEY 8d: batch 8, 2 warm-up + 6 timed steps at each of 32 / 64 / 128
+                torch threads (~20 s of CPU work); `value` is the best of the three, all three are in `sample` / `by_threads`.
 """
 import argparse
 import json
@@ -113,37 +115,47 @@ def host_description():
 
 
 def cpu_baseline(h, w, batch, steps, warmup, threads=None):
-    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (b8, 2 warm-up + 10 timed by default)."""
+    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (b8, warm-up + timed steps), at
+    32, 64 and 128 torch threads (capped at the logical CPU count; DN_CPU_THREADS=n[,n..] overrides): the BEST is `value`, all of them
+    are in `sample`.  Every logical CPU of the 2-socket GPU host oversubscribes oneDNN at this problem size (round 1: 0.04 img/s with
+    256 threads), so the sweep stops at 128."""
     from oracle import losses as OL, nets as ON
     model, physical, logical = host_description()
-    # oneDNN/OpenMP with every logical CPU of this 2-socket host oversubscribes badly at this problem size (measured in round 1:
-    # 0.04 img/s with 256 threads vs 7.1 with 32, batch 4), so the baseline runs on DN_CPU_THREADS (default 32) threads and the
-    # line says so next to the host's core counts.
-    cores = int(threads or os.environ.get("DN_CPU_THREADS", min(logical, 32)))
-    torch.set_num_threads(cores)
-    sd = ON.xavier_init_(ON.disp_vgg_bn_state_dict(), torch.Generator().manual_seed(0))
-    params = []
-    for k, v in sd.items():
-        if torch.is_floating_point(v) and "running" not in k:
-            v.requires_grad_(True)
-            params.append(v)
-    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
+    if threads:
+        sweep = [int(threads)]
+    elif os.environ.get("DN_CPU_THREADS"):
+        sweep = [int(t) for t in os.environ["DN_CPU_THREADS"].split(",")]
+    else:
+        sweep = sorted({min(t, logical) for t in (32, 64, 128)})
     img, gt = synthetic_batch(batch, h, w, "cpu", 0)
-    t0 = None
-    for it in range(warmup + steps):
-        if it == warmup:
-            t0 = time.perf_counter()
-        depth = [1 / d for d in ON.disp_vgg_bn(sd, img, training=True)]
-        loss = OL.l1_loss(gt, depth, "kitti")
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+    rates = {}
+    for cores in sweep:
+        torch.set_num_threads(cores)
+        sd = ON.xavier_init_(ON.disp_vgg_bn_state_dict(), torch.Generator().manual_seed(0))
+        params = []
+        for k, v in sd.items():
+            if torch.is_floating_point(v) and "running" not in k:
+                v.requires_grad_(True)
+                params.append(v)
+        opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
+        t0 = None
+        for it in range(warmup + steps):
+            if it == warmup:
+                t0 = time.perf_counter()
+            depth = [1 / d for d in ON.disp_vgg_bn(sd, img, training=True)]
+            loss = OL.l1_loss(gt, depth, "kitti")
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        rates[cores] = batch * steps / (time.perf_counter() - t0)
+    best = max(rates, key=rates.get)
+    return {"value": rates[best], "unit": "images/sec", "cores": best, "kind": "port",
             "host_cpu": model, "host_physical_cores": physical, "host_logical_cpus": logical,
-            "sample": "oracle Disp_vgg_BN+L1+Adam, %dx%d, batch %d, %d timed steps (%d warm-up), torch %d threads on a host with %s "
-                      "physical cores / %d logical CPUs (all-logical-CPU run measured 0.04 img/s in round 1: oversubscribed)" % (
-                          h, w, batch, steps, warmup, cores, physical, logical)}
+            "by_threads": {str(k): v for k, v in rates.items()},
+            "sample": "oracle Disp_vgg_BN+L1+Adam, %dx%d, batch %d, %d timed steps (%d warm-up) per thread count; img/s at %s torch threads "
+                      "(best: %d) on a host with %s physical cores / %d logical CPUs (all-logical-CPU run measured 0.04 img/s in round 1: "
+                      "oversubscribed)" % (h, w, batch, steps, warmup, ", ".join("%d: %.2f" % kv for kv in rates.items()), best,
+                                           physical, logical)}
 
 
 def measured_peaks(dev):
@@ -253,7 +265,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print the per-layer launch table to stderr")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--compute", default="f32x3", choices=["f32", "f32x3", "bf16"],
                     help="arithmetic of the Winograd forward / input-gradient kernels (tensors and every other kernel are fp32 in all modes). "
@@ -288,8 +300,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # invoked plainly (`python bench.py --gpus N`, as the reference's train.py needs no launcher either: train.py:316-317):
+        # become the launcher -- one rank per GPU under torch.distributed.run on a free local port; rank 0 prints the line
+        return self_launch(args.gpus)
     if args.dry_run:
         return dry_run(args, world, rank)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
@@ -317,6 +331,8 @@ def main():
     from supervised_dispnet_amd.optim import FusedAdam
 
     engine.set_compute(args.compute)
+    global PMC_CONFIG
+    PMC_CONFIG = args.config
     metric, netname, H, W, cfg_batch, ds, gflop_img = CONFIGS[args.config]
     if args.compute == "bf16":
         metric = metric.replace(", fp32)", ", mixed precision: bf16 multiplies / fp32 accumulation in the Winograd kernels)")
@@ -593,6 +609,26 @@ def main():
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command line as N ranks under torch.distributed.run
+    (--nnodes=1, rendezvous on 127.0.0.1 and a port the kernel just handed out), stream the children's output through, and
+    return their exit status.  LOCAL_RANK -> device is taken modulo the visible device count, so two ranks on a one-GPU box
+    (DN_DIST_BACKEND=gloo) exercise the same path."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
 def rccl_selfcheck(line, dev, rank, world, timeout_s=90.0):
     """N > 1 only, AFTER every timed region: one 20 MB gradient-bucket-sized buffer is summed over the ranks through this library's own
     RCCL communicator (rccl.Communicator: ncclCommInitRank from a unique id passed through torch.distributed's store, ncclAllReduce
@@ -695,16 +731,29 @@ def dry_run(args, world, rank):
         raise SystemExit(1)
 
 
+PMC_CONFIG = "vggbn128"     # set by main(): which committed PMC summary describes this run's workload
+
+
+def _pmc_file():
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if PMC_CONFIG == "vggbn128":        # rNN_x_pmc_traffic.json; the other configs' summaries carry the config name
+        files = [f for f in files if re.match(r"r\d+_[a-z]+_pmc_traffic\.json$", os.path.basename(f))]
+    else:
+        files = [f for f in files if os.path.basename(f).endswith("_%s_pmc_traffic.json" % PMC_CONFIG)]
+    return files[-1] if files else None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` (read + write) from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, corrected and calibrated as profiles/*pmc_traffic.json states), or None.
-    The counters cannot be collected from inside this process, so the latest committed summary is reported."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
+    The counters cannot be collected from inside this process, so the latest committed summary of this config is reported."""
+    f = _pmc_file()
+    if f is None:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        k = json.load(open(f))["kernels"].get(kernel)
         return (k["read_bytes"] + k["write_bytes"]) if k else None
     except Exception:
         return None
@@ -713,11 +762,10 @@ def pmc_traffic(kernel):
 def pmc_traffic_source(kernel):
     """Which committed profile `traffic` was read from: the PMC passes describe the build that was PROFILED, which may be older than
     the build this run timed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files or pmc_traffic(kernel) is None:
+    f = _pmc_file()
+    if f is None or pmc_traffic(kernel) is None:
         return None
-    return "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the build that was profiled, not measured in this run)" % os.path.basename(files[-1])
+    return "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the build that was profiled, not measured in this run)" % os.path.basename(f)
 
 
 def _quiet_init(net):

@@ -13,7 +13,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 # ABI version this binding was written against (include/dispnet_hip.h: dn_version(), bumped on any signature / struct change).
 # load() refuses a library that reports anything else: a stale .so (DISPNET_HIP_LIB, a build that did not re-run) would otherwise
 # read struct fields past the end of what this binding fills in and mis-marshal arguments -- silent memory corruption, not an error.
-EXPECTED_ABI = 11
+EXPECTED_ABI = 12
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
@@ -172,6 +172,7 @@ SIGNATURES = {
     "dn_ubench_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "dn_ubench_mfma_f32_flops": (_i64, [_i32, _i32]),
     "dn_ubench_mfma_f32": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "dn_xcd_probe": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     # diagnostic hook (host only)
     "dn_debug_conv_plan": (C.c_int, [_P(ConvDesc), C.c_int, _P(_i32), C.c_int]),
 }

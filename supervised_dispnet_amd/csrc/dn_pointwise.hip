@@ -122,21 +122,24 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __re
                                                                float* shift, long long* num_batches_tracked) {
   const int c = blockIdx.x;
   if (num_batches_tracked != nullptr && c == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;   // nn.BatchNorm2d's step counter
-  // One pass over the partial rows (was two: the sums for the mean, then the M2 merge about it): per row t the pair (s_t, M2_t about the
-  // tile's own mean) is read once and three sums are kept in fp64 -- S = sum s_t, Q = sum M2_t, P = sum s_t^2 / n_t -- from which
-  //   mean = S / N,   M2 = Q + sum_t n_t (s_t / n_t - mean)^2 = Q + P - N mean^2      (Chan et al., expanded).
-  // The expansion is taken in fp64 on TILE-centred second moments, so what cancels is only the between-tile part (a relative 1e-16
-  // of P against a result that is at least Q): nothing like the fp32 E[x^2] - mean^2 this layout was introduced to avoid.
+  // One pass over the partial rows: per row t the pair (s_t, M2_t about the tile's own mean) is read once and three sums are kept in
+  // fp64 -- S = sum s_t, Q = sum M2_t, P = sum n_t (s_t / n_t - pivot)^2 with pivot = the first tile's mean -- from which
+  //   mean = S / N,   M2 = Q + sum_t n_t (m_t - mean)^2 = Q + P - N (mean - pivot)^2      (Chan et al., expanded about the pivot).
+  // About a pivot inside the data's range the two terms that cancel are both of the order of the between-tile spread, so a channel
+  // with |mean| >> std (mean^2 / var ~ 1e10 and beyond) keeps its variance; the expansion about 0 lost it there.
   __shared__ double red[3][4];
   double s1 = 0.0, q = 0.0, pp = 0.0;
+  const double n0 = count < (double)kBnTileRows ? count : (double)kBnTileRows;
+  const double pivot = (double)partial[(long long)c * 2] / n0;
 #pragma unroll 8
   for (int r = threadIdx.x; r < rows; r += kThreads) {      // (8 strided 8-byte loads in flight)
     const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)r * C + c) * 2);
     const double left = count - (double)r * kBnTileRows;
     const double nt = left < (double)kBnTileRows ? left : (double)kBnTileRows;
+    const double dm = (double)v.x / nt - pivot;
     s1 += (double)v.x;
     q += (double)v.y;
-    pp += (double)v.x * (double)v.x / nt;
+    pp += nt * dm * dm;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __re
     const double Q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double P = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
     macc = S / count;
-    m2tot = Q + (P - count * macc * macc);
+    m2tot = Q + (P - count * (macc - pivot) * (macc - pivot));
   }
   if (threadIdx.x == 0) {
     double var = m2tot / count;   // biased; the conv bias shifts the mean only
@@ -1010,7 +1013,9 @@ int dn_bn_bwd_apply_relu(float* da_dy, const float* y, const float* scale, const
   hipStream_t s = as_stream(stream);
   int rc = bn_bwd_sums_to_params(partial, partial_rows, partial_stride, partial_offset, C, dgamma, dbeta, s, "dn_bn_bwd_apply_relu");
   if (rc != DN_OK) return rc;
-  if (C % 4 == 0 && kThreads % (C / 4) == 0 && !knobs().no_bn_hoist)
+  const bool hoisted = C % 4 == 0 && kThreads % (C / 4) == 0 && !knobs().no_bn_hoist;
+  set_last_kernel(hoisted ? "dn::bn_bwd_apply_relu_hoisted_kernel" : "dn::bn_bwd_apply_relu_kernel");
+  if (hoisted)
     DN_LAUNCH(bn_bwd_apply_relu_hoisted_kernel, dim3(ew_blocks((rows * (C / 4) + 3) / 4)), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean,
               invstd, gamma, dgamma, dbeta, (long long)rows, C, (float)(1.0 / (double)rows));
   else

@@ -47,6 +47,14 @@ __global__ void __launch_bounds__(256) ubench_mfma_kernel(float* out, int iters)
   out[(long long)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// one int per block: the XCD (HW_REG_XCC_ID, 0..7) the block was dispatched to, at its linear block index
+__global__ void __launch_bounds__(64) xcd_probe_kernel(int* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const unsigned id = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 15u;
+    out[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = (int)id;
+  }
+}
+
 }  // namespace dn
 
 using namespace dn;
@@ -70,6 +78,12 @@ int dn_ubench_mfma_f32(float* out, int32_t blocks, int32_t iters, dn_stream_t st
   DN_REQUIRE(out && blocks > 0 && iters > 0, DN_ERR_BAD_ARG, "dn_ubench_mfma_f32: bad argument");   // out: blocks * 256 floats
   DN_LAUNCH(ubench_mfma_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), out, iters);
   return check_launch("ubench_mfma_kernel");
+}
+
+int dn_xcd_probe(int32_t* out, int32_t gx, int32_t gy, int32_t gz, dn_stream_t stream) {
+  DN_REQUIRE(out && gx > 0 && gy > 0 && gz > 0 && gy <= 65535 && gz <= 65535, DN_ERR_BAD_ARG, "dn_xcd_probe: bad argument");   // out: gx*gy*gz ints
+  DN_LAUNCH(xcd_probe_kernel, dim3(gx, gy, gz), dim3(64), 0, as_stream(stream), out);
+  return check_launch("xcd_probe_kernel");
 }
 
 }  // extern "C"

@@ -220,13 +220,56 @@ _SPLITK = {}      # (device index, raw stream handle) -> (zeroed workspace, byte
 _SPLITK_BYTES = 80 << 20     # >= 4096 + 256 blocks x 8 splits x 32 KB of partial tiles: the largest workspace any launch asks for (dn_winograd.hip)
 
 
+_XCD_OK = {}      # device index -> bool: blocks with one blockIdx.x share an XCD (what the fence-free K split relies on)
+
+
+def xcd_placement_ok(device):
+    """One-time probe per device: the K-split kernels publish partial tiles to ONE XCD's L2 and rely on every block with the
+    same blockIdx.x (gridDim.x a multiple of 8) running on the same XCD.  HIP promises no placement, so the property is CHECKED on the
+    device in hand -- three grid shapes of the kind the split launches use, on the current stream and, concurrently, on a second one --
+    and the split is simply not offered (results identical, small grids slower) when it does not hold.  DN_SPLITK_TRUST=1 skips the probe."""
+    ok = _XCD_OK.get(device.index)
+    if ok is not None:
+        return ok
+    if os.environ.get("DN_SPLITK_TRUST") == "1":
+        _XCD_OK[device.index] = True
+        return True
+    ok = True
+    try:
+        with torch.cuda.device(device), outside_tape_pool():
+            props = torch.cuda.get_device_properties(device)
+            if "gfx950" not in getattr(props, "gcnArchName", "gfx950") or props.multi_processor_count % 8:
+                ok = False
+            shapes = ((8, 16, 1), (104, 4, 1), (32, 2, 4))
+            side = torch.cuda.Stream(device=device)
+            outs = []
+            for st in (torch.cuda.current_stream(device), side):
+                for gx, gy, gz in shapes:
+                    o = torch.full((gx * gy * gz,), -1, dtype=torch.int32, device=device)
+                    side.wait_stream(torch.cuda.current_stream(device))
+                    _lib.call("dn_xcd_probe", o.data_ptr(), gx, gy, gz, st.cuda_stream)
+                    outs.append((o, gx))
+            torch.cuda.synchronize(device)
+            for o, gx in outs:
+                ids = o.cpu().view(-1, gx)
+                if int(ids.min()) < 0 or int(ids.max()) > 7 or not bool((ids == ids[0:1]).all()):
+                    ok = False
+    except Exception:                                 # noqa: BLE001 -- a probe that cannot run proves nothing: no split
+        ok = False
+    if not ok:
+        import warnings
+        warnings.warn("supervised_dispnet_amd: block -> XCD placement on this device is not blockIdx.x % 8; K split of small grids disabled")
+    _XCD_OK[device.index] = ok
+    return ok
+
+
 def _splitk_workspace(d, device):
     """Attach the K-split workspace to a conv descriptor (small grids: a 4-image shard of the metric's batch); the
     library decides per launch whether it splits (dn_conv_splitk_workspace_bytes).  One zeroed buffer per (device, stream) serves every
     launch of that stream (the counters reset themselves; launches on different streams must not share one); launches on the
     weight-gradient side streams never split.  No torch calls on the hot path: the step makes ~80 of these and is launch-bound at 4
     images."""
-    if not SPLITK or device.type != "cuda":
+    if not SPLITK or device.type != "cuda" or not xcd_placement_ok(device):
         return
     h = _stream()
     cur = _SPLITK.get((device.index, h))
@@ -281,6 +324,8 @@ def hbm_call(kernel, nbytes, entry, *args):
     e0.record()
     _lib.call(entry, *args)
     e1.record()
+    if kernel is None:               # the entry point chooses between kernels: take the symbol it launched (the name rocprofv3 prints)
+        kernel = _lib.load().dn_last_kernel().decode(errors="replace")
     PROFILE.append((kernel, 0, e0, e1, entry, int(nbytes), int(nbytes)))
 
 
@@ -882,6 +927,7 @@ class GradSink:
         if dst is not None:
             if g.data_ptr() != dst.data_ptr():
                 dst.copy_(g.view_as(dst))
+            param._dn_zero_grad_slot = False          # the slice now holds a real gradient: a later "no gradient" must zero it again
             self.grads[id(param)] = None
             if GradSink.reducer is not None:
                 GradSink.reducer.grad_ready(param)
@@ -894,7 +940,7 @@ class GradSink:
         dst = getattr(param, "_dn_grad_view", None)
         if dst is not None:
             if not getattr(param, "_dn_zero_grad_slot", False):
-                dst.zero_()
+                _lib.call("dn_fill", dst.data_ptr(), 0.0, dst.numel(), _stream())      # (this library's fill: visible to a launch tape)
                 param._dn_zero_grad_slot = True
             self.grads[id(param)] = None
             if GradSink.reducer is not None:
@@ -907,6 +953,13 @@ class GradSink:
         an arena slice keeps its zeros and the reducer is told the slot is settled, so its bucket is not held back to the end."""
         if getattr(param, "_dn_grad_view", None) is not None:
             self.put_zero(param)
+
+    def settle(self, params):
+        """End of a backward pass: every arena-backed parameter no block reported a gradient for (a block whose output the loss did not
+        read returns early) is settled as "no gradient" -- its arena slice is zero, not last step's values."""
+        for p in params:
+            if id(p) not in self.grads and getattr(p, "_dn_grad_view", None) is not None and p.requires_grad:
+                self.put_zero(p)
 
     def get(self, param):
         return self.grads.get(id(param))
@@ -952,7 +1005,7 @@ def bn_backward(y, bn, sink, training):
                  dbeta.data_ptr(), _stream())
         y.pool_src = None
     elif relu_pending and not BN_MATERIALIZE_DZ:
-        hbm_call("dn::bn_bwd_apply_relu_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply_relu", g.data_ptr(), y_t.data_ptr(),
+        hbm_call(None, y.rows * Cn * 12, "dn_bn_bwd_apply_relu", g.data_ptr(), y_t.data_ptr(),
                  y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(),
                  y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn, dgamma.data_ptr(),
                  dbeta.data_ptr(), _stream())

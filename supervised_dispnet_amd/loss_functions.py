@@ -6,7 +6,7 @@ raise).  PyTorch only provides the tensors, the stream and the autograd hand-off
 import torch
 
 from . import _lib
-from .engine import _stream, require_cuda
+from .engine import _stream, hbm_call, require_cuda
 
 _MAX_DEPTH = {"kitti": 80.0, "nyu": 10.0}
 
@@ -61,7 +61,7 @@ class _MaskedLoss(torch.autograd.Function):
                           ws.data_ptr(), nbytes, _stream())
                 work.append((gtc, pc, g, pixels, stats, ws, nbytes))
             else:
-                _lib.call("dn_masked_loss_fwd", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, weights[i], 0 if i == 0 else 1,
+                hbm_call("dn::masked_stats_kernel", 8 * g * pixels, "dn_masked_loss_fwd", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, weights[i], 0 if i == 0 else 1,
                           stats.data_ptr(), ws.data_ptr(), nbytes, loss.data_ptr(), _stream())
             saved += [gtc, pc, stats]
             cfg.append((g, pixels, weights[i], pred.shape))
@@ -87,7 +87,7 @@ class _MaskedLoss(torch.autograd.Function):
         for i, (g, pixels, weight, shape) in enumerate(cfg):
             gtc, pc, stats = ctx.saved_tensors[3 * i:3 * i + 3]
             dpred = torch.empty(shape, dtype=torch.float32, device=pc.device)
-            _lib.call("dn_masked_loss_bwd", gtc.data_ptr(), pc.data_ptr(), stats.data_ptr(), dl.data_ptr(), g, pixels, max_depth, kind,
+            hbm_call("dn::masked_loss_bwd_kernel", 12 * g * pixels, "dn_masked_loss_bwd", gtc.data_ptr(), pc.data_ptr(), stats.data_ptr(), dl.data_ptr(), g, pixels, max_depth, kind,
                       weight * up, dpred.data_ptr(), _stream())
             grads.append(dpred)
         return (None, None, None, None, None, None) + tuple(grads)
@@ -259,11 +259,11 @@ class _Photometric(torch.autograd.Function):
                 tgt_s, refs_s = tgt, refs
             else:
                 tgt_s = torch.empty((B, 3, h, w), dtype=torch.float32, device=dev)
-                _lib.call("dn_area_down", tgt.data_ptr(), B * 3, H, W, f, tgt_s.data_ptr(), _stream())
+                hbm_call("dn::area_down_kernel", 12 * B * (H * W + h * w), "dn_area_down", tgt.data_ptr(), B * 3, H, W, f, tgt_s.data_ptr(), _stream())
                 refs_s = []
                 for r in refs:
                     rs = torch.empty((B, 3, h, w), dtype=torch.float32, device=dev)
-                    _lib.call("dn_area_down", r.data_ptr(), B * 3, H, W, f, rs.data_ptr(), _stream())
+                    hbm_call("dn::area_down_kernel", 12 * B * (H * W + h * w), "dn_area_down", r.data_ptr(), B * 3, H, W, f, rs.data_ptr(), _stream())
                     refs_s.append(rs)
             mc = m.contiguous().float() if m is not None else None
             nb = lib.dn_warp_blocks(h, w)
@@ -276,7 +276,7 @@ class _Photometric(torch.autograd.Function):
                 partial = torch.empty(B * nb, dtype=torch.float32, device=dev)
                 mptr = (mc.data_ptr() + 4 * i * h * w) if mc is not None else None
                 msb = mc.shape[1] * h * w if mc is not None else 0
-                _lib.call("dn_photometric_fwd", tgt_s.data_ptr(), rs.data_ptr(), dc.data_ptr(), proj.data_ptr(), kinv_s.data_ptr(),
+                hbm_call("dn::warp_fwd_kernel", 4 * B * h * w * (7 + (1 if mc is not None else 0)), "dn_photometric_fwd", tgt_s.data_ptr(), rs.data_ptr(), dc.data_ptr(), proj.data_ptr(), kinv_s.data_ptr(),
                           mptr, msb, B, h, w, pad, align, 1.0, 0 if first else 1, partial.data_ptr(), loss.data_ptr(), _stream())
                 first = False
                 per_ref.append((rs, proj, kinv_s))
@@ -304,7 +304,7 @@ class _Photometric(torch.autograd.Function):
                 mptr = (mc.data_ptr() + 4 * i * h * w) if mc is not None else None
                 msb = mc.shape[1] * h * w if mc is not None else 0
                 dmptr = (dm.data_ptr() + 4 * i * h * w) if dm is not None else None
-                _lib.call("dn_photometric_bwd", tgt_s.data_ptr(), rs.data_ptr(), dc.data_ptr(), proj.data_ptr(), kinv_s.data_ptr(),
+                hbm_call("dn::warp_bwd_kernel", 4 * B * h * w * (8 + (2 if mc is not None else 0)), "dn_photometric_bwd", tgt_s.data_ptr(), rs.data_ptr(), dc.data_ptr(), proj.data_ptr(), kinv_s.data_ptr(),
                           mptr, msb, B, h, w, pad, align, 1.0, dl.data_ptr(), dd.data_ptr(), 0 if i == 0 else 1, dpp.data_ptr(),
                           dmptr, msb, _stream())
                 _lib.call("dn_pose_proj_bwd", posec.data_ptr() + 4 * 6 * i, 6 * n_ref, K.data_ptr(), B, rot, down, dpp.data_ptr(), nb,
@@ -387,7 +387,7 @@ class _Smooth(torch.autograd.Function):
             b, c, h, wd = mc.shape
             nb = lib.dn_smooth_blocks(b * c, h, wd)
             partial = torch.empty((nb, 4), dtype=torch.float32, device=dev)
-            _lib.call("dn_smooth2_fwd", mc.data_ptr(), b * c, h, wd, w, partial.data_ptr(), loss.data_ptr(), _stream())
+            hbm_call("dn::smooth2_fwd_kernel", 4 * b * c * h * wd, "dn_smooth2_fwd", mc.data_ptr(), b * c, h, wd, w, partial.data_ptr(), loss.data_ptr(), _stream())
             saved.append(mc)
             cfg.append((b * c, h, wd, w))
             w /= weight_decay
@@ -401,7 +401,7 @@ class _Smooth(torch.autograd.Function):
         grads = []
         for mc, (bc, h, wd, w) in zip(ctx.saved_tensors, ctx.cfg):
             g = torch.empty_like(mc)
-            _lib.call("dn_smooth2_bwd", mc.data_ptr(), dl.data_ptr(), bc, h, wd, w, g.data_ptr(), _stream())
+            hbm_call("dn::smooth2_bwd_kernel", 8 * bc * h * wd, "dn_smooth2_bwd", mc.data_ptr(), dl.data_ptr(), bc, h, wd, w, g.data_ptr(), _stream())
             grads.append(g)
         return (None,) + tuple(grads)
 

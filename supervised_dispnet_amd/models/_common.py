@@ -99,6 +99,7 @@ class HipNetFunction(torch.autograd.Function):
                 if g is not None:
                     engine.seed_grad(a, g)
             ctx.tape.run_backward()
+            ctx.sink.settle(ctx.params)
             engine.join_side_stream()
         ig = tuple((a.grad.permute(0, 3, 1, 2) if (a.needs_grad and a.grad is not None) else None) for a in ctx.in_acts)
         pg = tuple(ctx.sink.get(p) for p in ctx.params)

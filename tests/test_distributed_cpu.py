@@ -238,6 +238,21 @@ def test_bench_dry_run_two_ranks_constructs_buckets_and_tears_down():
     assert d["ok"] and d["world"] == 2 and d["buckets"] >= 3 and d["shard"] == [0, 16] and d["arena_params"] == 80
 
 
+def test_bench_spawns_its_own_ranks_when_invoked_plainly():
+    """`python bench.py --gpus 2 --dry-run` with NO launcher and no WORLD_SIZE in the environment (the reference's train.py needs no
+    launcher either, train.py:316-317): bench.py re-executes itself as two ranks under torch.distributed.run on a free port."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["ok"] and d["world"] == 2 and d["shard"] == [0, 16] and d["arena_params"] == 80
+
+
 def _worker_two_communicators(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -230,3 +230,22 @@ def test_two_ranks_through_the_launch_tape_equal_the_eager_two_rank_run(tmp_path
     for lt, le in zip(t0["losses"], e0["losses"]):
         assert lt == pytest.approx(le, rel=1e-5)
     assert torch.allclose(t0["p"], e0["p"], rtol=0, atol=2e-7), float((t0["p"] - e0["p"]).abs().max())
+
+
+def test_bench_plain_gpus_2_spawns_both_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2 ...` with no launcher (what a driver's plain scale run would be): bench.py becomes its own
+    torch.distributed.run launcher; both ranks land on the one GPU (LOCAL_RANK modulo the device count), gloo carries the gradient
+    buckets, rank 0 prints the ONE JSON line with n_gpus 2, the strong-scaling shard (32 / 2 per rank) and config.comm."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DN_DIST_BACKEND="gloo", DN_COMM="torch")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--alt-steps", "0",
+                        "--profile-steps", "0", "--global-batch", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 8
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["comm"] not in (None, "none (one rank)")
+    assert d["value"] > 0 and d["steps"] == 3

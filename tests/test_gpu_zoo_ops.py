@@ -145,3 +145,27 @@ def test_bn_stats_of_a_materialised_tensor(rows, Cn):
     xd = x.double().cpu()
     np.testing.assert_allclose(y.mean.cpu().numpy(), xd.mean(0).numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(y.invstd.cpu().numpy(), (1 / torch.sqrt(xd.var(0, unbiased=False) + bn.eps)).numpy(), rtol=1e-5)
+
+
+def test_bn_finalize_keeps_the_variance_of_a_channel_with_a_large_offset():
+    """|mean| >> std.  The merge of the per-tile (sum, M2) pairs is expanded about the first tile's mean, not about 0, so
+    mean^2 / var = 1e10 (fp32 data: offset 4096, spread 0.04) loses nothing: the finalize step is exact to fp64 rounding on ITS inputs,
+    and what the test compares against is the fp64 statistics of the same fp32 tensor."""
+    torch.manual_seed(11)
+    rows, Cn = 128 * 301 + 17, 8
+    off = torch.tensor([4096.0, -4096.0, 1024.0, 0.0, 3.0e4, 1.0, -512.0, 65536.0], device=DEV)
+    spread = torch.tensor([0.04, 0.04, 0.02, 1.0, 0.5, 1e-3, 0.01, 1.0], device=DEV)
+    drift = torch.linspace(-1, 1, rows, device=DEV).view(rows, 1)                      # tile means differ: the between-tile term is live
+    x = (off + spread * (torch.randn(rows, Cn, device=DEV) + 2.0 * drift)).contiguous()
+    lib = _lib.load()
+    prow = lib.dn_bn_stats_rows(rows)
+    partial = torch.empty((prow, Cn, 2), device=DEV)
+    _lib.call("dn_bn_stats_partial", x.data_ptr(), rows, Cn, partial.data_ptr(), engine._stream())
+    bn = nn.BatchNorm2d(Cn, eps=1e-12).to(DEV)
+    y = engine.Act(x.view(1, rows, 1, Cn), 1, rows, 1, Cn)
+    engine._bn_pending(y, bn, partial, prow, True)
+    torch.cuda.synchronize()
+    xd = x.double().cpu()
+    var = xd.var(0, unbiased=False)
+    np.testing.assert_allclose(y.mean.cpu().numpy(), xd.mean(0).numpy(), rtol=5e-7)
+    np.testing.assert_allclose(y.invstd.cpu().numpy(), (1 / torch.sqrt(var + bn.eps)).numpy(), rtol=2e-3)   # (the tiles' own fp32 sums bound this)
