@@ -2101,7 +2101,9 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     p.compute = wl == 2 ? DN_COMPUTE_BF16 : (wl == 3 ? DN_COMPUTE_F32X3 : DN_COMPUTE_F32);
     return launch_wino_conv(p, s);
   }
+  if (stem3_conv_eligible(d, p)) return launch_stem3_conv(p, s);
   if (stem_eligible(d, p)) return launch_stem(p, s);
+  if (lds3_conv_eligible(d, p)) return launch_lds3_conv(d, p, s);
   if (thin_conv_eligible(d, p)) return launch_thin_conv(p, s);
   // Few row tiles (the 4x13 / 8x26 decoder levels at b32: 13-52 tiles of 128 rows) leave most of the 256 CUs without a block;
   // 64-row tiles double the block count at the same per-wave MFMA density along N.  Not with batch statistics: the

@@ -211,4 +211,10 @@ int launch_thin_wgrad(IgemmParams& p, float* dw, hipStream_t stream);
 bool thin_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_thin_conv(const IgemmParams& p, hipStream_t stream);
 
+// dn_lds3.hip: LDS-resident three-piece direct convolutions of the thin full-resolution decoder layers (iconv0 / upconv0 forward + input gradient)
+bool lds3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
+int launch_lds3_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t stream);
+bool stem3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
+int launch_stem3_conv(const IgemmParams& p, hipStream_t stream);
+
 }  // namespace dn

@@ -283,11 +283,24 @@ __global__ void __launch_bounds__(256) neglog_sum_kernel(const float* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
 }
 
-__global__ void mean_finalize_kernel(const float* __restrict__ partial, int blocks, double count, float weight, int accumulate,
-                                     float* __restrict__ loss) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// fixed-order fp64 sum of n strided floats by one block of 256 threads (see dn_warp.hip: the single-thread loops took 50-110 us)
+template <int STRIDE>
+__device__ __forceinline__ double loss_block_sum_f64(const float* __restrict__ v, int n, int offset, double* lds4) {
   double s = 0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[b];
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[(long long)i * STRIDE + offset];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+__global__ void __launch_bounds__(256) mean_finalize_kernel(const float* __restrict__ partial, int blocks, double count, float weight,
+                                                            int accumulate, float* __restrict__ loss) {
+  __shared__ double lds4[4];
+  const double s = loss_block_sum_f64<1>(partial, blocks, 0, lds4);
+  if (threadIdx.x != 0) return;
   const float v = (float)(s / count) * weight;
   loss[0] = accumulate ? loss[0] + v : v;
 }
@@ -329,12 +342,13 @@ __global__ void __launch_bounds__(256) smooth2_fwd_kernel(const float* __restric
     for (int k = 0; k < 4; ++k) partial[blockIdx.x * 4 + k] = acc[k];
 }
 
-__global__ void smooth2_finalize_kernel(const float* __restrict__ partial, int blocks, int B, int H, int W, float weight,
-                                        float* __restrict__ loss) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s[4] = {0, 0, 0, 0};
-  for (int b = 0; b < blocks; ++b)
-    for (int k = 0; k < 4; ++k) s[k] += (double)partial[b * 4 + k];
+__global__ void __launch_bounds__(256) smooth2_finalize_kernel(const float* __restrict__ partial, int blocks, int B, int H, int W, float weight,
+                                                               float* __restrict__ loss) {
+  __shared__ double lds4[4];
+  double s[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] = loss_block_sum_f64<4>(partial, blocks, k, lds4);
+  if (threadIdx.x != 0) return;
   const double n0 = (double)B * H * (W - 2), n1 = (double)B * (H - 1) * (W - 1), n3 = (double)B * (H - 2) * W;
   const float v = (float)(s[0] / n0) + (float)(s[1] / n1) + (float)(s[2] / n1) + (float)(s[3] / n3);
   loss[0] += v * weight;
@@ -594,7 +608,7 @@ int dn_explainability_fwd(const float* mask, int64_t n, float weight, int32_t ac
   hipStream_t s = as_stream(stream);
   const int blocks = dn_reduce1d_blocks(n);
   DN_LAUNCH(neglog_sum_kernel, dim3(blocks), dim3(256), 0, s, mask, (long long)n, partial);
-  DN_LAUNCH(mean_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, (double)n, weight, accumulate, loss);
+  DN_LAUNCH(mean_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, (double)n, weight, accumulate, loss);
   return check_launch("explainability_fwd");
 }
 
@@ -611,7 +625,7 @@ int dn_smooth2_fwd(const float* map, int32_t B, int32_t H, int32_t W, float weig
   hipStream_t s = as_stream(stream);
   const int blocks = smooth_blocks(B, H, W);
   DN_LAUNCH(smooth2_fwd_kernel, dim3(blocks), dim3(256), 0, s, map, B, H, W, partial);
-  DN_LAUNCH(smooth2_finalize_kernel, dim3(1), dim3(64), 0, s, partial, blocks, B, H, W, weight, loss);
+  DN_LAUNCH(smooth2_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, B, H, W, weight, loss);
   return check_launch("smooth2_fwd");
 }
 

@@ -92,10 +92,19 @@ __global__ void __launch_bounds__(256) ordinal_loss_fwd_kernel(const float* __re
 }
 
 // stats = (sum, num_valid); loss = sum / (-num_valid)
-__global__ void ordinal_loss_finalize_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ stats, float* __restrict__ loss) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(256) ordinal_loss_finalize_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ stats,
+                                                                    float* __restrict__ loss) {
+  // fixed-order fp64 sums by 256 threads (the single-thread loop took tens of microseconds on the critical queue)
+  __shared__ double lds[8];
   double s = 0, c = 0;
-  for (int k = 0; k < blocks; ++k) { s += (double)partial[k * 2]; c += (double)partial[k * 2 + 1]; }
+  for (int k = threadIdx.x; k < blocks; k += 256) { s += (double)partial[k * 2]; c += (double)partial[k * 2 + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); c += __shfl_xor(c, o); }
+  if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = s; lds[4 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  c = (lds[4] + lds[5]) + (lds[6] + lds[7]);
   stats[0] = (float)s;
   stats[1] = (float)c;
   loss[0] = (float)s / (-(float)c);
@@ -201,7 +210,7 @@ int dn_ordinal_loss_fwd(const float* ord, const float* gt, const int32_t* target
   hipStream_t s = as_stream(stream);
   const int nb = dn_ordinal_loss_blocks(N, HW);
   DN_LAUNCH(ordinal_loss_fwd_kernel, dim3(nb), dim3(256), 0, s, ord, gt, target, N, (long long)HW, K, max_depth, partial);
-  DN_LAUNCH(ordinal_loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, stats, loss);
+  DN_LAUNCH(ordinal_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nb, stats, loss);
   return check_launch("ordinal_loss_fwd");
 }
 

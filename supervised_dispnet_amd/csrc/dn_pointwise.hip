@@ -893,8 +893,19 @@ __global__ void adam_tick_kernel(int* __restrict__ step, const double* __restric
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int t = step[0] + 1;
   step[0] = t;
-  const double bc1 = 1.0 - pow(hyper[1], (double)t);
-  const double bc2 = 1.0 - pow(hyper[2], (double)t);
+  // beta^t by repeated squaring (<= 31 dependent multiplies; within an ulp or two of pow() in fp64, i.e. far below the fp32 the
+  // corrections are handed on in): the device library's double pow() made this one-thread kernel take 115 us on the critical queue
+  auto ipow = [](double b, int e) {
+    double r = 1.0;
+    while (e > 0) {
+      if (e & 1) r *= b;
+      b *= b;
+      e >>= 1;
+    }
+    return r;
+  };
+  const double bc1 = 1.0 - ipow(hyper[1], t);
+  const double bc2 = 1.0 - ipow(hyper[2], t);
   derived[0] = (float)(hyper[0] / bc1);
   derived[1] = (float)sqrt(bc2);
   derived[2] = (float)hyper[1];

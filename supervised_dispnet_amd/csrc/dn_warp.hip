@@ -244,11 +244,27 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(const WarpArgs a, float* 
   }
 }
 
-// loss[0] (+)= weight * sum(partial) / count
-__global__ void sum_finalize_kernel(const float* __restrict__ partial, int n, double count, float weight, int accumulate, float* __restrict__ loss) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Fixed-order fp64 sum of n floats by one block of 256 threads (thread t takes elements t, t + 256, ...; then a shuffle tree and four
+// wave totals added in index order): the single-thread loop this replaces walked up to 6656 dependent loads (53-112 us per launch,
+// 0.42 ms of a photometric step -- profiles/r04_a_photo128_kernel_stats.csv).  Result valid in thread 0.
+template <int STRIDE>
+__device__ __forceinline__ double block_sum_f64(const float* __restrict__ v, int n, int offset, double* lds4) {
   double s = 0;
-  for (int i = 0; i < n; ++i) s += (double)partial[i];
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[(long long)i * STRIDE + offset];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// loss[0] (+)= weight * sum(partial) / count
+__global__ void __launch_bounds__(256) sum_finalize_kernel(const float* __restrict__ partial, int n, double count, float weight, int accumulate,
+                                                           float* __restrict__ loss) {
+  __shared__ double lds4[4];
+  const double s = block_sum_f64<1>(partial, n, 0, lds4);
+  if (threadIdx.x != 0) return;
   const float v = (float)(s / count) * weight;
   loss[0] = accumulate ? loss[0] + v : v;
 }
@@ -464,10 +480,12 @@ __global__ void __launch_bounds__(256) edge_smooth_fwd_kernel(const float* __res
   block_sum256<2>(acc, lds, partial + blockIdx.x * 2);
 }
 
-__global__ void edge_smooth_finalize_kernel(const float* __restrict__ partial, int blocks, int B, int H, int W, float* __restrict__ loss) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double sx = 0, sy = 0;
-  for (int k = 0; k < blocks; ++k) { sx += (double)partial[k * 2]; sy += (double)partial[k * 2 + 1]; }
+__global__ void __launch_bounds__(256) edge_smooth_finalize_kernel(const float* __restrict__ partial, int blocks, int B, int H, int W,
+                                                                   float* __restrict__ loss) {
+  __shared__ double lds4[4];
+  const double sx = block_sum_f64<2>(partial, blocks, 0, lds4);
+  const double sy = block_sum_f64<2>(partial, blocks, 1, lds4);
+  if (threadIdx.x != 0) return;
   loss[0] = (float)(sx / ((double)B * H * (W - 1))) + (float)(sy / ((double)B * (H - 1) * W));
 }
 
@@ -572,7 +590,7 @@ int dn_photometric_fwd(const float* tgt, const float* ref, const float* depth, c
   hipStream_t s = as_stream(stream);
   const int nb = warp_blocks(h, w);
   DN_LAUNCH(warp_fwd_kernel, dim3(nb, B), dim3(256), 0, s, a, (float*)nullptr, partial);
-  DN_LAUNCH(sum_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb * B, (double)B * 3 * h * w, weight, accumulate, loss);
+  DN_LAUNCH(sum_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nb * B, (double)B * 3 * h * w, weight, accumulate, loss);
   return check_launch("photometric_fwd");
 }
 
@@ -621,7 +639,7 @@ int dn_edge_smooth_fwd(const float* disp, const float* img, int32_t B, int32_t C
   hipStream_t s = as_stream(stream);
   const int nb = ew_blocks((long long)B * H * W, 1024);
   DN_LAUNCH(edge_smooth_fwd_kernel, dim3(nb), dim3(256), 0, s, disp, img, B, C, H, W, partial);
-  DN_LAUNCH(edge_smooth_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nb, B, H, W, loss);
+  DN_LAUNCH(edge_smooth_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nb, B, H, W, loss);
   return check_launch("edge_smooth_fwd");
 }
 

@@ -76,6 +76,8 @@ CONV_CASES = [
     ("3x3_wino_iconv1",   (32, 64, 1),  (False, False, True), 32, 3, 1, 1, False, 0, 2, 64, 208, ACT_LEAKY, False),
     ("3x3_cat_193",       (64, 128, 1), (False, False, True), 64, 3, 1, 1, False, 0, 2, 8, 12, ACT_LEAKY, False),
     ("3x3_cat_17",        (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 1, 16, 24, ACT_LEAKY, False),
+    ("3x3_cat_17_tiles",  (16, 1),      (False, True),     16, 3, 1, 1, False, 0, 3, 20, 70, ACT_LEAKY, False),   # lds3: several ragged 8x32 tiles
+    ("3x3_16_16_tiles",   (16,),        (False,),          16, 3, 1, 1, False, 0, 2, 24, 40, ACT_RELU, False),
     ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
     ("3x3_head_16",       (16,),        (False,),          1, 3, 1, 1, False, 0, 3, 17, 23, ACT_SIGMOID_AFFINE, False),
     ("3x3_head_128",      (128,),       (False,),          1, 3, 1, 1, False, 0, 2, 5, 9, ACT_SIGMOID_AFFINE, False),
@@ -87,6 +89,8 @@ CONV_CASES = [
     ("3x3_elu",           (16,),        (False,),          16, 3, 1, 1, False, 0, 1, 8, 8, ACT_ELU, False),
     ("convT_k4s2p1",      (64,),        (False,),          32, 4, 2, 1, True, 0, 2, 6, 10, ACT_LEAKY, False),
     ("convT_k4s2p1_big",  (512,),       (False,),          256, 4, 2, 1, True, 0, 2, 4, 13, ACT_LEAKY, False),
+    ("convT_k4s2p1_32_16", (32,),       (False,),          16, 4, 2, 1, True, 0, 2, 9, 21, ACT_LEAKY, False),     # lds3: upconv0 (four phases / stride-2 gather)
+    ("convT_k4s2p1_32_16_tiles", (32,), (False,),          16, 4, 2, 1, True, 0, 3, 20, 70, ACT_LEAKY, False),
     ("convT_k3s2p1op1",   (32,),        (False,),          16, 3, 2, 1, True, 1, 2, 5, 7, ACT_RELU, False),
 ]
 

@@ -5,7 +5,7 @@
 tag=${1:-r04_a}
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
-  python -m pytest tests -q -m gpu -x > gpurun_out/tests_$tag.log 2>&1; tail -3 gpurun_out/tests_$tag.log
+  python -m pytest tests -q -m gpu > gpurun_out/tests_$tag.log 2>&1; tail -3 gpurun_out/tests_$tag.log
 fi
 bash tools/pmc_traffic.sh $tag
 bash tools/gpu_round.sh $tag
