@@ -2268,6 +2268,41 @@ static bool wgrad_split_plans(const dn_conv_desc* fwd, dn_conv_desc* d1, dn_conv
   return true;
 }
 
+// Kernels of more than 32 taps (the 7x7 / stride-2 first layers of ResNet-50 and PoseExpNet: reference models/Disp_res_50.py:65,141,
+// models/PoseExpNet.py:28): the scheduled weight-gradient kernels carry one validity bit per tap in a 32-bit word, so such layers fell to
+// the unscheduled kernel (1.30 ms at 18 TFLOP/s in config 4, 0.57 ms in config 3).  The taps are independent columns of dW, so the
+// gradient is taken as two launches over tap WINDOWS of <= 32 taps each, every one with the full plan's operands and its own rows of the
+// tap tables; the split sum of each window writes only its own (r, s) entries of dw.
+static int tap_windows(const IgemmParams& p) {
+  const int nt = p.ph[0].ntaps;
+  if (nt <= 32 || p.reflect || p.nphases != 1 || getenv("DN_NO_TAP_WINDOWS") != nullptr) return 1;
+  return (nt + 31) / 32;
+}
+
+static void tap_window_plan(const IgemmParams& full, int w, int nw, IgemmParams* q) {
+  *q = full;
+  const int nt = full.ph[0].ntaps, per = (nt + nw - 1) / nw;
+  const int t0 = w * per, t1 = t0 + per < nt ? t0 + per : nt;
+  for (int t = t0; t < t1; ++t) {
+    q->tdy[t - t0] = full.tdy[full.ph[0].tap0 + t];
+    q->tdx[t - t0] = full.tdx[full.ph[0].tap0 + t];
+    q->tr[t - t0] = full.tr[full.ph[0].tap0 + t];
+    q->ts[t - t0] = full.ts[full.ph[0].tap0 + t];
+  }
+  q->ph[0].tap0 = 0;
+  q->ph[0].ntaps = t1 - t0;
+  int nch = 0;
+  for (int i = 0; i < q->n_in; ++i) nch += (q->ph[0].ntaps * q->in[i].C + kChunk - 1) / kChunk;
+  q->ph[0].nchunks = nch;
+  q->uni32 = 1;
+  q->wg_uniform = 1;
+  for (int i = 0; i < q->n_in; ++i) {
+    const KOperand& o = q->in[i];
+    if (!o.small) q->uni32 = 0;
+    if (!o.small || (!o.vec && o.scale != nullptr) || o.C >= 32768) q->wg_uniform = 0;
+  }
+}
+
 extern "C" {
 
 int64_t dn_pack_entry_bytes(void) { return (int64_t)sizeof(PackEntry); }
@@ -2348,6 +2383,14 @@ size_t dn_conv_wgrad_workspace_bytes(const dn_conv_desc* fwd) {
     size_t w1 = 0, w2 = 0;
     if (wgrad_split_plans(fwd, &d1, &d2, &p1, &p2, &w1, &w2) && w1 + w2 > need) need = w1 + w2;
   }
+  const int nw = tap_windows(p);
+  for (int w = 0; w < nw && nw > 1; ++w) {
+    IgemmParams q;
+    tap_window_plan(p, w, nw, &q);
+    choose_splits(&q);
+    const size_t wneed = (size_t)q.splits * q.Npad * q.ph[0].nchunks * kChunk * sizeof(float);
+    if (wneed > need) need = wneed;
+  }
   return need;
 }
 
@@ -2386,6 +2429,15 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
       if (rc != DN_OK) return rc;
       return generic_wgrad(&d2, p2, dy, dw, reinterpret_cast<char*>(workspace) + w1, w2, as_stream(stream));
     }
+  }
+  if (const int nw = tap_windows(p); nw > 1 && fwd->kind == DN_CONV_FWD) {
+    for (int w = 0; w < nw; ++w) {
+      IgemmParams q;
+      tap_window_plan(p, w, nw, &q);
+      rc = generic_wgrad(fwd, q, dy, dw, workspace, workspace_bytes, as_stream(stream));
+      if (rc != DN_OK) return rc;
+    }
+    return DN_OK;
   }
   return generic_wgrad(fwd, p, dy, dw, workspace, workspace_bytes, as_stream(stream));
 }

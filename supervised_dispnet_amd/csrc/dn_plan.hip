@@ -124,6 +124,8 @@ static void read_knobs(Knobs* k) {
   k->no_bn_sums_fusion = on("DN_NO_BN_SUMS_FUSION");
   k->pack_blocks = num("DN_PACK_BLOCKS", 512);
   if (k->pack_blocks < 1) k->pack_blocks = 1;
+  k->wino_min_n = num("DN_WINO_MIN_N", 64);
+  k->wino_pad_pct = num("DN_WINO_PAD_PCT", 60);
   k->wino8 = num("DN_WINO8", -1);
   k->wino8_min_k = num("DN_WINO8_MIN_K", 128);
 }

@@ -46,13 +46,13 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
   if (p.nphases != 1 || p.ph[0].ntaps != 9) return false;
-  if (p.Ntot < 64) return false;
+  if (p.Ntot < knobs().wino_min_n) return false;
   if ((long long)p.M * 4 >= (1ll << 31)) return false;
   {
     // a block always computes 64 tiles x 64 output channels: not worth it (and not better than the direct kernel's 64-row tiles)
     // when padding eats the 2.25x, e.g. the 12-tile deep layers of a 64x96 test image
     const long long T = p.M / 4, Tpad = (T + 31) / 32 * 32, Npad = (p.Ntot + WBN - 1) / WBN * WBN;
-    if (T * p.Ntot * 10 < Tpad * Npad * 6) return false;
+    if (T * p.Ntot * 100 < Tpad * Npad * knobs().wino_pad_pct) return false;
     // Few tiles: F(2x2,3x3) rounds 2-3x coarser than the direct FMA chain (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64),
     // which the BatchNorm of a tiny map (batch statistics over a few dozen values) amplifies: such maps keep the direct kernel.
     // The floor is 192 tiles so that the 8x26 levels of a 4-image shard (208 tiles: BASELINE's b32 split over 8 GPUs) stay on
