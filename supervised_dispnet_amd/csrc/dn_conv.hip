@@ -2188,6 +2188,14 @@ static void choose_splits(IgemmParams* p) {
   p->splits = (p->M + per - 1) / per;
 }
 
+int launch_wgrad_reduce(const IgemmParams& p, float* dw, hipStream_t stream) {
+  const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 8192) blocks = 8192;
+  DN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, dw);
+  return check_launch("wgrad_reduce_kernel");
+}
+
 }  // namespace dn
 
 using namespace dn;
@@ -2377,6 +2385,7 @@ size_t dn_conv_wgrad_workspace_bytes(const dn_conv_desc* fwd) {
   if (head_wgrad_eligible(fwd, p) && head_wgrad_workspace_bytes(p) > need) need = head_wgrad_workspace_bytes(p);
   if (wino_wgrad_eligible(fwd, p) && wino_wgrad_workspace_bytes(p) > need) need = wino_wgrad_workspace_bytes(p);
   if (thin_wgrad_eligible(fwd, p) && thin_wgrad_workspace_bytes(p) > need) need = thin_wgrad_workspace_bytes(p);
+  if (lds3_wgrad_eligible(fwd, p) && lds3_wgrad_workspace_bytes(p) > need) need = lds3_wgrad_workspace_bytes(p);
   {
     dn_conv_desc d1, d2;
     IgemmParams p1, p2;
@@ -2410,6 +2419,12 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     p.g = dy;
     p.ws = reinterpret_cast<float*>(workspace);
     return launch_wino_wgrad(p, dw, as_stream(stream));
+  }
+  if (lds3_wgrad_eligible(fwd, p) && workspace_bytes >= lds3_wgrad_workspace_bytes(p) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+    for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
+    p.g = dy;
+    p.ws = reinterpret_cast<float*>(workspace);
+    return launch_lds3_wgrad(fwd, p, dw, as_stream(stream));
   }
   if (thin_wgrad_eligible(fwd, p) && workspace_bytes >= thin_wgrad_workspace_bytes(p)) {
     for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);

@@ -215,6 +215,11 @@ int launch_thin_conv(const IgemmParams& p, hipStream_t stream);
 // dn_lds3.hip: LDS-resident three-piece direct convolutions of the thin full-resolution decoder layers (iconv0 / upconv0 forward + input gradient)
 bool lds3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_lds3_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t stream);
+// dn_lds3_wgrad.hip: weight gradients of iconv0 (16 [+ 1] -> 16) and the first encoder layer (<= 3 -> 64) from channel-planar LDS tiles
+bool lds3_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
+size_t lds3_wgrad_workspace_bytes(const IgemmParams& p);
+int launch_lds3_wgrad(const dn_conv_desc* fwd, IgemmParams& p, float* dw, hipStream_t stream);
+int launch_wgrad_reduce(const IgemmParams& p, float* dw, hipStream_t stream);   // dn_conv.hip: fixed-order sum of p.splits slabs of p.ws -> dw
 bool stem3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_stem3_conv(const IgemmParams& p, hipStream_t stream);
 

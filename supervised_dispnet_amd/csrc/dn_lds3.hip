@@ -160,65 +160,72 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
   // XCD-aware tile walk: blocks b, b + 8, ... share an XCD (observed placement; only speed depends on it) and walk one contiguous band
   const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
   const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
+  // The global loads of tile t + 1 are issued before tile t is computed and land in registers under its matrix instructions; split +
+  // LDS writes follow the compute phase (one barrier each side).  Without the prefetch a block sat through a full memory latency per tile.
+  constexpr int ITEMS = ROWS * COLS * CG, ROUNDS = (ITEMS + 255) / 256;
+  f32x4 va[ROUNDS], vb[ROUNDS];
+  float dv[2] = {0.f, 0.f};
+  auto issue_loads = [&](int t) __attribute__((always_inline)) {
+    const int txb = t % geo.tilesX, r1 = t / geo.tilesX;
+    const int tyb = r1 % geo.tilesY, n = r1 / geo.tilesY;
+    const int iy0 = tyb * TH * STRIDE + geo.dy0, ix0 = txb * TW * STRIDE + geo.dx0;
+    const int nbase = n * (int)S.sn;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = tid + 256 * r;
+      const int cg = it % CG, px = it / CG;
+      const int row = px / COLS, col = px - row * COLS;
+      const int iy = iy0 + row, ix = ix0 + col;
+      const bool ok = it < ITEMS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const int off = (nbase + iy * (int)S.sh + ix * (int)S.sw + 8 * cg) * 4;
+      va[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : -1, 0, 0));
+      vb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off + 16 : -1, 0, 0));
+    }
+    if constexpr (HAS1) {
+      const KOperand& S1 = p.in[1];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int it = tid + 256 * r;
+        const int row = it / COLS, col = it - row * COLS;
+        const int iy = iy0 + row, ix = ix0 + col;
+        const bool ok = it < ROWS * COLS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int off = (n * (int)S1.sn + (iy >> S1.up) * (int)S1.sh + (ix >> S1.up) * (int)S1.sw) * 4;
+        dv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc1, ok ? off : -1, 0, 0));
+      }
+    }
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = tid + 256 * r;
+      if (it < ITEMS) {
+        const int cg = it % CG, px = it / CG;
+        const int row = px / COLS, col = px - row * COLS;
+        const int idx = STRIDE == 2 ? ((col & 1) * Cfg::HALFC + (col >> 1)) : col;
+        const float v[8] = {va[r][0], va[r][1], va[r][2], va[r][3], vb[r][0], vb[r][1], vb[r][2], vb[r][3]};
+        bf16x8 h, m, l;
+        split3(v, h, m, l);
+        char* dst = lds + cg * Cfg::CGSTRIDE + (row * Cfg::COLSP + idx) * 16;
+        *reinterpret_cast<bf16x8*>(dst) = h;
+        *reinterpret_cast<bf16x8*>(dst + Cfg::PSTRIDE) = m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * Cfg::PSTRIDE) = l;
+      }
+    }
+    if constexpr (HAS1) {
+      float* dpl = reinterpret_cast<float*>(lds + 3 * Cfg::PSTRIDE);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (tid + 256 * r < ROWS * COLS) dpl[tid + 256 * r] = dv[r];
+    }
+  };
+  if (band_lo + local < band_hi) issue_loads(band_lo + local);
   for (int t = band_lo + local; t < band_hi; t += nlocal) {
     const int txb = t % geo.tilesX, r1 = t / geo.tilesX;
     const int tyb = r1 % geo.tilesY, n = r1 / geo.tilesY;
     const int gy0 = tyb * TH, gx0 = txb * TW;
-    const int iy0 = gy0 * STRIDE + geo.dy0, ix0 = gx0 * STRIDE + geo.dx0;
-
-    // ---- stage the input tile: global -> three bf16 pieces -> LDS planes
-    {
-      constexpr int ITEMS = ROWS * COLS * CG, ROUNDS = (ITEMS + 255) / 256;
-      f32x4 va[ROUNDS], vb[ROUNDS];
-      const int nbase = n * (int)S.sn;
-#pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int it = tid + 256 * r;
-        const int cg = it % CG, px = it / CG;
-        const int row = px / COLS, col = px - row * COLS;
-        const int iy = iy0 + row, ix = ix0 + col;
-        const bool ok = it < ITEMS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-        const int off = (nbase + iy * (int)S.sh + ix * (int)S.sw + 8 * cg) * 4;
-        va[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : -1, 0, 0));
-        vb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off + 16 : -1, 0, 0));
-      }
-      float dv[2] = {0.f, 0.f};
-      if constexpr (HAS1) {
-        const KOperand& S1 = p.in[1];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int it = tid + 256 * r;
-          const int row = it / COLS, col = it - row * COLS;
-          const int iy = iy0 + row, ix = ix0 + col;
-          const bool ok = it < ROWS * COLS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-          const int off = (n * (int)S1.sn + (iy >> S1.up) * (int)S1.sh + (ix >> S1.up) * (int)S1.sw) * 4;
-          dv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc1, ok ? off : -1, 0, 0));
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int it = tid + 256 * r;
-        if (it < ITEMS) {
-          const int cg = it % CG, px = it / CG;
-          const int row = px / COLS, col = px - row * COLS;
-          const int idx = STRIDE == 2 ? ((col & 1) * Cfg::HALFC + (col >> 1)) : col;
-          const float v[8] = {va[r][0], va[r][1], va[r][2], va[r][3], vb[r][0], vb[r][1], vb[r][2], vb[r][3]};
-          bf16x8 h, m, l;
-          split3(v, h, m, l);
-          char* dst = lds + cg * Cfg::CGSTRIDE + (row * Cfg::COLSP + idx) * 16;
-          *reinterpret_cast<bf16x8*>(dst) = h;
-          *reinterpret_cast<bf16x8*>(dst + Cfg::PSTRIDE) = m;
-          *reinterpret_cast<bf16x8*>(dst + 2 * Cfg::PSTRIDE) = l;
-        }
-      }
-      if constexpr (HAS1) {
-        float* dpl = reinterpret_cast<float*>(lds + 3 * Cfg::PSTRIDE);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-          if (tid + 256 * r < ROWS * COLS) dpl[tid + 256 * r] = dv[r];
-      }
-    }
+    store_lds();
     __syncthreads();
+    if (t + nlocal < band_hi) issue_loads(t + nlocal);
 
     // ---- the wave's pixel tiles, two at a time (independent accumulators)
 #pragma unroll 1
@@ -308,9 +315,9 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
 // Same scheme as above with K = 9 * C <= 27 padded to ONE 32-wide K-step: the 18 x 34 x C input tile sits in LDS as fp32 planes, a lane
 // gathers the eight K values of its slot for a 16-pixel tile (8 ds_read_b32), splits them in registers, and 4 M tiles x 6 partial products
 // produce 64 output channels of 16 pixels; lane (j, g) then holds channels 16 m + 4 g .. + 3 of pixel j: four float4 stores.  A wave owns
-// 4 rows x 32 columns = 128 pixels = one row of the BatchNorm partial-statistics table (sum, M2 about the tile mean; dn_bn_finalize):
-// taken in one pass about a pivot (the first pixel's value), reduced over the 16 pixel lanes with row-rotate DPP adds -- no block barrier
-// between staging and the next tile.
+// 2 rows x 32 columns = 64 pixels; two waves make one 128-pixel row of the BatchNorm partial-statistics table (sum, M2 about the tile
+// mean; dn_bn_finalize): taken in one pass about a pivot (the wave's first pixel), reduced over the 16 pixel lanes with row-rotate DPP
+// adds, the two halves merged through LDS (Chan).  8 x 32 tiles: 6656 of them at 32 x 128 x 416 = 13 per resident block, no tail.
 template <int ROT>
 __device__ __forceinline__ float dpp_row_ror(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROT, 0xf, 0xf, false));
@@ -323,10 +330,11 @@ __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 la
   return v;
 }
 
-constexpr int STEM_TH = 16, STEM_TW = 32, STEM_ROWS = 18, STEM_COLS = 34, STEM_COLSP = 36, STEM_PLANE = STEM_ROWS * STEM_COLSP;
+constexpr int STEM_TH = 8, STEM_TW = 32, STEM_ROWS = 10, STEM_COLS = 34, STEM_COLSP = 36, STEM_PLANE = STEM_ROWS * STEM_COLSP;
 
 __global__ void __launch_bounds__(256, 2) stem3_conv_kernel(const IgemmParams p, const Lds3Geo geo) {
   __shared__ float pl[3 * STEM_PLANE];
+  __shared__ __align__(16) float wstat[4][64][2];       // per wave: (sum, M2 about the wave's mean) of its 64 pixels, per channel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const KOperand& S = p.in[0];
@@ -362,44 +370,47 @@ __global__ void __launch_bounds__(256, 2) stem3_conv_kernel(const IgemmParams p,
 
   const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
   const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
+  constexpr int PIX = STEM_ROWS * STEM_COLS, ROUNDS = (3 * PIX + 255) / 256;
+  float stg[ROUNDS];
+  auto issue_loads = [&](int t) __attribute__((always_inline)) {       // the image tile of tile t (zero halo) -> registers
+    const int txb = t % geo.tilesX, r1 = t / geo.tilesX;
+    const int tyb = r1 % geo.tilesY, n = r1 / geo.tilesY;
+    const int iy0 = tyb * STEM_TH + geo.dy0, ix0 = txb * STEM_TW + geo.dx0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = tid + 256 * r;
+      const int c = it / PIX, px = it - c * PIX;
+      const int row = px / STEM_COLS, col = px - row * STEM_COLS;
+      const int iy = iy0 + row, ix = ix0 + col;
+      const bool ok = c < C && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const int off = (n * (int)S.sn + iy * (int)S.sh + ix * (int)S.sw + c * (int)S.sc) * 4;
+      stg[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? off : -1, 0, 0));
+    }
+  };
+  if (band_lo + local < band_hi) issue_loads(band_lo + local);
   for (int t = band_lo + local; t < band_hi; t += nlocal) {
     const int txb = t % geo.tilesX, r1 = t / geo.tilesX;
     const int tyb = r1 % geo.tilesY, n = r1 / geo.tilesY;
     const int gy0 = tyb * STEM_TH, gx0 = txb * STEM_TW;
-    const int iy0 = gy0 + geo.dy0, ix0 = gx0 + geo.dx0;
-    // ---- stage the image tile (fp32 planes, zero halo)
-    {
-      constexpr int PIX = STEM_ROWS * STEM_COLS, ROUNDS = (3 * PIX + 255) / 256;
-      float v[ROUNDS];
 #pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int it = tid + 256 * r;
-        const int c = it / PIX, px = it - c * PIX;
-        const int row = px / STEM_COLS, col = px - row * STEM_COLS;
-        const int iy = iy0 + row, ix = ix0 + col;
-        const bool ok = c < C && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-        const int off = (n * (int)S.sn + iy * (int)S.sh + ix * (int)S.sw + c * (int)S.sc) * 4;
-        v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? off : -1, 0, 0));
-      }
-#pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int it = tid + 256 * r;
-        const int c = it / PIX, px = it - c * PIX;
-        const int row = px / STEM_COLS, col = px - row * STEM_COLS;
-        if (c < 3) pl[c * STEM_PLANE + row * STEM_COLSP + col] = v[r];
-      }
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = tid + 256 * r;
+      const int c = it / PIX, px = it - c * PIX;
+      const int row = px / STEM_COLS, col = px - row * STEM_COLS;
+      if (c < 3) pl[c * STEM_PLANE + row * STEM_COLSP + col] = stg[r];
     }
     __syncthreads();
+    if (t + nlocal < band_hi) issue_loads(t + nlocal);      // lands under this tile's matrix instructions
 
     float sv[4][4], qv[4][4], pv[4][4];
 #pragma unroll 1
-    for (int i = 0; i < 8; i += 2) {
+    for (int i = 0; i < 4; i += 2) {                        // the wave's rows 2 * wave, 2 * wave + 1: two 16-pixel tiles each
       f32x4 acc[2][4];
       bf16x8 b[2][3];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int pt = i + u;                                  // wave's rows 4 * wave .. + 3, two 16-pixel tiles per row
-        const int ty = 4 * wave + (pt >> 1), tx16 = pt & 1;
+        const int pt = i + u;
+        const int ty = 2 * wave + (pt >> 1), tx16 = pt & 1;
         const int base = ty * STEM_COLSP + tx16 * 16 + j;
         float v[8];
 #pragma unroll
@@ -443,7 +454,7 @@ __global__ void __launch_bounds__(256, 2) stem3_conv_kernel(const IgemmParams p,
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int pt = i + u;
-        const int gy = gy0 + 4 * wave + (pt >> 1), gx = gx0 + (pt & 1) * 16 + j;
+        const int gy = gy0 + 2 * wave + (pt >> 1), gx = gx0 + (pt & 1) * 16 + j;
         float* o = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw + 4 * g;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -455,20 +466,24 @@ __global__ void __launch_bounds__(256, 2) stem3_conv_kernel(const IgemmParams p,
       }
     }
     if (p.bn_partial != nullptr) {
-      // (sum, M2 about the mean) of the wave's 128 pixels per channel, from the pivot-centred sums: S = s + 128 pv, M2 = q - s^2 / 128
-      float* dst = p.bn_partial + ((long long)(4 * t + wave) * p.Ntot) * 2;
+      // (sum, M2 about the mean) of the wave's 64 pixels per channel from the pivot-centred sums: S = s + 64 pv, M2 = q - s^2 / 64
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float s1 = row16_sum(sv[m][e]), q1 = row16_sum(qv[m][e]);
-          if (j == 0) {
-            const int nn = 16 * m + 4 * g + e;
-            *reinterpret_cast<f32x2*>(dst + 2 * nn) = f32x2{fmaf(128.f, pv[m][e], s1), q1 - s1 * s1 * (1.f / 128.f)};
-          }
+          if (j == 0) *reinterpret_cast<f32x2*>(&wstat[wave][16 * m + 4 * g + e][0]) = f32x2{fmaf(64.f, pv[m][e], s1), q1 - s1 * s1 * (1.f / 64.f)};
         }
     }
     __syncthreads();
+    if (p.bn_partial != nullptr && tid < 128) {
+      // waves (0, 1) and (2, 3) make one 128-pixel row of the statistics table each (Chan's merge of two 64-pixel halves); the next
+      // tile's wstat writes come after the next barrier, so these reads cannot race them
+      const int h = tid >> 6, c = tid & 63;
+      const f32x2 a = *reinterpret_cast<const f32x2*>(&wstat[2 * h][c][0]), b2 = *reinterpret_cast<const f32x2*>(&wstat[2 * h + 1][c][0]);
+      const float dm = (b2[0] - a[0]) * (1.f / 64.f);
+      *reinterpret_cast<f32x2*>(p.bn_partial + ((long long)(2 * t + h) * p.Ntot + c) * 2) = f32x2{a[0] + b2[0], a[1] + b2[1] + dm * dm * 32.f};
+    }
   }
 }
 
@@ -481,7 +496,7 @@ static bool stem3_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   const KResult& r = p.out[0];
   if (!(o.C >= 1 && o.C <= 3 && o.up == 0 && o.scale == nullptr && o.small)) return false;
   if (!(r.linear && !r.accumulate && (r.sw & 3) == 0 && (reinterpret_cast<uintptr_t>(r.p) & 15) == 0)) return false;
-  return p.GH % STEM_TH == 0 && p.GW % STEM_TW == 0;          // full tiles: a wave's 128 pixels are one row of the statistics table
+  return p.GH % STEM_TH == 0 && p.GW % STEM_TW == 0;          // full tiles: two waves' 128 pixels are one row of the statistics table
 }
 
 bool stem3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) { return stem3_eligible(d, p); }

@@ -1,0 +1,458 @@
+// LDS-resident weight gradients of the thin full-resolution 3x3 layers (round 4): iconv0 (16 + 1 -> 16) and the first encoder layer
+// (3 -> 64 on the NCHW image); reference models/Disp_vgg_BN.py:84,110.  dW[co][tap][ci] = sum over pixels of dy[pixel][co] * x[pixel + tap][ci]:
+// the contraction runs over PIXELS, so on v_mfma_f32_16x16x32_bf16 a lane must hold eight consecutive pixels of one channel -- the
+// transpose of how NHWC tensors lie in memory.  Here the transposition is done once, by the staging threads:
+//   * a thread loads 8 pixels x 4 channels (eight float4), splits every value into its three exact bf16 pieces (DN_COMPUTE_F32X3) and
+//     writes, per channel and piece, the eight pixels as ONE 16-byte LDS word into channel-planar planes [piece][channel][row][col];
+//   * a K-step is one 32-pixel row of the 8 x 32 tile: A fragment = dy plane of output channel j at pixels 8 g .. 8 g + 7 (aligned
+//     ds_read_b128); B fragment of tap (dy, dx) = input plane of channel j, row + dy, the same eight columns shifted by dx: dx = 0 is the
+//     aligned word, dx = -1 / +1 are funnel shifts (v_alignbit_b32) of that word with one neighbour dword -- every tap of a row comes out
+//     of one b128 + two b32 reads per piece;
+//   * the four waves of a block take different rows and keep D[co][ci] of all taps (10 or 8 accumulator tiles) in registers across ALL
+//     tiles the persistent block walks; they meet once, at the end, through LDS, and the block writes one slab of the split-sum
+//     workspace that wgrad_reduce_kernel (dn_conv.hip) folds in a fixed order -- deterministic.
+// The 1-channel concat piece (nearest-x2 disparity) and the 3-channel image have their taps on the lanes (column n = tap, or tap * 3 + ci):
+// those fragments are gathered from small fp32 planes (8 ds_read_b32) and split in registers.
+#include <stdlib.h>
+
+#include "dn_internal.h"
+
+namespace dn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wg_split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 x = f32x2{v[e], v[e + 1]};
+    const bf16x2 h2 = __builtin_convertvector(x, bf16x2);
+    const f32x2 r = x - __builtin_convertvector(h2, f32x2);
+    const bf16x2 m2 = __builtin_convertvector(r, bf16x2);
+    const f32x2 q = r - __builtin_convertvector(m2, f32x2);
+    const bf16x2 l2 = __builtin_convertvector(q, bf16x2);
+    h[e] = h2[0]; h[e + 1] = h2[1];
+    m[e] = m2[0]; m[e + 1] = m2[1];
+    l[e] = l2[0]; l[e + 1] = l2[1];
+  }
+}
+
+struct WgGeo {
+  int tilesX, tilesY, ntiles, per_xcd;
+  long long slab;                  // floats per block slab of the workspace: Npad * Kp
+};
+
+constexpr int WG_TH = 8, WG_TW = 32;
+// ---- iconv0 form: 16-channel NHWC input (+ optional 1-channel nearest-x2 piece), 16 output channels
+constexpr int WG_GSTR = 528;                      // bytes between the dy planes of two output channels: 256 pixels x 2 + 16 (bank stagger)
+constexpr int WG_GPIECE = 16 * WG_GSTR;
+constexpr int WG_XROWB = 96;                      // one row of an input plane: 48 bf16, column c at element c + 8
+constexpr int WG_XSTR = 10 * WG_XROWB + 16;       // 976: bytes between the planes of two input channels
+constexpr int WG_XPIECE = 16 * WG_XSTR;
+constexpr int WG_DCOLS = 36;                      // fp32 plane of the 1-channel piece: [10][36], column c at c + 1
+constexpr int WG16_LDS = 3 * WG_GPIECE + 3 * WG_XPIECE + 10 * WG_DCOLS * 4;
+
+template <bool HAS1>
+__global__ void __launch_bounds__(256, 2) lds3_wgrad16_kernel(const IgemmParams p, const WgGeo geo) {
+  extern __shared__ __align__(16) char lds[];
+  char* Gp = lds;
+  char* Xp = lds + 3 * WG_GPIECE;
+  float* Dp = reinterpret_cast<float*>(lds + 3 * WG_GPIECE + 3 * WG_XPIECE);
+  constexpr int NT = HAS1 ? 10 : 9;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const KOperand& S = p.in[0];
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+  __amdgpu_buffer_rsrc_t r1 = rx;
+  if constexpr (HAS1) r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in[1].p), 0, 0x80000000u, 0x00020000);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the 1-channel piece: lane n < 9 is tap n, offsets into the fp32 plane in floats
+  const int dtap = j < 9 ? j : 0;
+  const int doff = (dtap / 3) * WG_DCOLS + (dtap % 3);          // (dy + 1) * cols + (dx + 1), column c at c + 1
+
+  f32x4 vg[8], vx[8];
+  float dv[2] = {0.f, 0.f};
+  auto issue_loads = [&](int t) __attribute__((always_inline)) {
+    const int txb = t % geo.tilesX, q1 = t / geo.tilesX;
+    const int tyb = q1 % geo.tilesY, n = q1 / geo.tilesY;
+    const int gy0 = tyb * WG_TH, gx0 = txb * WG_TW;
+    {   // dy: threads 0..127 take (row, 8-column group, channel quad)
+      const int cq = tid & 3, pxg = tid >> 2, row = pxg >> 2, cgp = pxg & 3;
+      const int gy = gy0 + row;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gx = gx0 + 8 * cgp + i;
+        const bool ok = tid < 128 && gy < p.GH && gx < p.GW;
+        const int off = (((n * p.GH + gy) * p.GW + gx) * p.Ntot + 4 * cq) * 4;
+        vg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : -1, 0, 0));
+      }
+    }
+    {   // input rows gy0 - 1 .. gy0 + 8, columns gx0 - 8 .. gx0 + 39 in 8-column groups (only columns -1 .. 32 are fetched)
+      const int cq = tid & 3, grp = tid >> 2, row = grp / 6, cgp = grp - row * 6;
+      const int iy = gy0 - 1 + row;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ix = gx0 + 8 * cgp - 8 + i;
+        const bool need = cgp == 0 ? i == 7 : (cgp == 5 ? i == 0 : true);
+        const bool ok = tid < 240 && need && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int off = (n * (int)S.sn + iy * (int)S.sh + ix * (int)S.sw + 4 * cq) * 4;
+        vx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : -1, 0, 0));
+      }
+    }
+    if constexpr (HAS1) {
+      const KOperand& S1 = p.in[1];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int it = tid + 256 * r;
+        const int row = it / 34, col = it - row * 34;
+        const int iy = gy0 - 1 + row, ix = gx0 - 1 + col;
+        const bool ok = it < 340 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int off = (n * (int)S1.sn + (iy >> S1.up) * (int)S1.sh + (ix >> S1.up) * (int)S1.sw) * 4;
+        dv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, ok ? off : -1, 0, 0));
+      }
+    }
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+    if (tid < 128) {
+      const int cq = tid & 3, pxg = tid >> 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v[8] = {vg[0][e], vg[1][e], vg[2][e], vg[3][e], vg[4][e], vg[5][e], vg[6][e], vg[7][e]};
+        bf16x8 h, m, l;
+        wg_split3(v, h, m, l);
+        char* dst = Gp + (4 * cq + e) * WG_GSTR + pxg * 16;
+        *reinterpret_cast<bf16x8*>(dst) = h;
+        *reinterpret_cast<bf16x8*>(dst + WG_GPIECE) = m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * WG_GPIECE) = l;
+      }
+    }
+    if (tid < 240) {
+      const int cq = tid & 3, grp = tid >> 2, row = grp / 6, cgp = grp - row * 6;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v[8] = {vx[0][e], vx[1][e], vx[2][e], vx[3][e], vx[4][e], vx[5][e], vx[6][e], vx[7][e]};
+        bf16x8 h, m, l;
+        wg_split3(v, h, m, l);
+        char* dst = Xp + (4 * cq + e) * WG_XSTR + row * WG_XROWB + cgp * 16;
+        *reinterpret_cast<bf16x8*>(dst) = h;
+        *reinterpret_cast<bf16x8*>(dst + WG_XPIECE) = m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * WG_XPIECE) = l;
+      }
+    }
+    if constexpr (HAS1) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int it = tid + 256 * r;
+        const int row = it / 34, col = it - row * 34;
+        if (it < 340) Dp[row * WG_DCOLS + col] = dv[r];
+      }
+    }
+  };
+
+  const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
+  const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
+  constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+  if (band_lo + local < band_hi) issue_loads(band_lo + local);
+  for (int t = band_lo + local; t < band_hi; t += nlocal) {
+    store_lds();
+    __syncthreads();
+    if (t + nlocal < band_hi) issue_loads(t + nlocal);
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * wave + rr;                                   // this wave's K-step: tile row r, pixels 8 g .. 8 g + 7 per lane group
+      bf16x8 a[3];
+#pragma unroll
+      for (int P = 0; P < 3; ++P) a[P] = *reinterpret_cast<const bf16x8*>(Gp + P * WG_GPIECE + j * WG_GSTR + (r * 32 + 8 * g) * 2);
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const char* rowb = Xp + j * WG_XSTR + (r + ty) * WG_XROWB + (8 * g + 8) * 2;
+        u32x4 c[3];
+        unsigned lf[3], rt[3];
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+          c[P] = *reinterpret_cast<const u32x4*>(rowb + P * WG_XPIECE);
+          lf[P] = *reinterpret_cast<const unsigned*>(rowb + P * WG_XPIECE - 4);
+          rt[P] = *reinterpret_cast<const unsigned*>(rowb + P * WG_XPIECE + 16);
+        }
+        bf16x8 bm[3], bz[3], bp[3];
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+          const u32x4 m4 = u32x4{__builtin_amdgcn_alignbit(c[P][0], lf[P], 16), __builtin_amdgcn_alignbit(c[P][1], c[P][0], 16),
+                                 __builtin_amdgcn_alignbit(c[P][2], c[P][1], 16), __builtin_amdgcn_alignbit(c[P][3], c[P][2], 16)};
+          const u32x4 p4 = u32x4{__builtin_amdgcn_alignbit(c[P][1], c[P][0], 16), __builtin_amdgcn_alignbit(c[P][2], c[P][1], 16),
+                                 __builtin_amdgcn_alignbit(c[P][3], c[P][2], 16), __builtin_amdgcn_alignbit(rt[P], c[P][3], 16)};
+          bm[P] = __builtin_bit_cast(bf16x8, m4);
+          bz[P] = __builtin_bit_cast(bf16x8, c[P]);
+          bp[P] = __builtin_bit_cast(bf16x8, p4);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          acc[3 * ty + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS[q]], bm[BS[q]], acc[3 * ty + 0], 0, 0, 0);
+          acc[3 * ty + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS[q]], bz[BS[q]], acc[3 * ty + 1], 0, 0, 0);
+          acc[3 * ty + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS[q]], bp[BS[q]], acc[3 * ty + 2], 0, 0, 0);
+        }
+      }
+      if constexpr (HAS1) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = Dp[r * WG_DCOLS + 8 * g + e + doff];
+          v[e] = j < 9 ? x : 0.f;
+        }
+        bf16x8 b[3];
+        wg_split3(v, b[0], b[1], b[2]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[9] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS[q]], b[BS[q]], acc[9], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- the four waves meet (fixed order) and the block writes its slab ws[block][co][k], k = tap * 16 + ci (operand 0), kbase1 + tap
+  f32x4* red = reinterpret_cast<f32x4*>(lds);          // [wave][tile][lane]: 4 * 10 * 64 * 16 B = 40 KB (the planes are free now)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
+  __syncthreads();
+  const int Kp = p.ph[0].nchunks * kChunk;
+  const int kbase1 = ((9 * 16 + kChunk - 1) / kChunk) * kChunk;
+  float* slab = p.ws + (long long)blockIdx.x * geo.slab;
+  for (int it = tid; it < NT * 64; it += 256) {
+    const int t = it >> 6, l = it & 63;
+    const f32x4 s = (red[(0 * NT + t) * 64 + l] + red[(1 * NT + t) * 64 + l]) + (red[(2 * NT + t) * 64 + l] + red[(3 * NT + t) * 64 + l]);
+    const int jj = l & 15, gg = l >> 4;
+    const int k = t < 9 ? t * 16 + jj : kbase1 + jj;
+    if (t < 9 || jj < 9) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) slab[(long long)(4 * gg + e) * Kp + k] = s[e];
+    }
+  }
+}
+
+// ---- stem form: <= 3-channel image through its strides (NCHW), 64 output channels.  dy is staged half a tile (4 rows) at a time.
+constexpr int WS_GSTR = 272;                      // 128 pixels x 2 + 16
+constexpr int WS_GPIECE = 64 * WS_GSTR;
+constexpr int WS_ICOLS = 36;                      // fp32 image planes [3][10][36], column c at c + 1
+constexpr int WS_IPLANE = 10 * WS_ICOLS;
+constexpr int WGS_LDS = 3 * WS_GPIECE + 3 * WS_IPLANE * 4;
+
+__global__ void __launch_bounds__(256, 2) lds3_wgrad_stem_kernel(const IgemmParams p, const WgGeo geo) {
+  extern __shared__ __align__(16) char lds[];
+  char* Gp = lds;
+  float* Ip = reinterpret_cast<float*>(lds + 3 * WS_GPIECE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const KOperand& S = p.in[0];
+  const int C = S.C, K = 9 * C;
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // column 16 nt + j = tap * C + ci: offset of its pixel (0, 0) value in the image planes
+  int ioff[2];
+  bool ilive[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = 16 * nt + j;
+    ilive[nt] = col < K;
+    const int tap = ilive[nt] ? col / C : 0, ci = ilive[nt] ? col - tap * C : 0;
+    ioff[nt] = ci * WS_IPLANE + (tap / 3) * WS_ICOLS + (tap % 3);
+  }
+
+  f32x4 vg[8];
+  float vi[4];
+  auto issue_g = [&](int t, int h) __attribute__((always_inline)) {
+    const int txb = t % geo.tilesX, q1 = t / geo.tilesX;
+    const int tyb = q1 % geo.tilesY, n = q1 / geo.tilesY;
+    const int pxg = tid & 15, cq = tid >> 4, row = pxg >> 2, cgp = pxg & 3;
+    const int gy = tyb * WG_TH + 4 * h + row;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gx = txb * WG_TW + 8 * cgp + i;
+      const bool ok = gy < p.GH && gx < p.GW;
+      const int off = (((n * p.GH + gy) * p.GW + gx) * p.Ntot + 4 * cq) * 4;
+      vg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : -1, 0, 0));
+    }
+  };
+  auto issue_img = [&](int t) __attribute__((always_inline)) {
+    const int txb = t % geo.tilesX, q1 = t / geo.tilesX;
+    const int tyb = q1 % geo.tilesY, n = q1 / geo.tilesY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int it = tid + 256 * r;
+      const int c = it / 340, px = it - c * 340;
+      const int row = px / 34, col = px - row * 34;
+      const int iy = tyb * WG_TH - 1 + row, ix = txb * WG_TW - 1 + col;
+      const bool ok = c < C && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const int off = (n * (int)S.sn + iy * (int)S.sh + ix * (int)S.sw + c * (int)S.sc) * 4;
+      vi[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? off : -1, 0, 0));
+    }
+  };
+  auto store_g = [&]() __attribute__((always_inline)) {
+    const int pxg = tid & 15, cq = tid >> 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v[8] = {vg[0][e], vg[1][e], vg[2][e], vg[3][e], vg[4][e], vg[5][e], vg[6][e], vg[7][e]};
+      bf16x8 h, m, l;
+      wg_split3(v, h, m, l);
+      char* dst = Gp + (4 * cq + e) * WS_GSTR + pxg * 16;
+      *reinterpret_cast<bf16x8*>(dst) = h;
+      *reinterpret_cast<bf16x8*>(dst + WS_GPIECE) = m;
+      *reinterpret_cast<bf16x8*>(dst + 2 * WS_GPIECE) = l;
+    }
+  };
+  auto store_img = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int it = tid + 256 * r;
+      const int c = it / 340, px = it - c * 340;
+      const int row = px / 34, col = px - row * 34;
+      if (c < 3) Ip[c * WS_IPLANE + row * WS_ICOLS + col] = vi[r];
+    }
+  };
+
+  const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
+  const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
+  constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+  if (band_lo + local < band_hi) {
+    issue_g(band_lo + local, 0);
+    issue_img(band_lo + local);
+  }
+  for (int t = band_lo + local; t < band_hi; t += nlocal) {
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      store_g();
+      if (h == 0) store_img();
+      __syncthreads();
+      if (h == 0) issue_g(t, 1);
+      else if (t + nlocal < band_hi) {
+        issue_g(t + nlocal, 0);
+        issue_img(t + nlocal);
+      }
+      // this wave's K-step: row 4 h + wave of the tile = row `wave` of the staged half
+      const int r = 4 * h + wave;
+      bf16x8 b[2][3];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = Ip[r * WS_ICOLS + 8 * g + e + ioff[nt]];
+          v[e] = ilive[nt] ? x : 0.f;
+        }
+        wg_split3(v, b[nt][0], b[nt][1], b[nt][2]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int P = 0; P < 3; ++P) a[P] = *reinterpret_cast<const bf16x8*>(Gp + P * WS_GPIECE + (16 * m + j) * WS_GSTR + (wave * 32 + 8 * g) * 2);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS[q]], b[nt][BS[q]], acc[m][nt], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  f32x4* red = reinterpret_cast<f32x4*>(lds);          // [wave][m][nt][lane]: 32 KB
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) red[((wave * 4 + m) * 2 + nt) * 64 + lane] = acc[m][nt];
+  __syncthreads();
+  const int Kp = p.ph[0].nchunks * kChunk;
+  float* slab = p.ws + (long long)blockIdx.x * geo.slab;
+  for (int it = tid; it < 8 * 64; it += 256) {
+    const int mn = it >> 6, l = it & 63, m = mn >> 1, nt = mn & 1;
+    const f32x4 s = (red[((0 * 4 + m) * 2 + nt) * 64 + l] + red[((1 * 4 + m) * 2 + nt) * 64 + l]) +
+                    (red[((2 * 4 + m) * 2 + nt) * 64 + l] + red[((3 * 4 + m) * 2 + nt) * 64 + l]);
+    const int jj = l & 15, gg = l >> 4, k = 16 * nt + jj;
+    if (k < K) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) slab[(long long)(16 * m + 4 * gg + e) * Kp + k] = s[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ dispatch
+static int lds3_wgrad_form(const dn_conv_desc* d, const IgemmParams& p) {     // 0 none, 1 iconv0 (16 -> 16), 2 iconv0 + 1-channel piece, 3 stem
+  static const bool off = getenv("DN_NO_LDS3") != nullptr || getenv("DN_NO_LDS3_WGRAD") != nullptr;
+  if (off || d->compute != DN_COMPUTE_F32X3) return 0;
+  if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return 0;
+  if (d->IH != d->OH || d->IW != d->OW) return 0;
+  if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.g) & 15)) return 0;
+  for (int t = 0; t < 9; ++t)
+    if (p.tdy[t] != t / 3 - 1 || p.tdx[t] != t % 3 - 1) return 0;
+  const KOperand& a = p.in[0];
+  if (!a.small || a.scale != nullptr || a.up != 0) return 0;
+  if (p.Ntot == 16 && a.C == 16 && a.vec) {
+    if (p.n_in == 1) return 1;
+    const KOperand& b = p.in[1];
+    if (p.n_in == 2 && b.C == 1 && b.small && b.scale == nullptr) return 2;
+    return 0;
+  }
+  if (p.Ntot == 64 && p.n_in == 1 && a.C >= 1 && a.C <= 3) return 3;
+  return 0;
+}
+
+static int lds3_wgrad_blocks(const IgemmParams& p) {
+  const int ntiles = p.N * ((p.GH + WG_TH - 1) / WG_TH) * ((p.GW + WG_TW - 1) / WG_TW);
+  int blocks = ntiles < 512 ? ntiles : 512;
+  return (blocks + 7) / 8 * 8;
+}
+
+bool lds3_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) { return lds3_wgrad_form(d, p) != 0; }
+
+size_t lds3_wgrad_workspace_bytes(const IgemmParams& p) {
+  return (size_t)lds3_wgrad_blocks(p) * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
+}
+
+int launch_lds3_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStream_t stream) {
+  const int form = lds3_wgrad_form(d, p);
+  WgGeo geo;
+  geo.tilesX = (p.GW + WG_TW - 1) / WG_TW;
+  geo.tilesY = (p.GH + WG_TH - 1) / WG_TH;
+  geo.ntiles = p.N * geo.tilesX * geo.tilesY;
+  geo.per_xcd = (geo.ntiles + 7) / 8;
+  geo.slab = (long long)p.Npad * p.ph[0].nchunks * kChunk;
+  const int blocks = lds3_wgrad_blocks(p);
+  hipError_t e = hipSuccess;
+  if (form == 3) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3_wgrad_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
+    if (e == hipSuccess) DN_LAUNCH(lds3_wgrad_stem_kernel, dim3(blocks), dim3(256), (size_t)WGS_LDS, stream, p, geo);
+    set_last_kernel("dn::lds3_wgrad_stem_kernel");
+  } else if (form == 2) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3_wgrad16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WG16_LDS);
+    if (e == hipSuccess) DN_LAUNCH(lds3_wgrad16_kernel<true>, dim3(blocks), dim3(256), (size_t)WG16_LDS, stream, p, geo);
+    set_last_kernel("dn::lds3_wgrad16_kernel<true>");
+  } else if (form == 1) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3_wgrad16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WG16_LDS);
+    if (e == hipSuccess) DN_LAUNCH(lds3_wgrad16_kernel<false>, dim3(blocks), dim3(256), (size_t)WG16_LDS, stream, p, geo);
+    set_last_kernel("dn::lds3_wgrad16_kernel<false>");
+  } else {
+    set_error("launch_lds3_wgrad: no form");
+    return DN_ERR_UNSUPPORTED;
+  }
+  if (e != hipSuccess) {
+    set_error("lds3 wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return DN_ERR_LAUNCH;
+  }
+  int rc = check_launch("lds3_wgrad_kernel");
+  if (rc != DN_OK) return rc;
+  p.splits = blocks;                                 // wgrad_reduce_kernel: fixed-order sum of the block slabs + scatter into dw's layout
+  return launch_wgrad_reduce(p, dw, stream);
+}
+
+}  // namespace dn

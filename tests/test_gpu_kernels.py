@@ -60,6 +60,7 @@ CONV_CASES = [
     # name,               cins,         ups,               cout, k, s, p, transposed, out_pad, N, H, W, act, affine
     ("3x3_64_64",         (64,),        (False,),          64, 3, 1, 1, False, 0, 2, 12, 20, ACT_NONE, False),
     ("3x3_first_nchw",    (3,),         (False,),          64, 3, 1, 1, False, 0, 2, 16, 24, ACT_NONE, False),
+    ("3x3_first_tiles_nchw", (3,),      (False,),          64, 3, 1, 1, False, 0, 2, 24, 64, ACT_NONE, False),     # stem3 / lds3 wgrad: 8x32 tiles
     ("3x3_128_256_bnload", (128,),      (False,),          256, 3, 1, 1, False, 0, 2, 8, 12, ACT_NONE, True),
     ("3x3_wino_cat",      (32, 64),     (False, False),    96, 3, 1, 1, False, 0, 3, 18, 22, ACT_LEAKY, False),
     ("3x3_wino_cat_aff",  (64, 16),     (False, False),    64, 3, 1, 1, False, 0, 2, 20, 26, ACT_RELU, True),
