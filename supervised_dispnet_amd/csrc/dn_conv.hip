@@ -2238,10 +2238,14 @@ static int generic_wgrad(const dn_conv_desc* fwd, IgemmParams& p, const float* d
   if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0 && (long long)p.M * p.Ntot < (1ll << 31))) p.allvec = 0;
   // the G operand must be float4-addressable with 32-bit BYTE offsets for the fast kernel
   if (!(p.Ntot % 4 == 0 && (reinterpret_cast<uintptr_t>(p.g) & 15) == 0) || (long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) p.wg_uniform = 0;
-  switch (p.BN) {
-    case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;
-    case 64: rc = launch_wgrad<64, 64, 32>(p, s); break;
-    default: rc = launch_wgrad<32, 32, 32>(p, s); break;
+  if (wgrad_x3_eligible(p)) {
+    rc = launch_wgrad_x3(p, s);           // fp32 products on the bf16 matrix cores (dn_wgrad_x3.hip)
+  } else {
+    switch (p.BN) {
+      case 128: rc = launch_wgrad<128, 64, 64>(p, s); break;
+      case 64: rc = launch_wgrad<64, 64, 32>(p, s); break;
+      default: rc = launch_wgrad<32, 32, 32>(p, s); break;
+    }
   }
   if (rc != DN_OK) return rc;
   const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;

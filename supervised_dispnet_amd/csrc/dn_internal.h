@@ -220,6 +220,9 @@ bool lds3_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
 size_t lds3_wgrad_workspace_bytes(const IgemmParams& p);
 int launch_lds3_wgrad(const dn_conv_desc* fwd, IgemmParams& p, float* dw, hipStream_t stream);
 int launch_wgrad_reduce(const IgemmParams& p, float* dw, hipStream_t stream);   // dn_conv.hip: fixed-order sum of p.splits slabs of p.ws -> dw
+// dn_wgrad_x3.hip: the tiled weight gradient with three-piece arithmetic on the bf16 matrix cores (64 / 128-wide n tiles, float4 operands)
+bool wgrad_x3_eligible(const IgemmParams& p);
+int launch_wgrad_x3(const IgemmParams& p, hipStream_t stream);
 bool stem3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_stem3_conv(const IgemmParams& p, hipStream_t stream);
 
