@@ -2268,14 +2268,23 @@ static bool wgrad_split_plans(const dn_conv_desc* fwd, dn_conv_desc* d1, dn_conv
   d2->n_in = 1;
   d2->in[0] = fwd->in[fwd->n_in - 1];
   if (build_plan(d1, true, p1) != DN_OK || build_plan(d2, true, p2) != DN_OK) return false;
-  if (!wino_wgrad_eligible(d1, *p1)) return false;
   int cin_total = 0;
   for (int i = 0; i < fwd->n_in; ++i) cin_total += fwd->in[i].C;
-  p1->dw_cin_total = cin_total;
+  if (wino_wgrad_eligible(d1, *p1)) {
+    p1->dw_cin_total = cin_total;
+    *w1 = (wino_wgrad_workspace_bytes(*p1) + 255) / 256 * 256;
+  } else if (wgrad_x3_eligible(*p1) && getenv("DN_WGRAD_SPLIT_X3") != nullptr) {
+    // (round 4, opt-in: measured SLOWER -- iconv1 97 -> 32 @64x208 0.375 -> 0.508 ms, a 32-wide n tile is bound by its staging) the pieces
+    // in front on the three-piece tiled kernel -- the trailing scalar piece is what keeps the whole layer off it
+    p1->D1 = cin_total;                          // packed_to_framework: row stride of the full weight tensor
+    choose_splits(p1);
+    *w1 = ((size_t)p1->splits * p1->Npad * p1->ph[0].nchunks * kChunk * sizeof(float) + 255) / 256 * 256;
+  } else {
+    return false;
+  }
   p2->in[0].ch_off = cin_total - 1;              // (packed_to_framework: the column block of this channel in the full weight tensor)
   p2->D1 = cin_total;
   choose_splits(p2);
-  *w1 = (wino_wgrad_workspace_bytes(*p1) + 255) / 256 * 256;
   *w2 = (size_t)p2->splits * p2->Npad * p2->ph[0].nchunks * kChunk * sizeof(float);
   return true;
 }
@@ -2442,9 +2451,13 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     size_t w1 = 0, w2 = 0;
     if (wgrad_split_plans(fwd, &d1, &d2, &p1, &p2, &w1, &w2) && workspace_bytes >= w1 + w2) {
       for (int i = 0; i < fwd->n_in; ++i) DN_REQUIRE(fwd->in[i].data != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
-      p1.g = dy;
-      p1.ws = reinterpret_cast<float*>(workspace);
-      rc = launch_wino_wgrad(p1, dw, as_stream(stream));
+      if (wino_wgrad_eligible(&d1, p1)) {
+        p1.g = dy;
+        p1.ws = reinterpret_cast<float*>(workspace);
+        rc = launch_wino_wgrad(p1, dw, as_stream(stream));
+      } else {
+        rc = generic_wgrad(&d1, p1, dy, dw, workspace, w1, as_stream(stream));
+      }
       if (rc != DN_OK) return rc;
       return generic_wgrad(&d2, p2, dy, dw, reinterpret_cast<char*>(workspace) + w1, w2, as_stream(stream));
     }

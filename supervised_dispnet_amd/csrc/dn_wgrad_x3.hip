@@ -58,10 +58,12 @@ template <int BNW, bool AFF>
 __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_kernel(const IgemmParams p) {
   constexpr int BKW = 128;
   constexpr int NCH = BNW + BKW, PIECE = NCH * WX_ROWB;
-  constexpr int NI = BNW / 64, KI = 2;             // 32 x 32 tiles per wave: the wave tile is (BNW / 2) x 64
+  constexpr int WAVES_K = BNW == 32 ? 4 : 2, WAVES_N = 4 / WAVES_K;       // four waves as 2 x 2 (1 x 4 for the 32-wide n tile)
+  constexpr int WNn = BNW / WAVES_N, WKk = BKW / WAVES_K;
+  constexpr int NI = WNn / 32, KI = WKk / 32;      // 32 x 32 tiles per wave
   extern __shared__ __align__(16) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave / WAVES_K, wk = wave % WAVES_K;
   const KPhase ph = p.ph[0];
   const int ntaps = ph.ntaps, nchunks = ph.nchunks, Kp = nchunks * kChunk;
   // XCD-aware order (igemm_wgrad_u32_kernel): the k tiles and n tiles of ONE pixel split are consecutive logical tiles on one XCD
@@ -179,8 +181,8 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_kernel(const IgemmParam
   };
 
   const int nsteps = (m_end > m_begin) ? (m_end - m_begin + 31) / 32 : 0;
-  const int frA = (wn * (BNW / 2) + (lane & 31)) * WX_ROWB + (lane >> 5) * 16;
-  const int frB = (BNW + wk * 64 + (lane & 31)) * WX_ROWB + (lane >> 5) * 16;
+  const int frA = (wn * WNn + (lane & 31)) * WX_ROWB + (lane >> 5) * 16;
+  const int frB = (BNW + wk * WKk + (lane & 31)) * WX_ROWB + (lane >> 5) * 16;
   constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
   if (nsteps > 0) issue_loads(m_begin);
   for (int st = 0; st < nsteps; ++st) {
@@ -211,23 +213,24 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_kernel(const IgemmParam
   float* ws = p.ws + (long long)split * p.Npad * Kp;
 #pragma unroll
   for (int j = 0; j < KI; ++j) {
-    const int k = kt * BKW + wk * 64 + j * 32 + (lane & 31);
+    const int k = kt * BKW + wk * WKk + j * 32 + (lane & 31);
     if (k >= Kp) continue;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int n = n0 + wn * (BNW / 2) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int n = n0 + wn * WNn + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         ws[(long long)n * Kp + k] = acc[i][j][reg];
       }
   }
 }
 
 // plans the kernel takes: the fast weight-gradient plan (<= 32 taps, zero padding, 32-bit offsets) whose operands are all float4-addressable,
-// a 64- or 128-wide n tile, and a grid row of at least 8 pixels (an 8-pixel staging group wraps at most once)
+// and a grid row of at least 8 pixels (an 8-pixel staging group wraps at most once)
 bool wgrad_x3_eligible(const IgemmParams& p) {
   static const bool off = getenv("DN_NO_X3_WGRAD") != nullptr;
-  if (off || p.compute != DN_COMPUTE_F32X3 || !p.wg_uniform || p.GW < 8 || !(p.BN == 64 || p.BN == 128)) return false;
+  static const bool no32 = getenv("DN_NO_X3_WGRAD32") != nullptr;
+  if (off || p.compute != DN_COMPUTE_F32X3 || !p.wg_uniform || p.GW < 8 || (p.BN == 32 && no32)) return false;
   for (int i = 0; i < p.n_in; ++i) {
     const KOperand& o = p.in[i];
     if (!(o.vec && o.small)) return false;
@@ -256,7 +259,8 @@ static int launch_wx(const IgemmParams& p, hipStream_t stream) {
 
 int launch_wgrad_x3(const IgemmParams& p, hipStream_t stream) {
   if (p.BN == 128) return p.any_affine ? launch_wx<128, true>(p, stream) : launch_wx<128, false>(p, stream);
-  return p.any_affine ? launch_wx<64, true>(p, stream) : launch_wx<64, false>(p, stream);
+  if (p.BN == 64) return p.any_affine ? launch_wx<64, true>(p, stream) : launch_wx<64, false>(p, stream);
+  return p.any_affine ? launch_wx<32, true>(p, stream) : launch_wx<32, false>(p, stream);
 }
 
 }  // namespace dn
