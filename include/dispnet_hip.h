@@ -146,6 +146,11 @@ typedef struct dn_conv_desc {
    * one buffer serves every launch of ONE stream; launches on different streams need different buffers.  NULL: never split. */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
+  /* Optional (round 4): second result of a one-channel disparity head.  The reference computes depth = 1 / disp in
+   * the caller, right behind the network (train.py:445, `depth = [1/disp for disp in disparities]`); when dn_conv_fwd_fuses_reciprocal(desc)
+   * returns 1 the head kernel that writes disp = alpha * sigmoid(conv) + beta also writes 1 / disp here (dense [N][OH][OW] floats, the
+   * same IEEE division dn_reciprocal_fwd performs), so the caller's reciprocal needs no launch.  Otherwise ignored; NULL: not wanted. */
+  float* recip_out;
 } dn_conv_desc;
 
 enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2 };
@@ -179,6 +184,8 @@ int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d);
 int64_t dn_conv_splitk_workspace_bytes(const dn_conv_desc* d);
 /* 1 if dn_conv2d_dgrad(d) will write bnb_partial (see dn_conv_desc), 0 if it ignores the bnb_* fields, < 0 on a bad descriptor. */
 int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d);
+/* 1 if dn_conv2d_fwd(d) writes 1 / out[0] to d->recip_out (a one-channel head on the second-generation head kernel), else 0. */
+int32_t dn_conv_fwd_fuses_reciprocal(const dn_conv_desc* d);
 /* Enqueue the convolution described by d. */
 int dn_conv2d_fwd(const dn_conv_desc* d, dn_stream_t stream);      /* kind == DN_CONV_FWD */
 int dn_conv2d_dgrad(const dn_conv_desc* d, dn_stream_t stream);    /* kind == DN_CONV_DGRAD */

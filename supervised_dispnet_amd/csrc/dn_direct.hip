@@ -235,6 +235,8 @@ __global__ void __launch_bounds__(256) head_fwd2_kernel(const IgemmParams p, int
       float* op = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
       if (R.accumulate) v += *op;
       *op = v;
+      // depth = 1 / disp (train.py:445) leaves with the disparity: the caller's reciprocal() then launches nothing
+      if (p.recip_out != nullptr) p.recip_out[((long long)n * p.GH + gy) * p.GW + gx] = 1.f / v;
     }
   }
 }
@@ -391,6 +393,10 @@ int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
   DN_LAUNCH(head_fwd_kernel, dim3(hblocks), dim3(256), p.ph[0].ntaps * p.in[0].C * sizeof(float), stream, p, LG);
   set_last_kernel("dn::head_fwd_kernel");
   return check_launch("head_fwd_kernel");
+}
+
+bool head_fwd_fuses_reciprocal(const dn_conv_desc* d, const IgemmParams& p) {
+  return !knobs().no_direct && head_fwd_eligible(d, p) && head2_geometry(p, p.in[0].C) && p.GH == p.IH && p.GW == p.IW && !p.out[0].accumulate;
 }
 
 bool head_dgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {

@@ -146,6 +146,7 @@ struct IgemmParams {
   int ksplit, ks_chunks, ks_cnt_floats;   // input-channel split of small grids (dn_winograd.hip): splits, chunks of the K axis, float offset of the partial tiles
   int dw_cin_total;                       // weight gradient of the LEADING operands of a wider layer: channels per row of dw (0: this plan's own)
   int ks_reg, ks_tail;                    // 8-wave kernel: tiles [0, ks_reg) run whole, the ks_tail tiles after them are split (dn_winograd8.hip)
+  float* recip_out;              // one-channel heads: 1 / result, dense [N][OH][OW] (dn_conv_desc.recip_out), or nullptr
   float* ks_ws;                  // caller workspace (dn_conv_desc.splitk_ws): zeroed int counters, then the partial tiles
   size_t ks_ws_bytes;
   int T, TH, TW;                 // 2x2 output tiles: total, per image column / row
@@ -186,6 +187,7 @@ __device__ __forceinline__ unsigned fastdiv_dev(unsigned n, unsigned d, unsigned
 // dn_direct.hip: matrix-core-free kernels for the one-channel disparity heads, dispatched from the conv entry points
 bool head_fwd_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_head_fwd(const IgemmParams& p, hipStream_t stream);
+bool head_fwd_fuses_reciprocal(const dn_conv_desc* d, const IgemmParams& p);
 bool head_dgrad_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_head_dgrad(const IgemmParams& p, hipStream_t stream);
 bool head_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);

@@ -172,6 +172,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     p->bnb_invstd = d->bnb_invstd;
     p->bnb_partial = d->bnb_partial;
   }
+  if (!for_wgrad && d->kind == DN_CONV_FWD) p->recip_out = d->recip_out;
   if (!for_wgrad && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0) {
     p->ks_ws = reinterpret_cast<float*>(d->splitk_ws);
     p->ks_ws_bytes = (size_t)d->splitk_ws_bytes;
@@ -378,7 +379,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 12; }
+int dn_version(void) { return 13; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);
@@ -422,6 +423,12 @@ int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (dn::build_plan(d, false, &p) != DN_OK) return -1;
   return (p.M + 127) / 128;
+}
+
+int32_t dn_conv_fwd_fuses_reciprocal(const dn_conv_desc* d) {
+  dn::IgemmParams p;
+  if (d == nullptr || d->kind != DN_CONV_FWD || dn::build_plan(d, false, &p) != DN_OK) return 0;
+  return dn::head_fwd_fuses_reciprocal(d, p) ? 1 : 0;
 }
 
 int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d) {

@@ -395,7 +395,8 @@ def require_cuda(t, what):
 class Act:
     """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
     __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
-                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar", "pool_src", "sums_ready")
+                 "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar", "pool_src", "sums_ready",
+                 "recip_t")
 
     def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
         self.t = t
@@ -413,6 +414,7 @@ class Act:
         self.pool_src = None            # (dpooled, idx): the gradient arrives through a 2x2 max-pool and is expanded by the BatchNorm
                                         # backward itself (dn_bn_bwd_apply_pool); .grad is then only the destination buffer
         self.planar = False             # .t is [N,C,H,W] (a network OUTPUT the caller's API wants planar: ord_c1, decode_c)
+        self.recip_t = None             # a one-channel disparity head's 1 / disp, written by the head kernel (dn_conv_desc.recip_out)
         self.needs_grad = needs_grad
         self.strides = strides or (H * W * C, W * C, C, 1)   # (n, h, w, c) element strides
 
@@ -692,7 +694,10 @@ def prepack_all(device):
         t.run(PARAM_EPOCH)
 
 
-def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None, out_view=None):
+FUSE_RECIP = os.environ.get("DN_NO_RECIP_FUSION") is None       # a one-channel disparity head also emits depth = 1 / disp (train.py:445)
+
+
+def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None, out_view=None, recip=None):
     """Forward of conv / conv-transpose over virtually concatenated `pieces`.  Returns (y tensor NHWC, partial, rows).
     `out_view` = (tensor, element offset, (stride_n, stride_h, stride_w), accumulate): write the result into a strided view of an
     existing tensor instead of a fresh one (FCRN's interleaved up-projection maps; the ASPP classifier's sum of four convolutions)."""
@@ -723,6 +728,10 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
     d.act, d.act_p0, d.act_p1 = act, p0, p1
     _splitk_workspace(d, a0.t.device)
     partial, rows = None, 0
+    if recip is not None and out_view is None and layer.Cout == 1 and _lib.load().dn_conv_fwd_fuses_reciprocal(C.byref(d)) == 1:
+        # `recip`: a one-element list the caller gets the [N, OH, OW, 1] reciprocal back in
+        recip.append(torch.empty((N, OH, OW, 1), dtype=torch.float32, device=a0.t.device))
+        d.recip_out = recip[0].data_ptr()
     if bn_stats:
         rows = _lib.load().dn_conv_bn_partial_rows(C.byref(d))
         partial = torch.empty((rows, layer.Cout, 2), dtype=torch.float32, device=y.device)
@@ -1120,9 +1129,12 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
     self.bn1(conv1); relu1 = self.relu(conv1)`): only its running statistics are updated, from the conv epilogue's sums."""
     a0 = pieces[0].act
     in_hw = (a0.H * (2 if pieces[0].up else 1), a0.W * (2 if pieces[0].up else 1))
-    y_t, partial, prow = conv_forward(layer, pieces, act, p0, p1, out_hw=out_hw, bn_stats=stat_bn is not None)
+    want_recip = [] if (FUSE_RECIP and act == ACT_SIGMOID_AFFINE and layer.Cout == 1 and stat_bn is None) else None
+    y_t, partial, prow = conv_forward(layer, pieces, act, p0, p1, out_hw=out_hw, bn_stats=stat_bn is not None, recip=want_recip)
     OH, OW = y_t.shape[1], y_t.shape[2]
     y = Act(y_t, a0.N, OH, OW, layer.Cout)
+    if want_recip:
+        y.recip_t = want_recip[0]             # depth = 1 / disp, written by the head kernel: functional.reciprocal() hands it out
     if stat_bn is not None:
         Cn, dev = layer.Cout, y_t.device
         scratch = torch.empty((4, Cn), dtype=torch.float32, device=dev)

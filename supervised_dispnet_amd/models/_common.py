@@ -87,6 +87,10 @@ class HipNetFunction(torch.autograd.Function):
             outs = net._hip_forward(tape, sink, *in_acts)     # list[Act]
         ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
         results = tuple(a.t if a.planar else (a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2)) for a in outs)
+        # 1 / disp of the one-channel heads, written by the head kernels themselves: run_net attaches them to the
+        # tensors it returns and functional.reciprocal() hands them out without a launch
+        object.__setattr__(net, "_dn_recips", [a.recip_t.view(a.N, 1, a.H, a.W) if (a.recip_t is not None and a.C == 1 and not a.planar) else None
+                                               for a in outs])
         for r in results:
             if not torch.is_floating_point(r):
                 ctx.mark_non_differentiable(r)
@@ -120,4 +124,11 @@ def run_net(net, *inputs):
         for p in params:
             engine.require_cuda(p, "model parameters")
         object.__setattr__(net, "_dn_param_cache", params)
-    return HipNetFunction.apply(net, len(inputs), torch.is_grad_enabled(), *inputs, *params)
+    outs = HipNetFunction.apply(net, len(inputs), torch.is_grad_enabled(), *inputs, *params)
+    recips = getattr(net, "_dn_recips", None)
+    if recips is not None:
+        object.__setattr__(net, "_dn_recips", None)
+        for o, r in zip(outs, recips):
+            if r is not None:
+                o._dn_recip = (r, o._version)      # valid while the disparity tensor is unmodified
+    return outs
