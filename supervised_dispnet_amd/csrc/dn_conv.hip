@@ -2296,7 +2296,7 @@ static bool wgrad_split_plans(const dn_conv_desc* fwd, dn_conv_desc* d1, dn_conv
 // tap tables; the split sum of each window writes only its own (r, s) entries of dw.
 static int tap_windows(const IgemmParams& p) {
   const int nt = p.ph[0].ntaps;
-  if (nt <= 32 || p.reflect || p.nphases != 1 || getenv("DN_NO_TAP_WINDOWS") != nullptr) return 1;
+  if (nt <= 32 || p.reflect || p.nphases != 1 || knobs().no_tap_windows) return 1;
   return (nt + 31) / 32;
 }
 

@@ -488,8 +488,7 @@ __global__ void __launch_bounds__(256, 2) stem3_conv_kernel(const IgemmParams p,
 }
 
 static bool stem3_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  static const bool off = getenv("DN_NO_LDS3") != nullptr || getenv("DN_NO_STEM3") != nullptr;
-  if (off || p.compute != DN_COMPUTE_F32X3) return false;
+  if (knobs().no_stem3 || p.compute != DN_COMPUTE_F32X3) return false;
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (p.n_in != 1 || p.n_out != 1 || p.Ntot != 64 || p.nphases != 1) return false;
   const KOperand& o = p.in[0];
@@ -525,8 +524,7 @@ struct Lds3Pick {
 static Lds3Pick lds3_pick(const dn_conv_desc* d, const IgemmParams& p) {
   Lds3Pick r;
   r.cfg = 0;
-  static const bool off = getenv("DN_NO_LDS3") != nullptr;
-  if (off || p.compute != DN_COMPUTE_F32X3) return r;             // three-piece arithmetic only (DN_COMPUTE=f32 keeps the fp32 instruction)
+  if (knobs().no_lds3 || p.compute != DN_COMPUTE_F32X3) return r;             // three-piece arithmetic only (DN_COMPUTE=f32 keeps the fp32 instruction)
   if (p.reflect || p.bn_partial != nullptr || p.bnb_y != nullptr || p.Ntot > 32 || p.n_in > 2 || p.n_out < 1) return r;
   if (d->dilation > 1) return r;
   if (!(p.nphases == 1 || (p.nphases == 4 && p.Ntot <= 16))) return r;

@@ -126,6 +126,11 @@ static void read_knobs(Knobs* k) {
   if (k->pack_blocks < 1) k->pack_blocks = 1;
   k->wino_min_n = num("DN_WINO_MIN_N", 64);
   k->wino_pad_pct = num("DN_WINO_PAD_PCT", 60);
+  k->no_lds3 = on("DN_NO_LDS3");
+  k->no_lds3_wgrad = on("DN_NO_LDS3") || on("DN_NO_LDS3_WGRAD");
+  k->no_stem3 = on("DN_NO_LDS3") || on("DN_NO_STEM3");
+  k->no_x3_wgrad = on("DN_NO_X3_WGRAD");
+  k->no_tap_windows = on("DN_NO_TAP_WINDOWS");
   k->wino8 = num("DN_WINO8", -1);
   k->wino8_min_k = num("DN_WINO8_MIN_K", 128);
 }

@@ -235,6 +235,12 @@ def xcd_placement_ok(device):
         _XCD_OK[device.index] = True
         return True
     ok = True
+    # (a launch tape being recorded must not see the probe: its launches would be replayed into buffers that are long freed -- found by
+    #  test_two_ranks_through_the_launch_tape..., whose FIRST step is the recorded one; graph.TapedStep also probes before it records)
+    pause = TAPE is not None and not TAPE.get("paused")
+    if pause:
+        _lib.call("dn_tape_pause", TAPE["handle"], 1)
+        TAPE["paused"] = True
     try:
         with torch.cuda.device(device), outside_tape_pool():
             props = torch.cuda.get_device_properties(device)
@@ -258,6 +264,10 @@ def xcd_placement_ok(device):
                     ok = False
     except Exception:                                 # noqa: BLE001 -- a probe that cannot run proves nothing: no split
         ok = False
+    finally:
+        if pause:
+            TAPE["paused"] = False
+            _lib.call("dn_tape_pause", TAPE["handle"], 0)
     if not ok:
         import warnings
         warnings.warn("supervised_dispnet_amd: block -> XCD placement on this device is not blockIdx.x % 8; K split of small grids disabled")

@@ -122,6 +122,8 @@ class TapedStep(object):
         gc.collect()
         for t in engine._PACK_TABLES.values():
             t._prune()
+        if engine.SPLITK:
+            engine.xcd_placement_ok(torch.device("cuda", dev))     # the one-time placement probe belongs in front of the recording
         self._pool = torch.cuda.MemPool()
         handle = lib.dn_tape_begin()
         if not handle:

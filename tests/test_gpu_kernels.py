@@ -237,27 +237,33 @@ def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
     close("wino_vs_direct:dw", res["wino"][4], res["direct"][4], rtol=1e-4, atol_rel=1e-5)
 
 
-@pytest.mark.parametrize("kind", ["iconv0", "upconv0", "iconv0_dgrad"])
+@pytest.mark.parametrize("kind", ["iconv0", "upconv0", "iconv0_dgrad", "upconv0_dgrad"])
 def test_thin_conv_matches_tiled_kernel(monkeypatch, kind):
-    """dn::thin_conv_kernel (16x16x4 MFMAs fed from global memory) against the tiled implicit GEMM (DN_NO_THIN_CONV=1) on the
-    layers it serves, at the metric's resolution: same fp32 products, different summation order -> agreement to round-off
-    everywhere, including the borders and the 1-channel upsampled piece."""
+    """The thin full-resolution layers at the metric's resolution on their three implementations: dn::lds3_conv_kernel (round 4: input
+    tile resident in LDS as three bf16 pieces, DN_COMPUTE_F32X3 arithmetic), dn::thin_conv_kernel (DN_NO_LDS3=1: 16x16x4 fp32 MFMAs fed
+    from global memory) and the tiled implicit GEMM (+ DN_NO_THIN_CONV=1).  Same fp32-level products, different summation order ->
+    agreement to round-off everywhere, including the borders, the ragged last tile column and the 1-channel upsampled piece."""
     torch.manual_seed(5)
     N, H, W = 4, 128, 416
     res = {}
-    for tag, env in (("thin", None), ("tiled", "1")):
-        if env is None:
-            monkeypatch.delenv("DN_NO_THIN_CONV", raising=False)
-        else:
-            monkeypatch.setenv("DN_NO_THIN_CONV", env)
+    for tag, envs in (("lds3", ()), ("thin", ("DN_NO_LDS3",)), ("tiled", ("DN_NO_LDS3", "DN_NO_THIN_CONV"))):
+        for e in ("DN_NO_LDS3", "DN_NO_THIN_CONV"):
+            monkeypatch.delenv(e, raising=False)
+        for e in envs:
+            monkeypatch.setenv(e, "1")
         _lib.load().dn_reload_knobs()
         torch.manual_seed(6)
-        if kind == "upconv0":
+        if kind.startswith("upconv0"):
             mod = nn.ConvTranspose2d(32, 16, 4, 2, 1).to(DEV)
             layer = engine.ConvLayer(mod, transposed=True)
             x = engine.Act(torch.randn(N, H // 2, W // 2, 32, device=DEV), N, H // 2, W // 2, 32)
-            y, _, _ = engine.conv_forward(layer, [engine.Piece(x)], ACT_LEAKY, 0.1, 0.0)
-            outs = [y]
+            if kind == "upconv0":
+                y, _, _ = engine.conv_forward(layer, [engine.Piece(x)], ACT_LEAKY, 0.1, 0.0)
+                outs = [y]
+            else:
+                dy = torch.randn(N, H, W, 16, device=DEV)
+                engine.conv_dgrad(layer, dy, N, H, W, [engine.Piece(x)], (H // 2, W // 2))
+                outs = [x.grad]
         else:
             mod = nn.Conv2d(17, 16, 3, 1, 1).to(DEV)
             layer = engine.ConvLayer(mod)
@@ -274,10 +280,15 @@ def test_thin_conv_matches_tiled_kernel(monkeypatch, kind):
         name = _lib.load().dn_last_kernel().decode()
         torch.cuda.synchronize()
         res[tag] = (outs, name)
-    assert "thin_conv_kernel" in res["thin"][1] or kind == "iconv0_dgrad"
-    assert "thin" not in res["tiled"][1]
-    for i, (got, want) in enumerate(zip(res["thin"][0], res["tiled"][0])):
-        close("%s[%d]" % (kind, i), got, want, rtol=2e-5, atol_rel=2e-6)
+    for e in ("DN_NO_LDS3", "DN_NO_THIN_CONV"):
+        monkeypatch.delenv(e, raising=False)
+    _lib.load().dn_reload_knobs()
+    assert "lds3_conv_kernel" in res["lds3"][1], res["lds3"][1]
+    assert "thin_conv_kernel" in res["thin"][1] or kind.endswith("_dgrad")
+    assert "thin" not in res["tiled"][1] and "lds3" not in res["tiled"][1]
+    for tag in ("lds3", "thin"):
+        for i, (got, want) in enumerate(zip(res[tag][0], res["tiled"][0])):
+            close("%s:%s[%d]" % (tag, kind, i), got, want, rtol=2e-5, atol_rel=2e-6)
 
 
 def test_winograd_error_vs_fp64(monkeypatch):
