@@ -42,11 +42,16 @@ def main():
         f, nf = fetch.get(k, (0.0, 0))
         w, nw = write.get(k, (0.0, 0))
         out["kernels"][k] = {"launches": max(nf, nw), "read_bytes": f * 1024.0 * 2.0 / max(nf, 1), "write_bytes": w * 1024.0 / max(nw, 1)}
-    ad = out["kernels"].get("dn::adam_kernel")
-    if ad:
-        out["calibration"] = {"kernel": "dn::adam_kernel", "expected_read_bytes": 4 * arena_bytes, "expected_write_bytes": 3 * arena_bytes,
-                              "read_measured_over_expected": ad["read_bytes"] / (4 * arena_bytes),
-                              "write_measured_over_expected": ad["write_bytes"] / (3 * arena_bytes)}
+    for name in ("dn::adam_kernel", "dn::adam_dev_kernel"):
+        ad = out["kernels"].get(name)
+        if ad and ad["write_bytes"] > 0:
+            # with the per-bucket update (FusedAdam.overlap_backward, the default at 32 images) one launch covers one gradient bucket:
+            # the average launch is 1/k of the arena, k = the number of buckets
+            k = max(1, int(round(3 * arena_bytes / ad["write_bytes"])))
+            out["calibration"] = {"kernel": name, "launches_per_arena_pass": k, "expected_read_bytes": 4 * arena_bytes, "expected_write_bytes": 3 * arena_bytes,
+                                  "read_measured_over_expected": k * ad["read_bytes"] / (4 * arena_bytes),
+                                  "write_measured_over_expected": k * ad["write_bytes"] / (3 * arena_bytes)}
+            break
     print(json.dumps(out, indent=1))
 
 
