@@ -2104,6 +2104,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
   if (stem3_conv_eligible(d, p)) return launch_stem3_conv(p, s);
   if (stem_eligible(d, p)) return launch_stem(p, s);
   if (lds3_conv_eligible(d, p)) return launch_lds3_conv(d, p, s);
+  if (lds3k_conv_eligible(d, p)) return launch_lds3k_conv(d, p, s);
   if (thin_conv_eligible(d, p)) return launch_thin_conv(p, s);
   // Few row tiles (the 4x13 / 8x26 decoder levels at b32: 13-52 tiles of 128 rows) leave most of the 256 CUs without a block;
   // 64-row tiles double the block count at the same per-wave MFMA density along N.  Not with batch statistics: the

@@ -226,6 +226,9 @@ int launch_wgrad_reduce(const IgemmParams& p, float* dw, hipStream_t stream);   
 // dn_wgrad_x3.hip: the tiled weight gradient with three-piece arithmetic on the bf16 matrix cores (64 / 128-wide n tiles, float4 operands)
 bool wgrad_x3_eligible(const IgemmParams& p);
 int launch_wgrad_x3(const IgemmParams& p, hipStream_t stream);
+// dn_lds3k.hip: the 8-wave form (roles = phase x M tile x K quarter) for iconv1 / upconv1
+bool lds3k_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
+int launch_lds3k_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t stream);
 bool stem3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_stem3_conv(const IgemmParams& p, hipStream_t stream);
 

@@ -90,6 +90,8 @@ CONV_CASES = [
     ("3x3_elu",           (16,),        (False,),          16, 3, 1, 1, False, 0, 1, 8, 8, ACT_ELU, False),
     ("convT_k4s2p1",      (64,),        (False,),          32, 4, 2, 1, True, 0, 2, 6, 10, ACT_LEAKY, False),
     ("convT_k4s2p1_big",  (512,),       (False,),          256, 4, 2, 1, True, 0, 2, 4, 13, ACT_LEAKY, False),
+    ("convT_k4s2p1_64_32_tiles", (64,), (False,),          32, 4, 2, 1, True, 0, 8, 30, 100, ACT_LEAKY, False),   # lds3k: upconv1 (8-wave roles, ragged tiles)
+    ("3x3_iconv1_tiles",  (32, 64, 1),  (False, False, True), 32, 3, 1, 1, False, 0, 3, 60, 200, ACT_LEAKY, False),  # lds3k: K-split roles, ragged tiles
     ("convT_k4s2p1_32_16", (32,),       (False,),          16, 4, 2, 1, True, 0, 2, 9, 21, ACT_LEAKY, False),     # lds3: upconv0 (four phases / stride-2 gather)
     ("convT_k4s2p1_32_16_tiles", (32,), (False,),          16, 4, 2, 1, True, 0, 3, 20, 70, ACT_LEAKY, False),
     ("convT_k3s2p1op1",   (32,),        (False,),          16, 3, 2, 1, True, 1, 2, 5, 7, ACT_RELU, False),
