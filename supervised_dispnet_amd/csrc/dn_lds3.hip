@@ -79,7 +79,7 @@ struct Lds3Cfg {
   static_assert(TW % 16 == 0 && PT_PER_WAVE % 2 == 0, "pixel tiles are processed in pairs");
 };
 
-template <int CG, int NKS, bool HAS1, int ROLES, int STRIDE, int TH, int TW, int ROWS, int COLS>
+template <int CG, int NKS, bool HAS1, int ROLES, int STRIDE, int TH, int TW, int ROWS, int COLS, bool PIPE>
 __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, const Lds3Geo geo) {
   using Cfg = Lds3Cfg<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS>;
   constexpr int C = 8 * CG;
@@ -240,9 +240,8 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
         dbase[u] = ty * COLS + tx16 * 16 + j;
         acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 b[2][3];
+      // B fragments of K-step ks for both pixel tiles (the 1-channel piece: gathered + split for the lanes whose slot it is)
+      auto load_b = [&](int ks, bf16x8 (&b)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -265,12 +264,34 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
             }
           }
         }
-        // x . w partial products, smallest first: (w0 x2) (w0 x1) (w1 x1) (w0 x0) (w1 x0) (w2 x0)
-        constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+      };
+      // x . w partial products, smallest first: (w0 x2) (w0 x1) (w1 x1) (w0 x0) (w1 x0) (w2 x0)
+      constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+      if constexpr (PIPE) {
+        // software pipeline: the LDS reads of K-step ks + 1 are ISSUED before the matrix instructions of K-step ks (the compiler's own
+        // order waited for each K-step's reads right in front of its first matrix instruction)
+        bf16x8 bq[2][2][3];
+        load_b(0, bq[0]);
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks + 1 < NKS) load_b(ks + 1, bq[(ks + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][AS[q]], b[u][BS[q]], acc[u], 0, 0, 0);
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][AS[q]], bq[ks & 1][u][BS[q]], acc[u], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          bf16x8 b[2][3];
+          load_b(ks, b);
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][AS[q]], b[u][BS[q]], acc[u], 0, 0, 0);
+        }
       }
       // ---- epilogue: lane (j, g) holds output channels n0 .. n0 + 3 of grid point (gy, gx0 + 16 * tx16 + j)
 #pragma unroll
@@ -577,7 +598,8 @@ bool lds3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) { return ld
 template <int CG, int NKS, bool HAS1, int ROLES, int STRIDE, int TH, int TW, int ROWS, int COLS>
 static int lds3_launch(const IgemmParams& p, const Lds3Geo& geo, hipStream_t stream) {
   using Cfg = Lds3Cfg<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS>;
-  auto kernel = lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS>;
+  static const bool nopipe = getenv("DN_LDS3_NOPIPE") != nullptr;
+  auto kernel = nopipe ? lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, false> : lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, true>;
   const size_t lds = Cfg::LDS;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -589,7 +611,8 @@ static int lds3_launch(const IgemmParams& p, const Lds3Geo& geo, hipStream_t str
   int blocks = geo.ntiles < 512 ? geo.ntiles : 512;            // two resident blocks per CU, persistent over the tiles
   blocks = (blocks + 7) / 8 * 8;
   DN_LAUNCH(kernel, dim3(blocks), dim3(256), lds, stream, p, geo);
-  set_last_kernel("dn::lds3_conv_kernel<%d, %d, %s, %d, %d, %d, %d, %d, %d>", CG, NKS, HAS1 ? "true" : "false", ROLES, STRIDE, TH, TW, ROWS, COLS);
+  set_last_kernel("dn::lds3_conv_kernel<%d, %d, %s, %d, %d, %d, %d, %d, %d, %s>", CG, NKS, HAS1 ? "true" : "false", ROLES, STRIDE, TH, TW, ROWS, COLS,
+                  nopipe ? "false" : "true");
   return check_launch("lds3_conv_kernel");
 }
 
