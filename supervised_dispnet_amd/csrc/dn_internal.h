@@ -222,6 +222,9 @@ int launch_lds3_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t st
 bool lds3_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);
 size_t lds3_wgrad_workspace_bytes(const IgemmParams& p);
 int launch_lds3_wgrad(const dn_conv_desc* fwd, IgemmParams& p, float* dw, hipStream_t stream);
+bool lds3k_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p);      // 96-channel form (iconv1), eight waves
+size_t lds3k_wgrad_workspace_bytes(const IgemmParams& p);
+int launch_lds3k_wgrad(const dn_conv_desc* fwd, IgemmParams& p, float* dw, hipStream_t stream);
 int launch_wgrad_reduce(const IgemmParams& p, float* dw, hipStream_t stream);   // dn_conv.hip: fixed-order sum of p.splits slabs of p.ws -> dw
 // dn_wgrad_x3.hip: the tiled weight gradient with three-piece arithmetic on the bf16 matrix cores (64 / 128-wide n tiles, float4 operands)
 bool wgrad_x3_eligible(const IgemmParams& p);

@@ -455,3 +455,320 @@ int launch_lds3_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStrea
 }
 
 }  // namespace dn
+
+// ---- iconv1 form (second half of round 4): 96 input channels in one or two NHWC operands (+ the 1-channel nearest-x2 piece), <= 32 output
+// channels.  55 accumulator tiles (9 taps x 6 sixteen-channel groups + the 1-channel piece) x 2 M tiles do not fit one wave: ONE block of
+// eight waves per CU, each wave owning whole (channel group, tap row) UNITS of three tap columns -- its own output columns for ALL pixels,
+// so no wave ever meets another.  18 units over 8 waves as (3, 3, 2, 2, 2, 2, 2, 2) puts 5 / 5 / 4 / 4 units on the four SIMDs.  A tile is
+// 2 rows x 32 pixels (input planes of 4 rows x 96 channels x three pieces = 113 KB of LDS); staging, funnel-shifted taps and the
+// fixed-order slab fold are the 16-channel form's.
+namespace dn {
+
+constexpr int WK_TH = 2;
+constexpr int WK_GSTR = WK_TH * 32 * 2 + 16;      // 144: bytes between the dy planes of two output channels
+constexpr int WK_GPIECE = 32 * WK_GSTR;
+constexpr int WK_XROWS = WK_TH + 2;
+constexpr int WK_XSTR = WK_XROWS * WG_XROWB + 16; // 400: bytes between the planes of two input channels
+constexpr int WK_NCI = 96;
+constexpr int WK_XPIECE = WK_NCI * WK_XSTR;
+constexpr int WK_LDS = 3 * WK_GPIECE + 3 * WK_XPIECE + WK_XROWS * WG_DCOLS * 4;
+
+template <bool HAS1>
+__global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p, const WgGeo geo, int c0) {
+  extern __shared__ __align__(16) char lds[];
+  char* Gp = lds;
+  char* Xp = lds + 3 * WK_GPIECE;
+  float* Dp = reinterpret_cast<float*>(lds + 3 * WK_GPIECE + 3 * WK_XPIECE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const KOperand& S0 = p.in[0];
+  const bool two = p.n_in - (HAS1 ? 1 : 0) == 2;
+  const KOperand& S1 = p.in[two ? 1 : 0];
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S0.p), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S1.p), 0, 0x80000000u, 0x00020000);
+  const KOperand& SD = p.in[HAS1 ? p.n_in - 1 : 0];
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SD.p), 0, 0x80000000u, 0x00020000);
+
+  // units of this wave: u0 = wave, u1 = wave + 8, u2 = wave + 16 (waves 0 and 1 only); unit = tap row * 6 + channel group
+  const int nunits = wave < 2 ? 3 : 2;
+  f32x4 acc[3][3][2];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[u][x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // the 1-channel piece's tile: wave 2
+  const int dtap = j < 9 ? j : 0;
+  const int doff = (dtap / 3) * WG_DCOLS + (dtap % 3);
+
+  f32x4 va[8], vb[8];
+  float dv = 0.f;
+  // staging jobs: x job = (row 0..3, column group 0..5, channel quad 0..23) -> 576: round A = jobs tid, round B = jobs 512 + tid (tid < 64);
+  // dy job = (row 0..1, column group 0..3, channel quad 0..7) -> 64: round B, threads 64..127
+  auto x_job = [&](int job, int gy0, int gx0, int n, f32x4 (&v)[8], bool live) __attribute__((always_inline)) {
+    const int quad = job % 24, rc = job / 24, cgp = rc % 6, row = rc / 6;
+    const int iy = gy0 - 1 + row;
+    const bool second = two && 4 * quad >= c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ix = gx0 + 8 * cgp - 8 + i;
+      const bool need = cgp == 0 ? i == 7 : (cgp == 5 ? i == 0 : true);
+      const bool ok = live && need && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const int o0 = (n * (int)S0.sn + iy * (int)S0.sh + ix * (int)S0.sw + 4 * quad) * 4;
+      const int o1 = (n * (int)S1.sn + iy * (int)S1.sh + ix * (int)S1.sw + 4 * quad - c0) * 4;
+      const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0, (ok && !second) ? o0 : -1, 0, 0));
+      if (two) {
+        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, (ok && second) ? o1 : -1, 0, 0));
+        v[i] = a + b;                               // (one of the two is the hardware's zero fill)
+      } else {
+        v[i] = a;
+      }
+    }
+  };
+  auto issue_loads = [&](int t) __attribute__((always_inline)) {
+    const int txb = t % geo.tilesX, q1 = t / geo.tilesX;
+    const int tyb = q1 % geo.tilesY, n = q1 / geo.tilesY;
+    const int gy0 = tyb * WK_TH, gx0 = txb * WG_TW;
+    x_job(tid, gy0, gx0, n, va, true);
+    if (tid < 64) {
+      x_job(512 + tid, gy0, gx0, n, vb, true);
+    } else if (tid < 128) {
+      const int job = tid - 64, cq = job & 7, pxg = job >> 3, row = pxg >> 2, cgp = pxg & 3;
+      const int gy = gy0 + row;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gx = gx0 + 8 * cgp + i;
+        const bool ok = gy < p.GH && gx < p.GW && 4 * cq < p.Ntot;
+        const int off = (((n * p.GH + gy) * p.GW + gx) * p.Ntot + 4 * cq) * 4;
+        vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : -1, 0, 0));
+      }
+    }
+    if constexpr (HAS1) {
+      const int row = tid / 34, col = tid - row * 34;
+      const int iy = gy0 - 1 + row, ix = gx0 - 1 + col;
+      const bool ok = tid < WK_XROWS * 34 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const int off = (n * (int)SD.sn + (iy >> SD.up) * (int)SD.sh + (ix >> SD.up) * (int)SD.sw) * 4;
+      dv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, ok ? off : -1, 0, 0));
+    }
+  };
+  auto store_x = [&](int job, const f32x4 (&v)[8]) __attribute__((always_inline)) {
+    const int quad = job % 24, rc = job / 24, cgp = rc % 6, row = rc / 6;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f[8] = {v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e]};
+      bf16x8 h, m, l;
+      wg_split3(f, h, m, l);
+      char* dst = Xp + (4 * quad + e) * WK_XSTR + row * WG_XROWB + cgp * 16;
+      *reinterpret_cast<bf16x8*>(dst) = h;
+      *reinterpret_cast<bf16x8*>(dst + WK_XPIECE) = m;
+      *reinterpret_cast<bf16x8*>(dst + 2 * WK_XPIECE) = l;
+    }
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+    store_x(tid, va);
+    if (tid < 64) {
+      store_x(512 + tid, vb);
+    } else if (tid < 128) {
+      const int job = tid - 64, cq = job & 7, pxg = job >> 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f[8] = {vb[0][e], vb[1][e], vb[2][e], vb[3][e], vb[4][e], vb[5][e], vb[6][e], vb[7][e]};
+        bf16x8 h, m, l;
+        wg_split3(f, h, m, l);
+        char* dst = Gp + (4 * cq + e) * WK_GSTR + pxg * 16;
+        *reinterpret_cast<bf16x8*>(dst) = h;
+        *reinterpret_cast<bf16x8*>(dst + WK_GPIECE) = m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * WK_GPIECE) = l;
+      }
+    }
+    if constexpr (HAS1) {
+      const int row = tid / 34, col = tid - row * 34;
+      if (tid < WK_XROWS * 34) Dp[row * WG_DCOLS + col] = dv;
+    }
+  };
+
+  const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
+  const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
+  constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+  if (band_lo + local < band_hi) issue_loads(band_lo + local);
+  for (int t = band_lo + local; t < band_hi; t += nlocal) {
+    store_lds();
+    __syncthreads();
+    if (t + nlocal < band_hi) issue_loads(t + nlocal);
+#pragma unroll 1
+    for (int r = 0; r < WK_TH; ++r) {                                  // K-step: tile row r, pixels 8 g .. 8 g + 7 per lane group
+      bf16x8 a[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int P = 0; P < 3; ++P) a[m][P] = *reinterpret_cast<const bf16x8*>(Gp + P * WK_GPIECE + (16 * m + j) * WK_GSTR + (r * 32 + 8 * g) * 2);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (u < nunits) {
+          const int unit = wave + 8 * u, c16 = unit % 6, ty = unit / 6;
+          const char* rowb = Xp + (16 * c16 + j) * WK_XSTR + (r + ty) * WG_XROWB + (8 * g + 8) * 2;
+          u32x4 c[3];
+          unsigned lf[3], rt[3];
+#pragma unroll
+          for (int P = 0; P < 3; ++P) {
+            c[P] = *reinterpret_cast<const u32x4*>(rowb + P * WK_XPIECE);
+            lf[P] = *reinterpret_cast<const unsigned*>(rowb + P * WK_XPIECE - 4);
+            rt[P] = *reinterpret_cast<const unsigned*>(rowb + P * WK_XPIECE + 16);
+          }
+          bf16x8 bm[3], bz[3], bp[3];
+#pragma unroll
+          for (int P = 0; P < 3; ++P) {
+            const u32x4 m4 = u32x4{__builtin_amdgcn_alignbit(c[P][0], lf[P], 16), __builtin_amdgcn_alignbit(c[P][1], c[P][0], 16),
+                                   __builtin_amdgcn_alignbit(c[P][2], c[P][1], 16), __builtin_amdgcn_alignbit(c[P][3], c[P][2], 16)};
+            const u32x4 p4 = u32x4{__builtin_amdgcn_alignbit(c[P][1], c[P][0], 16), __builtin_amdgcn_alignbit(c[P][2], c[P][1], 16),
+                                   __builtin_amdgcn_alignbit(c[P][3], c[P][2], 16), __builtin_amdgcn_alignbit(rt[P], c[P][3], 16)};
+            bm[P] = __builtin_bit_cast(bf16x8, m4);
+            bz[P] = __builtin_bit_cast(bf16x8, c[P]);
+            bp[P] = __builtin_bit_cast(bf16x8, p4);
+          }
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              acc[u][0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], bm[BS[q]], acc[u][0][m], 0, 0, 0);
+              acc[u][1][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], bz[BS[q]], acc[u][1][m], 0, 0, 0);
+              acc[u][2][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], bp[BS[q]], acc[u][2][m], 0, 0, 0);
+            }
+        }
+      }
+      if constexpr (HAS1) {
+        if (wave == 2) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = Dp[r * WG_DCOLS + 8 * g + e + doff];
+            v[e] = j < 9 ? x : 0.f;
+          }
+          bf16x8 b[3];
+          wg_split3(v, b[0], b[1], b[2]);
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) accd[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], b[BS[q]], accd[m], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- every wave owns its columns: straight into the block's slab ws[block][co][k]
+  const int Kp = p.ph[0].nchunks * kChunk;
+  const int C1 = WK_NCI - c0;
+  const int kb1 = ((9 * c0 + kChunk - 1) / kChunk) * kChunk;
+  const int kbs = two ? kb1 + ((9 * C1 + kChunk - 1) / kChunk) * kChunk : ((9 * WK_NCI + kChunk - 1) / kChunk) * kChunk;
+  float* slab = p.ws + (long long)blockIdx.x * geo.slab;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    if (u < nunits) {
+      const int unit = wave + 8 * u, c16 = unit % 6, ty = unit / 6;
+      const int ci = 16 * c16 + j;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const int tap = 3 * ty + x;
+        const int k = (two && ci >= c0) ? kb1 + tap * C1 + (ci - c0) : tap * (two ? c0 : WK_NCI) + ci;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int co = 16 * m + 4 * g + e;
+            if (co < p.Ntot) slab[(long long)co * Kp + k] = acc[u][x][m][e];
+          }
+      }
+    }
+  }
+  if constexpr (HAS1) {
+    if (wave == 2 && j < 9) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = 16 * m + 4 * g + e;
+          if (co < p.Ntot) slab[(long long)co * Kp + kbs + j] = accd[m][e];
+        }
+    }
+  }
+}
+
+// 0 none, 1 without / 2 with the trailing 1-channel piece
+static int lds3k_wgrad_form(const dn_conv_desc* d, const IgemmParams& p) {
+  static const bool off = getenv("DN_NO_LDS3K_WGRAD") != nullptr;
+  if (off || knobs().no_lds3_wgrad || d->compute != DN_COMPUTE_F32X3) return 0;
+  if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return 0;
+  if (d->IH != d->OH || d->IW != d->OW || p.Ntot > 32 || p.Ntot < 17 || (p.Ntot & 3)) return 0;
+  if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) return 0;
+  for (int t = 0; t < 9; ++t)
+    if (p.tdy[t] != t / 3 - 1 || p.tdx[t] != t % 3 - 1) return 0;
+  int nmain = p.n_in;
+  bool has1 = false;
+  if (p.n_in >= 2 && p.in[p.n_in - 1].C == 1) {
+    const KOperand& b = p.in[p.n_in - 1];
+    if (!(b.small && b.scale == nullptr)) return 0;
+    has1 = true;
+    nmain = p.n_in - 1;
+  }
+  if (nmain < 1 || nmain > 2) return 0;
+  int ctot = 0;
+  for (int i = 0; i < nmain; ++i) {
+    const KOperand& a = p.in[i];
+    if (!(a.vec && a.small && a.up == 0 && a.scale == nullptr && a.C % 4 == 0)) return 0;
+    ctot += a.C;
+  }
+  if (ctot != WK_NCI) return 0;
+  const int ntiles = p.N * ((p.GH + WK_TH - 1) / WK_TH) * ((p.GW + WG_TW - 1) / WG_TW);
+  if (ntiles < 192) return 0;
+  return has1 ? 2 : 1;
+}
+
+static int lds3k_wgrad_blocks(const IgemmParams& p) {
+  const int ntiles = p.N * ((p.GH + WK_TH - 1) / WK_TH) * ((p.GW + WG_TW - 1) / WG_TW);
+  int blocks = ntiles < 256 ? ntiles : 256;
+  return (blocks + 7) / 8 * 8;
+}
+
+bool lds3k_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) { return lds3k_wgrad_form(d, p) != 0; }
+
+size_t lds3k_wgrad_workspace_bytes(const IgemmParams& p) {
+  return (size_t)lds3k_wgrad_blocks(p) * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
+}
+
+int launch_lds3k_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStream_t stream) {
+  const int form = lds3k_wgrad_form(d, p);
+  WgGeo geo;
+  geo.tilesX = (p.GW + WG_TW - 1) / WG_TW;
+  geo.tilesY = (p.GH + WK_TH - 1) / WK_TH;
+  geo.ntiles = p.N * geo.tilesX * geo.tilesY;
+  geo.per_xcd = (geo.ntiles + 7) / 8;
+  geo.slab = (long long)p.Npad * p.ph[0].nchunks * kChunk;
+  const int blocks = lds3k_wgrad_blocks(p);
+  const int c0 = p.in[0].C;
+  hipError_t e = hipSuccess;
+  if (form == 2) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3k_wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS);
+    if (e == hipSuccess) DN_LAUNCH(lds3k_wgrad_kernel<true>, dim3(blocks), dim3(512), (size_t)WK_LDS, stream, p, geo, c0);
+    set_last_kernel("dn::lds3k_wgrad_kernel<true>");
+  } else if (form == 1) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3k_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS);
+    if (e == hipSuccess) DN_LAUNCH(lds3k_wgrad_kernel<false>, dim3(blocks), dim3(512), (size_t)WK_LDS, stream, p, geo, c0);
+    set_last_kernel("dn::lds3k_wgrad_kernel<false>");
+  } else {
+    set_error("launch_lds3k_wgrad: no form");
+    return DN_ERR_UNSUPPORTED;
+  }
+  if (e != hipSuccess) {
+    set_error("lds3k wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return DN_ERR_LAUNCH;
+  }
+  int rc = check_launch("lds3k_wgrad_kernel");
+  if (rc != DN_OK) return rc;
+  p.splits = blocks;
+  return launch_wgrad_reduce(p, dw, stream);
+}
+
+}  // namespace dn
