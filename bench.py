@@ -66,7 +66,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 matrix peak (the p
 X3_PRODUCTS = 6                      # f32x3: six bf16 partial products per fp32 multiply
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0               # same guide: HBM3E spec (6.29 TB/s measured float4 copy there)
-THIN_KERNELS = ("stem3_conv_kernel", "lds3_conv_kernel", "lds3_wgrad_kernel", "stem_conv_kernel", "thin_conv_kernel", "thin_wgrad_kernel", "head_fwd", "head_dgrad", "head_wgrad", "igemm_conv_u32_kernel<128, 32, 32, 32>",
+THIN_KERNELS = ("stem3_conv_kernel", "lds3_conv_kernel", "lds3k_conv_kernel", "lds3_wgrad", "lds3k_wgrad", "stem_conv_kernel", "thin_conv_kernel", "thin_wgrad_kernel", "head_fwd", "head_dgrad", "head_wgrad", "igemm_conv_u32_kernel<128, 32, 32, 32>",
                 "igemm_wgrad_kernel<32, 32, 32, true>", "igemm_wgrad_u32_kernel<32, 32, 32, false>")
 WINO_EXEC = 16.0 / 36.0              # F(2x2,3x3): 16 element-wise products per 2x2 tile instead of 36 MACs
 
