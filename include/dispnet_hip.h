@@ -531,6 +531,9 @@ int dn_flip_w(const float* src, const uint8_t* flip, int32_t B, int32_t H, int32
 int dn_ubench_copy(const float* src, float* dst, int64_t n, dn_stream_t stream);
 int64_t dn_ubench_mfma_f32_flops(int32_t blocks, int32_t iters);
 int dn_ubench_mfma_f32(float* out, int32_t blocks, int32_t iters, dn_stream_t stream);
+/* store-only probe: n floats (multiple of 1024) written with 16-byte stores; mode 0: 1 KiB contiguous per wave instruction, mode 1: 64-byte
+ * segments at a 256-byte stride (the four-instruction pattern of a 64-channel result whose lanes hold 4 channels of one pixel). */
+int dn_ubench_store(float* dst, int64_t n, int32_t mode, dn_stream_t stream);
 /* Block -> XCD placement probe: out[x + gx*(y + gy*z)] = HW_REG_XCC_ID of block (x, y, z) of a (gx, gy, gz) grid.  The K-split paths
  * (dn_conv_desc.splitk_ws) meet the partial tiles of one output tile in ONE XCD's L2 (no agent-scope fence); that is only correct if
  * all blocks with the same blockIdx.x land on the same XCD when gridDim.x is a multiple of 8 -- observed on MI355X, promised by

@@ -47,6 +47,23 @@ __global__ void __launch_bounds__(256) ubench_mfma_kernel(float* out, int iters)
   out[(long long)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// store-only patterns: mode 0 = every instruction writes 1 KiB contiguous (lane l: 16 bytes at 16 l); mode 1 = the first layer's pattern
+// before round 4's store shuffle: four instructions per 16-pixel tile, instruction m gives pixel j (256-byte rows) its bytes 64 m .. 64 m + 63
+// (lane (j, g): 16 bytes at 256 j + 64 m + 16 g); mode 2 = 16 pixels x 64 bytes contiguous rows (a 16-channel layer).  n4 = float4 count.
+__global__ void __launch_bounds__(256) ubench_store_kernel(f32x4* __restrict__ dst, long long n4, int mode) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const f32x4 v = f32x4{1.f, 2.f, 3.f, (float)lane};
+  const long long ntiles = n4 / 256;                      // a "tile" = 16 pixels x 256 bytes = 4 KiB = 256 float4
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
+    f32x4* base = dst + t * 256;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (mode == 1) base[j * 16 + m * 4 + g] = v;
+      else base[m * 64 + lane] = v;
+    }
+  }
+}
+
 // one int per block: the XCD (HW_REG_XCC_ID, 0..7) the block was dispatched to, at its linear block index
 __global__ void __launch_bounds__(64) xcd_probe_kernel(int* __restrict__ out) {
   if (threadIdx.x == 0) {
@@ -78,6 +95,12 @@ int dn_ubench_mfma_f32(float* out, int32_t blocks, int32_t iters, dn_stream_t st
   DN_REQUIRE(out && blocks > 0 && iters > 0, DN_ERR_BAD_ARG, "dn_ubench_mfma_f32: bad argument");   // out: blocks * 256 floats
   DN_LAUNCH(ubench_mfma_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), out, iters);
   return check_launch("ubench_mfma_kernel");
+}
+
+int dn_ubench_store(float* dst, int64_t n, int32_t mode, dn_stream_t stream) {
+  DN_REQUIRE(dst && n > 0 && n % 1024 == 0 && ((uintptr_t)dst & 15) == 0, DN_ERR_BAD_ARG, "dn_ubench_store: need a 16-byte aligned buffer of a multiple of 1024 floats");
+  DN_LAUNCH(ubench_store_kernel, dim3(256 * 8), dim3(256), 0, as_stream(stream), (f32x4*)dst, (long long)(n / 4), mode);
+  return check_launch("ubench_store_kernel");
 }
 
 int dn_xcd_probe(int32_t* out, int32_t gx, int32_t gy, int32_t gz, dn_stream_t stream) {

@@ -169,7 +169,9 @@ class TapedStep(object):
         else:
             rc = 0
             for i in range(self.segments):
-                rc = rc or self._lib.dn_tape_replay(self.tape, i)
+                rc = self._lib.dn_tape_replay(self.tape, i)
+                if rc != 0:               # a failed segment: no further collectives on top of it
+                    break
                 if i < len(self.host_calls):
                     fn, st = self.host_calls[i]
                     with torch.cuda.stream(st), engine.stream_scope():      # the stream the call was issued on when recorded

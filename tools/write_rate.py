@@ -30,6 +30,8 @@ def main():
         fill = rate(lambda: _lib.call("dn_fill", a.data_ptr(), 1.0, n, st), 4.0 * n)
         tfill = rate(lambda: a.fill_(2.0), 4.0 * n)
         copy = rate(lambda: _lib.call("dn_ubench_copy", a.data_ptr(), b.data_ptr(), n, st), 8.0 * n)
+        pat = [rate(lambda m=m: _lib.call("dn_ubench_store", a.data_ptr(), n, m, st), 4.0 * n) for m in (0, 1)]
+        print("%5d MiB: 16-byte stores, 1 KiB contiguous per instruction %7.0f GB/s | 64-byte segments at 256-byte stride (4 instructions per row) %7.0f GB/s" % (mb, pat[0], pat[1]))
         print("%5d MiB: dn_fill (store only) %7.0f GB/s | torch fill_ %7.0f GB/s | dn_ubench_copy (read + write) %7.0f GB/s" % (mb, fill, tfill, copy))
         del a, b
 

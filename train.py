@@ -395,8 +395,22 @@ class TapedTrainer(object):
             why = "needs -p 1 -m 0 -s 0 (the weighted sum of loss terms is framework-side arithmetic)"
         elif not hasattr(optimizer, "arena"):
             why = "needs the fused Adam (not --sgd / --diff-lr)"
+        else:
+            from supervised_dispnet_amd.distributed import data_parallel_world
+            if data_parallel_world() > 1 and (args.loss.startswith("Multi") or args.loss == "DORN"):
+                # decided up front: found out by a failed recording, the first batch's forward ran twice (BatchNorm
+                # running statistics updated twice) before the eager fallback took over
+                why = "--loss {} exchanges whole-batch statistics between the ranks inside the forward pass (a host-side collective)".format(args.loss)
+        # every rank takes the same decision (one rank on the tape and another eager would interleave their collectives differently)
+        if not self._agree(why is None) and why is None:
+            why = "another rank cannot use the tape"
         if why is not None:
             self._off(why)
+
+    def _agree(self, ok):
+        from supervised_dispnet_amd.distributed import agree_all_ranks
+        dev = next(self.net.parameters()).device
+        return agree_all_ranks(ok, device=dev if dev.type == "cuda" else None)
 
     def close(self):
         """End of training: free the tape now (graph.TapedStep.close -- a DataLoader worker forked later must not inherit it as garbage)."""
@@ -437,11 +451,17 @@ class TapedTrainer(object):
                 self.ts = TapedStep(self._step, optimizer=self.opt, warmup=0, static_inputs=(self.img, self.gt))
                 loss = self.ts()                                   # recorded = executed
                 self.state = "recorded"
+                if not self._agree(True):
+                    self._off("the recording failed on another rank")
                 return float(loss.item())
             if self.state == "recorded":
                 st = [self.opt.arena.flat_p, self.opt.exp_avg, self.opt.exp_avg_sq, self.opt._dev["step"], self.opt._dev["derived"]]
                 st += [b for b in self.net.buffers() if b.is_cuda]
                 same, worst = self.ts.verify(st)                   # (leaves the state one step further: this batch's eager step)
+                if same and not self._agree(True):
+                    same, worst = False, float("nan")              # (another rank's check failed: all ranks leave the tape together)
+                elif not same:
+                    self._agree(False)
                 if same:
                     self.state = "verified"
                     if self.rank == 0:
@@ -451,9 +471,11 @@ class TapedTrainer(object):
                     self._off("replay differs from the eager step on the second batch, max |diff| {:.3g}".format(worst))
                 return float(self.ts.last_eager_out[0].item())     # (either way this batch's step was taken: the check's eager one)
             return float(self.ts().item())
-        except Exception as e:          # noqa: BLE001 -- a setting the tape refuses (e.g. whole-batch loss statistics under data parallelism)
+        except Exception as e:          # noqa: BLE001 -- a setting the tape refuses
             if self.state == "verified":
                 raise
+            if self.state in ("new", "recorded"):
+                self._agree(False)       # (the peers wait in the agreement that follows their recording / their check)
             self._off("{}: {}".format(type(e).__name__, str(e)[:160]))
             return None
 
