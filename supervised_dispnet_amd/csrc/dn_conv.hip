@@ -1304,6 +1304,149 @@ __global__ void __launch_bounds__(256, 2) igemm_conv_x3_kernel(const IgemmParams
   conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, As, m0, n0);
 }
 
+// ------------------------------------------------------------------ forward family, three-piece arithmetic, 128 x 128 tile (round 4)
+// igemm_conv_x3_kernel splits (BM + BN) x 32 values per 96 matrix instructions of a 128 x 64 / 64 x 128 block -- with K = C_in only (the
+// 1x1 convolutions of ResNet bottlenecks: 13.8 of config 4's 39 ms) it is bound by that split, 85-89 TFLOP/s fp32-equivalent.  This
+// variant takes the layers whose ONE operand has C % 32 == 0 (every K chunk lies inside one tap: block-uniform tap and channel base) on
+// a 128 x 128 tile: (128 + 128) x 32 values per 192 matrix instructions, wave tile 64 x 64 (2 x 2 tiles of 32 x 32).  LDS rows of
+// [3 pieces][32 bf16] + 16 bytes (208: the 16-lane fragment reads touch 16 distinct 16-byte slots), ONE buffer + the next chunk's eight
+// float4 loads per thread in registers under the current chunk's matrix instructions (two blocks per CU fill each other's staging
+// phase).  Epilogue: the shared one (bias, activation, BatchNorm partials, whole-pixel tile stores).
+constexpr int X3B_ROWB = 208;
+
+template <bool HA>
+__global__ void __launch_bounds__(256, 2) igemm_conv_x3b_kernel(const IgemmParams p) {
+  constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MI = 2, NI = 2;
+  constexpr int PIECE = 64;                                   // bytes of one piece of a row (32 bf16)
+  extern __shared__ __align__(16) float smem[];
+  char* T = reinterpret_cast<char*>(smem);                    // [BM + BN rows][X3B_ROWB]; reused by the epilogue's [BM][BN + 4] float tile
+  int* rowpix = reinterpret_cast<int*>(T + (size_t)BM * (BN + 4) * sizeof(float));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int MT = (p.M + BM - 1) / BM, NT = p.Npad / BN;
+  const int per = (MT * NT + 7) >> 3;
+  const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;
+  const int m0 = (q / NT) * BM, n0 = (q % NT) * BN;
+  const KPhase ph = p.ph[blockIdx.z];
+  const int nchunks = ph.nchunks, Kp = nchunks * kChunk;
+  const KOperand& S = p.in[0];
+  const int cpt = S.C / kChunk;                               // chunks per tap
+
+  for (int r = tid; r < BM; r += 256) {
+    int m = m0 + r, pix = -1;
+    if (m < p.M) {
+      unsigned gx, gy;
+      const unsigned t = fastdiv((unsigned)m, (unsigned)p.GW, p.mGW, &gx);
+      const int n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+      const int oy = (int)gy * p.osy + ph.ooy, ox = (int)gx * p.osx + ph.oox;
+      if (oy < p.OH && ox < p.OW) pix = (n * p.OH + oy) * p.OW + ox;
+    }
+    rowpix[r] = pix;
+  }
+  // staging assignment: K group g (4 floats) of rows r0 + 32 i of A (pixels) and of B (output channels)
+  const int g = tid & 7, r0 = tid >> 3;
+  int rbase[4], rby[4], rbx[4];
+  bool rvalid[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    rvalid[i] = m < p.M;
+    unsigned gx, gy;
+    const unsigned t = fastdiv(rvalid[i] ? (unsigned)m : 0u, (unsigned)p.GW, p.mGW, &gx);
+    const int n = (int)fastdiv(t, (unsigned)p.GH, p.mGH, &gy);
+    rby[i] = (int)gy * p.sy;
+    rbx[i] = (int)gx * p.sx;
+    rbase[i] = n * (int)S.sn + 4 * g;
+  }
+  const float* wbase = p.w + ph.w_off + (long long)(n0 + r0) * Kp + 4 * g;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 av[4], bv[4], sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned okm = 0;
+  auto issue_loads = [&](int kc) __attribute__((always_inline)) {
+    const int tap = kc / cpt, c0 = (kc - tap * cpt) * kChunk;
+    const int dy = p.tdy[ph.tap0 + tap], dx = p.tdx[ph.tap0 + tap];
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = rby[i] + dy, ix = rbx[i] + dx;
+      const bool ok = rvalid[i] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      int off = rbase[i] + iy * (int)S.sh + ix * (int)S.sw + c0;
+      asm volatile("" : "+v"(off));
+      off = ok ? off : 0;
+      av[i] = *reinterpret_cast<const f32x4*>(S.p + off);
+      okm |= ok ? (1u << i) : 0u;
+      bv[i] = *reinterpret_cast<const f32x4*>(wbase + (long long)(32 * i) * Kp + kc * kChunk);
+    }
+    if constexpr (HA) {
+      sc4 = *reinterpret_cast<const f32x4*>(S.scale + c0 + 4 * g);
+      sh4 = *reinterpret_cast<const f32x4*>(S.shift + c0 + 4 * g);
+    }
+  };
+  auto split_store = [&](char* dst, const f32x4& v) __attribute__((always_inline)) {
+    const bf16x2 h0 = __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2), h1 = __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2);
+    const f32x2 ra = f32x2{v[0], v[1]} - __builtin_convertvector(h0, f32x2), rb = f32x2{v[2], v[3]} - __builtin_convertvector(h1, f32x2);
+    const bf16x2 m0_ = __builtin_convertvector(ra, bf16x2), m1_ = __builtin_convertvector(rb, bf16x2);
+    const f32x2 sa = ra - __builtin_convertvector(m0_, f32x2), sb = rb - __builtin_convertvector(m1_, f32x2);
+    const bf16x2 l0 = __builtin_convertvector(sa, bf16x2), l1 = __builtin_convertvector(sb, bf16x2);
+    *reinterpret_cast<bf16x4*>(dst) = bf16x4{h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<bf16x4*>(dst + PIECE) = bf16x4{m0_[0], m0_[1], m1_[0], m1_[1]};
+    *reinterpret_cast<bf16x4*>(dst + 2 * PIECE) = bf16x4{l0[0], l0[1], l1[0], l1[1]};
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = av[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = v[e];
+        if constexpr (HA) t = fmaxf(0.f, fmaf(t, sc4[e], sh4[e]));
+        v[e] = (okm >> i) & 1u ? t : 0.f;
+      }
+      split_store(T + (r0 + 32 * i) * X3B_ROWB + g * 8, v);
+      split_store(T + (BM + r0 + 32 * i) * X3B_ROWB + g * 8, bv[i]);
+    }
+  };
+  const int frA = (wm * WM + (lane & 31)) * X3B_ROWB + (lane >> 5) * 16;
+  const int frB = (BM + wn * WN + (lane & 31)) * X3B_ROWB + (lane >> 5) * 16;
+  constexpr int AS[6] = {2, 1, 1, 0, 0, 0}, BS[6] = {0, 0, 1, 0, 1, 2};      // x2y0, x1y0, x1y1, x0y0, x0y1, x0y2: smallest first
+  __syncthreads();
+  if (nchunks > 0) issue_loads(0);
+  for (int kc = 0; kc < nchunks; ++kc) {
+    store_lds();
+    __syncthreads();
+    if (kc + 1 < nchunks) issue_loads(kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[MI][3], b[NI][3];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int P = 0; P < 3; ++P) a[i][P] = *reinterpret_cast<const bf16x8*>(T + frA + i * 32 * X3B_ROWB + P * PIECE + ks * 32);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int P = 0; P < 3; ++P) b[j][P] = *reinterpret_cast<const bf16x8*>(T + frB + j * 32 * X3B_ROWB + P * PIECE + ks * 32);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][AS[t]], b[j][BS[t]], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  conv_epilogue<BM, BN, WM, WN>(p, acc, rowpix, smem, m0, n0);
+}
+
 // ------------------------------------------------------------------------------------------------ first layer (stem)
 // conv3x3 of a <= 4-channel image (the NCHW user tensor through its strides) to 64 channels, torchvision vgg16_bn features[0]:
 // K = 27 is one MFMA chunk, so on the tiled kernel a block's whole "main loop" is a single barrier-bound iteration and the launch
@@ -2073,6 +2216,34 @@ static int launch_conv_x3(const IgemmParams& p, hipStream_t stream) {
   return check_launch("igemm_conv_x3_kernel");
 }
 
+static bool conv_x3b_eligible(const IgemmParams& p) {
+  static const bool off = getenv("DN_NO_X3B") != nullptr;
+  if (off || p.compute != DN_COMPUTE_F32X3 || !p.uni32 || p.n_in != 1 || p.BN != 128 || p.reflect) return false;
+  const KOperand& S = p.in[0];
+  if (!(S.vec && S.small && S.up == 0 && S.C % kChunk == 0)) return false;
+  if (S.scale != nullptr && ((reinterpret_cast<uintptr_t>(S.scale) | reinterpret_cast<uintptr_t>(S.shift)) & 15)) return false;
+  const long long tiles = (long long)((p.M + 127) / 128) * (p.Npad / 128) * p.nphases;
+  return tiles >= 192;                                        // smaller grids: the 64-row tiles / K splits of igemm_conv_x3_kernel
+}
+
+static int launch_conv_x3b(const IgemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)128 * (128 + 4) * sizeof(float) + 128 * sizeof(int);
+  const int tiles = ((p.M + 127) / 128) * (p.Npad / 128);
+  dim3 grid((tiles + 7) / 8 * 8, 1, p.nphases);
+  int rc;
+  if (p.in[0].scale != nullptr) {
+    rc = enable_big_lds(igemm_conv_x3b_kernel<true>, lds);
+    if (rc != DN_OK) return rc;
+    DN_LAUNCH(igemm_conv_x3b_kernel<true>, grid, dim3(256), lds, stream, p);
+  } else {
+    rc = enable_big_lds(igemm_conv_x3b_kernel<false>, lds);
+    if (rc != DN_OK) return rc;
+    DN_LAUNCH(igemm_conv_x3b_kernel<false>, grid, dim3(256), lds, stream, p);
+  }
+  set_last_kernel("dn::igemm_conv_x3b_kernel<%s>", p.in[0].scale != nullptr ? "true" : "false");
+  return check_launch("igemm_conv_x3b_kernel");
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const IgemmParams& p, hipStream_t stream) {
   if (p.uni32 && !knobs().no_u32)
@@ -2115,6 +2286,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     // (the 32-wide N tile -- one 32 x 32 tile per wave, 12 matrix instructions per chunk against five split-and-store items -- measured
     //  4-17 % slower than the fp32 instruction: it stays on that)
     // fp32 products on the bf16 matrix cores (wave tiles of at most 2 x 32 x 32: the 128-wide N tile runs as 64-row blocks)
+    if (conv_x3b_eligible(p)) return launch_conv_x3b(p, s);       // 128 x 128 tile: one operand with C % 32 == 0, enough tiles (round 4)
     switch (p.BN) {
       case 128: return p.bn_partial == nullptr ? launch_conv_x3<64, 128, 32, 64>(p, s) : launch_conv_x3<128, 64, 64, 32>(p, s);   // (statistics rows are per 128-row tile)
       case 64: return (small_m || p.bn_partial == nullptr && blocks128 <= 416) ? launch_conv_x3<64, 64, 32, 32>(p, s) : launch_conv_x3<128, 64, 64, 32>(p, s);

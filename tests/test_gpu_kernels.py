@@ -87,6 +87,12 @@ CONV_CASES = [
     ("5x5_s2",            (32,),        (False,),          64, 5, 2, 2, False, 0, 2, 18, 22, ACT_RELU, False),
     ("3x3_s2_odd",        (64,),        (False,),          128, 3, 2, 1, False, 0, 2, 13, 7, ACT_RELU, False),
     ("1x1",               (64,),        (False,),          160, 1, 1, 0, False, 0, 2, 6, 10, ACT_NONE, False),
+    # 128 x 128 three-piece tile (round 4).  Smooth activations at this size: with 6 M outputs a ReLU whose pre-activation lies within fp32
+    # round-off of zero flips against the CPU reference somewhere, and ONE flipped (pixel, channel) moves 256 entries of dw by ~0.2
+    ("1x1_256_256_x3b",   (256,),       (False,),          256, 1, 1, 0, False, 0, 8, 48, 64, ACT_ELU, False),
+    ("1x1_128_512_x3b_aff", (128,),     (False,),          512, 1, 1, 0, False, 0, 4, 48, 64, ACT_NONE, True),
+    ("3x3_s2_128_256_x3b", (128,),      (False,),          256, 3, 2, 1, False, 0, 8, 96, 128, ACT_NONE, False),
+    ("convT_k4s2p1_128_128_x3b", (128,), (False,),         128, 4, 2, 1, True, 0, 4, 32, 48, ACT_LEAKY, False),
     ("3x3_elu",           (16,),        (False,),          16, 3, 1, 1, False, 0, 1, 8, 8, ACT_ELU, False),
     ("convT_k4s2p1",      (64,),        (False,),          32, 4, 2, 1, True, 0, 2, 6, 10, ACT_LEAKY, False),
     ("convT_k4s2p1_big",  (512,),       (False,),          256, 4, 2, 1, True, 0, 2, 4, 13, ACT_LEAKY, False),
