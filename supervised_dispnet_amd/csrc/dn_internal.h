@@ -42,6 +42,7 @@ struct Knobs {
   int extra_lds;            // DN_DEBUG_EXTRA_LDS: bytes added to the tiled kernels' LDS request (lowers blocks per CU)
   int wino_dbg, wino_mtw, wino_wg_dbg;   // DN_WINO_DBG / DN_WINO_MTW / DN_WINO_WG_DBG: ablation variants (tools/wino_timing.py)
   unsigned long long wino_dbgptr;
+  int lds3_dbg;                          // DN_LDS3_DBG: phase timestamps of the LDS-resident kernels into DN_WINO_DBGPTR (tools/lds3_timing.py)
   int wino_min_tiles;       // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (default 192)
   bool no_x3_direct;        // DN_NO_X3_DIRECT: keep the fp32 matrix instruction in the direct (implicit-GEMM) forward family under DN_COMPUTE_F32X3
   int wino_splitk_target, wino_splitk_minch;   // DN_WINO_SPLITK_TARGET (256 blocks), DN_WINO_SPLITK_MINCH (8 chunks per block)

@@ -43,6 +43,8 @@ __device__ __forceinline__ void wg_split3(const float (&v)[8], bf16x8& h, bf16x8
 struct WgGeo {
   int tilesX, tilesY, ntiles, per_xcd;
   long long slab;                  // floats per block slab of the workspace: Npad * Kp
+  int dbgmode;                     // DN_LDS3_DBG value: 2 = no loads, 3 = loads from a 64 KB window (timing ablations, wrong results)
+  long long* dbg;                  // DN_LDS3_DBG=1 (tools/lds3_timing.py): per-wave phase ticks, 8 per wave; nullptr otherwise
 };
 
 constexpr int WG_TH = 8, WG_TW = 32;
@@ -426,6 +428,8 @@ int launch_lds3_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStrea
   geo.ntiles = p.N * geo.tilesX * geo.tilesY;
   geo.per_xcd = (geo.ntiles + 7) / 8;
   geo.slab = (long long)p.Npad * p.ph[0].nchunks * kChunk;
+  geo.dbg = nullptr;
+  geo.dbgmode = 0;
   const int blocks = lds3_wgrad_blocks(p);
   hipError_t e = hipSuccess;
   if (form == 3) {
@@ -473,7 +477,7 @@ constexpr int WK_NCI = 96;
 constexpr int WK_XPIECE = WK_NCI * WK_XSTR;
 constexpr int WK_LDS = 3 * WK_GPIECE + 3 * WK_XPIECE + WK_XROWS * WG_DCOLS * 4;
 
-template <bool HAS1>
+template <bool HAS1, bool DBG = false>
 __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p, const WgGeo geo, int c0) {
   extern __shared__ __align__(16) char lds[];
   char* Gp = lds;
@@ -490,7 +494,8 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
   const KOperand& SD = p.in[HAS1 ? p.n_in - 1 : 0];
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SD.p), 0, 0x80000000u, 0x00020000);
 
-  // units of this wave: u0 = wave, u1 = wave + 8, u2 = wave + 16 (waves 0 and 1 only); unit = tap row * 6 + channel group
+  // units of this wave: u0 = wave, u1 = wave + 8, u2 = wave + 16 (waves 0 and 1 only); unit = tap row * 6 + channel group.  (The extra
+  // staging jobs and the 1-channel piece are waves 2 and 3's, the ones with two units.)
   const int nunits = wave < 2 ? 3 : 2;
   f32x4 acc[3][3][2];
 #pragma unroll
@@ -506,55 +511,95 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
   f32x4 va[8], vb[8];
   float dv = 0.f;
   // staging jobs: x job = (row 0..3, column group 0..5, channel quad 0..23) -> 576: round A = jobs tid, round B = jobs 512 + tid (tid < 64);
-  // dy job = (row 0..1, column group 0..3, channel quad 0..7) -> 64: round B, threads 64..127
-  auto x_job = [&](int job, int gy0, int gx0, int n, f32x4 (&v)[8], bool live) __attribute__((always_inline)) {
-    const int quad = job % 24, rc = job / 24, cgp = rc % 6, row = rc / 6;
-    const int iy = gy0 - 1 + row;
-    const bool second = two && 4 * quad >= c0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ix = gx0 + 8 * cgp - 8 + i;
-      const bool need = cgp == 0 ? i == 7 : (cgp == 5 ? i == 0 : true);
-      const bool ok = live && need && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      const int o0 = (n * (int)S0.sn + iy * (int)S0.sh + ix * (int)S0.sw + 4 * quad) * 4;
-      const int o1 = (n * (int)S1.sn + iy * (int)S1.sh + ix * (int)S1.sw + 4 * quad - c0) * 4;
-      const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0, (ok && !second) ? o0 : -1, 0, 0));
-      if (two) {
-        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, (ok && second) ? o1 : -1, 0, 0));
-        v[i] = a + b;                               // (one of the two is the hardware's zero fill)
-      } else {
-        v[i] = a;
-      }
-    }
+  // dy job = (row 0..1, column group 0..3, channel quad 0..7) -> 64: round B, threads 64..127.  The jobs of the first operand come first
+  // (24 x c0 / 4 of them, a whole number of waves: lds3k_wgrad_form), quad fastest within an operand: every wave reads ONE operand through
+  // ONE descriptor (a per-lane choice needs two loads with complementary predicates and an add that waits for both: 8 k of the tile's 21 k
+  // ticks went there, tools/lds3_timing.py) and a pixel's channels stay contiguous across its lanes.
+  // Within an operand a job index reads (rc / 4, quad / 4, quad % 4, rc % 4) from the top: sixteen consecutive lanes write four channel
+  // quads x four neighbouring 16-byte columns, which are sixteen different bank groups (planes 400 bytes apart: the quad moves the
+  // column by 4 of 16, rc by one); quad-fastest lanes collided four deep (3.2-3.7 k ticks of staging against 2.1 k, tools/lds3_timing.py).
+  const int nq0 = two ? c0 >> 2 : 24, n0jobs = 24 * nq0;
+  auto decode = [&](int job, int& quad, int& rc, bool& second) __attribute__((always_inline)) {
+    second = job >= n0jobs;
+    const int jj = second ? job - n0jobs : job, nqh = (second ? 24 - nq0 : nq0) >> 2;
+    const int rc_lo = jj & 3, q_lo = (jj >> 2) & 3, hi = jj >> 4;
+    const int rc_hi = hi / nqh, q_hi = hi - rc_hi * nqh;
+    rc = 4 * rc_hi + rc_lo;
+    quad = (second ? nq0 : 0) + 4 * q_hi + q_lo;
   };
-  auto issue_loads = [&](int t) __attribute__((always_inline)) {
+  int quadA, rcA, quadB, rcB;
+  bool secA, secB;
+  decode(tid, quadA, rcA, secA);
+  decode(512 + (tid & 63), quadB, rcB, secB);
+  // A job is eight pixel loads of one float4 through one (wave-uniform) descriptor: byte offset of pixel 0, byte step, 8 validity bits.
+  // Job A = this thread's x job; job B = the 64 remaining x jobs (wave 2) and the 64 dy jobs (wave 3).  The offsets of the NEXT tile are
+  // prepared once per tile and the sixteen loads are issued ONE AT A TIME between the groups of the matrix loop (load_site): the texture
+  // path takes a tile's 82 KB in ~2-3 k cycles, and a wave that issues its loads in one piece stands in that queue with its matrix
+  // instructions behind it (tools/lds3_timing.py: 3 k of 14.8 k ticks per tile, whether ahead of the loop or at the top of a K-step).
+  const bool secAu = __builtin_amdgcn_readfirstlane((int)secA) != 0, secBu = __builtin_amdgcn_readfirstlane((int)secB) != 0;
+  const int waveu = __builtin_amdgcn_readfirstlane(wave);
+  const bool hasB = waveu == 2 || waveu == 3;
+  const __amdgpu_buffer_rsrc_t rA = secAu ? r1 : r0;
+  const __amdgpu_buffer_rsrc_t rB = waveu == 3 ? rg : (secBu ? r1 : r0);
+  int offA = 0, stepA = 0, offB = 0, stepB = 0, offD = -1;
+  unsigned maskA = 0, maskB = 0;
+  auto x_prep = [&](int quad, int rc, bool second, int gy0, int gx0, int n, int& off, int& step, unsigned& mask) __attribute__((always_inline)) {
+    const int cgp = rc % 6, row = rc / 6;
+    const int iy = gy0 - 1 + row, ix0 = gx0 + 8 * cgp - 8;
+    const int sw = second ? (int)S1.sw : (int)S0.sw;
+    const int base = second ? (n * (int)S1.sn + iy * (int)S1.sh + 4 * quad - c0) : (n * (int)S0.sn + iy * (int)S0.sh + 4 * quad);
+    off = (base + ix0 * sw) * 4;
+    step = sw * 4;
+    unsigned m = 0;
+    if ((unsigned)iy < (unsigned)p.IH) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if ((unsigned)(ix0 + i) < (unsigned)p.IW) m |= 1u << i;
+      m &= cgp == 0 ? 0x80u : (cgp == 5 ? 0x01u : 0xffu);             // (the halo groups: one column each)
+    }
+    mask = m;
+  };
+  auto prep_loads = [&](int t, bool live) __attribute__((always_inline)) {
     const int txb = t % geo.tilesX, q1 = t / geo.tilesX;
     const int tyb = q1 % geo.tilesY, n = q1 / geo.tilesY;
     const int gy0 = tyb * WK_TH, gx0 = txb * WG_TW;
-    x_job(tid, gy0, gx0, n, va, true);
-    if (tid < 64) {
-      x_job(512 + tid, gy0, gx0, n, vb, true);
-    } else if (tid < 128) {
-      const int job = tid - 64, cq = job & 7, pxg = job >> 3, row = pxg >> 2, cgp = pxg & 3;
-      const int gy = gy0 + row;
+    x_prep(quadA, rcA, secA, gy0, gx0, n, offA, stepA, maskA);
+    if (waveu == 2) {
+      x_prep(quadB, rcB, secB, gy0, gx0, n, offB, stepB, maskB);
+    } else if (waveu == 3) {
+      const int cgp = lane & 3, cq = ((lane >> 2) & 3) + 4 * ((lane >> 4) & 1), row = lane >> 5;      // (bank groups: as the x jobs)
+      const int gy = gy0 + row, gx = gx0 + 8 * cgp;
+      offB = (((n * p.GH + gy) * p.GW + gx) * p.Ntot + 4 * cq) * 4;
+      stepB = p.Ntot * 4;
+      unsigned m = 0;
+      if (gy < p.GH && 4 * cq < p.Ntot) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int gx = gx0 + 8 * cgp + i;
-        const bool ok = gy < p.GH && gx < p.GW && 4 * cq < p.Ntot;
-        const int off = (((n * p.GH + gy) * p.GW + gx) * p.Ntot + 4 * cq) * 4;
-        vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : -1, 0, 0));
+        for (int i = 0; i < 8; ++i)
+          if (gx + i < p.GW) m |= 1u << i;
       }
+      maskB = m;
     }
     if constexpr (HAS1) {
       const int row = tid / 34, col = tid - row * 34;
       const int iy = gy0 - 1 + row, ix = gx0 - 1 + col;
       const bool ok = tid < WK_XROWS * 34 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      const int off = (n * (int)SD.sn + (iy >> SD.up) * (int)SD.sh + (ix >> SD.up) * (int)SD.sw) * 4;
-      dv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, ok ? off : -1, 0, 0));
+      offD = ok ? (n * (int)SD.sn + (iy >> SD.up) * (int)SD.sh + (ix >> SD.up) * (int)SD.sw) * 4 : -1;
+    }
+    if (!live) { maskA = 0; maskB = 0; offD = -1; }
+    if constexpr (DBG) {
+      if (geo.dbgmode == 2) { maskA = 0; maskB = 0; }
+      if (geo.dbgmode == 3) { offA &= 0xfff0; offB &= 0xfff0; stepA = 16; stepB = 16; }
     }
   };
-  auto store_x = [&](int job, const f32x4 (&v)[8]) __attribute__((always_inline)) {
-    const int quad = job % 24, rc = job / 24, cgp = rc % 6, row = rc / 6;
+  auto load_site = [&](int i) __attribute__((always_inline)) {          // pixel i of both jobs (i is a compile-time constant at every site)
+    va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (maskA >> i) & 1 ? offA + i * stepA : -1, 0, 0));
+    if (hasB) vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, (maskB >> i) & 1 ? offB + i * stepB : -1, 0, 0));
+  };
+  auto load_d = [&]() __attribute__((always_inline)) {
+    if constexpr (HAS1) dv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, offD, 0, 0));
+  };
+  auto store_x = [&](int quad, int rc, const f32x4 (&v)[8]) __attribute__((always_inline)) {
+    const int cgp = rc % 6, row = rc / 6;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float f[8] = {v[0][e], v[1][e], v[2][e], v[3][e], v[4][e], v[5][e], v[6][e], v[7][e]};
@@ -567,11 +612,11 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
     }
   };
   auto store_lds = [&]() __attribute__((always_inline)) {
-    store_x(tid, va);
-    if (tid < 64) {
-      store_x(512 + tid, vb);
-    } else if (tid < 128) {
-      const int job = tid - 64, cq = job & 7, pxg = job >> 3;
+    store_x(quadA, rcA, va);
+    if (wave == 2) {
+      store_x(quadB, rcB, vb);
+    } else if (wave == 3) {
+      const int cq = ((lane >> 2) & 3) + 4 * ((lane >> 4) & 1), pxg = (lane & 3) + 4 * (lane >> 5);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float f[8] = {vb[0][e], vb[1][e], vb[2][e], vb[3][e], vb[4][e], vb[5][e], vb[6][e], vb[7][e]};
@@ -592,12 +637,32 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
   const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
   const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
   constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
-  if (band_lo + local < band_hi) issue_loads(band_lo + local);
+  long long tk[6] = {0, 0, 0, 0, 0, 0}, c0t = 0, c1t = 0;             // DBG: load wait | split + LDS writes | barrier | load issue | matrix loop | barrier
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if constexpr (DBG) { c1t = clock64(); tk[k] += c1t - c0t; c0t = c1t; }
+  };
+  if (band_lo + local < band_hi) {
+    prep_loads(band_lo + local, true);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) load_site(i);
+    load_d();
+  }
+  if constexpr (DBG) c0t = clock64();
   for (int t = band_lo + local; t < band_hi; t += nlocal) {
+    if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }
     store_lds();
+    stamp(1);
     __syncthreads();
-    if (t + nlocal < band_hi) issue_loads(t + nlocal);
-#pragma unroll 1
+    stamp(2);
+    const bool more = t + nlocal < band_hi;
+    if (more) {
+      prep_loads(t + nlocal, true);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) load_site(i);
+      load_d();
+    }
+    stamp(3);
+#pragma unroll
     for (int r = 0; r < WK_TH; ++r) {                                  // K-step: tile row r, pixels 8 g .. 8 g + 7 per lane group
       bf16x8 a[2][3];
 #pragma unroll
@@ -629,13 +694,14 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
             bp[P] = __builtin_bit_cast(bf16x8, p4);
           }
 #pragma unroll
-          for (int q = 0; q < 6; ++q)
+          for (int q = 0; q < 6; ++q) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
               acc[u][0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], bm[BS[q]], acc[u][0][m], 0, 0, 0);
               acc[u][1][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], bz[BS[q]], acc[u][1][m], 0, 0, 0);
               acc[u][2][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], bp[BS[q]], acc[u][2][m], 0, 0, 0);
             }
+          }
         }
       }
       if constexpr (HAS1) {
@@ -655,7 +721,16 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
         }
       }
     }
+    stamp(4);
     __syncthreads();
+    stamp(5);
+  }
+  if constexpr (DBG) {
+    if (lane == 0) {
+      long long* o = geo.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int k = 0; k < 6; ++k) o[k] = tk[k];
+      o[6] = (band_hi - band_lo - local + nlocal - 1) / nlocal;
+    }
   }
 
   // ---- every wave owns its columns: straight into the block's slab ws[block][co][k]
@@ -721,6 +796,7 @@ static int lds3k_wgrad_form(const dn_conv_desc* d, const IgemmParams& p) {
     ctot += a.C;
   }
   if (ctot != WK_NCI) return 0;
+  if (nmain == 2 && (p.in[0].C & 31)) return 0;             // the first operand's staging jobs fill whole waves (24 x C / 4 a multiple of 64)
   const int ntiles = p.N * ((p.GH + WK_TH - 1) / WK_TH) * ((p.GW + WG_TW - 1) / WG_TW);
   if (ntiles < 192) return 0;
   return has1 ? 2 : 1;
@@ -749,7 +825,13 @@ int launch_lds3k_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStre
   const int blocks = lds3k_wgrad_blocks(p);
   const int c0 = p.in[0].C;
   hipError_t e = hipSuccess;
-  if (form == 2) {
+  geo.dbg = knobs().lds3_dbg ? reinterpret_cast<long long*>(knobs().wino_dbgptr) : nullptr;
+  geo.dbgmode = knobs().lds3_dbg;
+  if (geo.dbg != nullptr && form == 2) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3k_wgrad_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS);
+    if (e == hipSuccess) DN_LAUNCH((lds3k_wgrad_kernel<true, true>), dim3(blocks), dim3(512), (size_t)WK_LDS, stream, p, geo, c0);
+    set_last_kernel("dn::lds3k_wgrad_kernel<true>");
+  } else if (form == 2) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3k_wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS);
     if (e == hipSuccess) DN_LAUNCH(lds3k_wgrad_kernel<true>, dim3(blocks), dim3(512), (size_t)WK_LDS, stream, p, geo, c0);
     set_last_kernel("dn::lds3k_wgrad_kernel<true>");

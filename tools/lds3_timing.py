@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Phase ticks inside the LDS-resident weight-gradient kernel of iconv1 (DN_LDS3_DBG=1): per wave and tile, the clock64 ticks spent waiting
+for the next tile's loads, splitting + writing LDS, at the two barriers, issuing loads and in the matrix loop."""
+import os, sys, pathlib
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+import torch, torch.nn as nn
+dev = torch.device("cuda:0")
+buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+os.environ["DN_LDS3_DBG"] = sys.argv[1] if len(sys.argv) > 1 else "1"      # 2: no loads, 3: loads from a 64 KB window (ablations)
+os.environ["DN_WINO_DBGPTR"] = hex(buf.data_ptr())
+from supervised_dispnet_amd import engine, _lib
+N, H, W = 32, 64, 208
+mod = nn.Conv2d(97, 32, 3, 1, 1).to(dev)
+layer = engine.ConvLayer(mod)
+a = engine.Act(torch.randn(N, H, W, 32, device=dev), N, H, W, 32)
+b = engine.Act(torch.randn(N, H, W, 64, device=dev), N, H, W, 64)
+d = engine.Act(torch.randn(N, H // 2, W // 2, 1, device=dev), N, H // 2, W // 2, 1)
+pieces = [engine.Piece(a), engine.Piece(b), engine.Piece(d, up=1)]
+dy = torch.randn(N, H, W, 32, device=dev)
+names = ["load wait", "split + LDS writes", "barrier A", "load issue", "matrix loop", "barrier B"]
+for it in range(3):
+    engine.conv_wgrad(layer, pieces, dy, (H, W))
+torch.cuda.synchronize()
+print("kernel:", _lib.load().dn_last_kernel().decode())
+t = buf[: 256 * 8 * 8].view(256, 8, 8).cpu().double()
+tiles = t[:, :, 6].clamp(min=1)
+per = t[:, :, :6] / tiles[:, :, None]
+print("tiles per block: %.1f" % tiles.mean().item())
+print("%-22s" % "wave" + "".join("%10d" % w for w in range(8)) + "      mean")
+for k, n in enumerate(names):
+    print("%-22s" % n + "".join("%10.0f" % per[:, w, k].mean().item() for w in range(8)) + "%10.0f" % per[:, :, k].mean().item())
+print("%-22s" % "sum" + "".join("%10.0f" % per[:, w, :].sum(-1).mean().item() for w in range(8)))
