@@ -2097,8 +2097,12 @@ __global__ void pack_weights_many_kernel(const PackEntry* __restrict__ tab) {
 // 64 consecutive packed elements per block (coalesced 256-byte rows of every split slab); the four waves take the splits z = w, w + 4,
 // ... and meet through LDS in a fixed order (deterministic).  The thin full-resolution layers have a few thousand weights and hundreds
 // of splits: one thread per element walking all of them serially ran 10 blocks for up to 90 us.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const IgemmParams p, float* __restrict__ dw) {
-  __shared__ float part[4][64];
+// NW waves per block: 4 for the tiled kernels' handful of splits, 16 for the hundreds of block slabs of the persistent thin-layer
+// kernels (round 4: 40 blocks of 4 waves walking 128 slabs each took 30-60 us per launch, as long as half the kernel they follow); a
+// wave keeps four running sums (z = w + NW (4 i + u)) so that its loads are in flight four deep.  The order is fixed by the indices.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) wgrad_reduce_kernel(const IgemmParams p, float* __restrict__ dw) {
+  __shared__ float part[NW][64];
   const KPhase& ph = p.ph[0];
   const int Kp = ph.nchunks * kChunk;
   const long long total = (long long)p.Ntot * Kp;
@@ -2107,13 +2111,23 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const IgemmParams p, 
   for (long long base = blockIdx.x * 64ll; base < total; base += (long long)gridDim.x * 64) {
     const long long idx = base + lane;
     const bool live = idx < total;
-    float s = 0.f;
-    if (live)
-      for (int z = w; z < p.splits; z += 4) s += p.ws[z * slab + idx];
-    part[w][lane] = s;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      int z = w;
+      for (; z + 3 * NW < p.splits; z += 4 * NW) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += p.ws[(z + u * NW) * slab + idx];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (z + u * NW < p.splits) s[u] += p.ws[(z + u * NW) * slab + idx];
+    }
+    part[w][lane] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
     if (w == 0 && live) {
-      const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+      float tot = part[0][lane];
+#pragma unroll
+      for (int q = 1; q < NW; ++q) tot += part[q][lane];
       const int n = (int)(idx / Kp), k = (int)(idx - (long long)n * Kp);
       const long long dst = packed_to_framework(p, ph, n, k);
       if (dst >= 0) dw[dst] = tot;
@@ -2365,7 +2379,8 @@ int launch_wgrad_reduce(const IgemmParams& p, float* dw, hipStream_t stream) {
   const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;
   int blocks = (int)((total + 63) / 64);
   if (blocks > 8192) blocks = 8192;
-  DN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, dw);
+  if (p.splits >= 32) DN_LAUNCH(wgrad_reduce_kernel<16>, dim3(blocks), dim3(1024), 0, stream, p, dw);
+  else DN_LAUNCH(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, stream, p, dw);
   return check_launch("wgrad_reduce_kernel");
 }
 
@@ -2421,11 +2436,7 @@ static int generic_wgrad(const dn_conv_desc* fwd, IgemmParams& p, const float* d
     }
   }
   if (rc != DN_OK) return rc;
-  const long long total = (long long)p.Ntot * p.ph[0].nchunks * kChunk;
-  int blocks = (int)((total + 63) / 64);
-  if (blocks > 8192) blocks = 8192;
-  DN_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, dw);
-  return check_launch("wgrad_reduce_kernel");
+  return launch_wgrad_reduce(p, dw, s);
 }
 
 // A concatenated input whose LAST piece is a 1-channel map (the upsampled disparity of the iconv layers: 64 + 128 + 1, 64 + 256 + 1):

@@ -57,7 +57,7 @@ constexpr int WG_XPIECE = 16 * WG_XSTR;
 constexpr int WG_DCOLS = 36;                      // fp32 plane of the 1-channel piece: [10][36], column c at c + 1
 constexpr int WG16_LDS = 3 * WG_GPIECE + 3 * WG_XPIECE + 10 * WG_DCOLS * 4;
 
-template <bool HAS1>
+template <bool HAS1, bool DBG = false>
 __global__ void __launch_bounds__(256, 2) lds3_wgrad16_kernel(const IgemmParams p, const WgGeo geo) {
   extern __shared__ __align__(16) char lds[];
   char* Gp = lds;
@@ -161,11 +161,20 @@ __global__ void __launch_bounds__(256, 2) lds3_wgrad16_kernel(const IgemmParams 
   const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
   const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
   constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+  long long tk[6] = {0, 0, 0, 0, 0, 0}, c0t = 0, c1t = 0;             // DBG: load wait | split + LDS writes | barrier | load issue | matrix loop | barrier
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if constexpr (DBG) { c1t = clock64(); tk[k] += c1t - c0t; c0t = c1t; }
+  };
   if (band_lo + local < band_hi) issue_loads(band_lo + local);
+  if constexpr (DBG) c0t = clock64();
   for (int t = band_lo + local; t < band_hi; t += nlocal) {
+    if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }
     store_lds();
+    stamp(1);
     __syncthreads();
+    stamp(2);
     if (t + nlocal < band_hi) issue_loads(t + nlocal);
+    stamp(3);
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
       const int r = 2 * wave + rr;                                   // this wave's K-step: tile row r, pixels 8 g .. 8 g + 7 per lane group
@@ -214,7 +223,16 @@ __global__ void __launch_bounds__(256, 2) lds3_wgrad16_kernel(const IgemmParams 
         for (int q = 0; q < 6; ++q) acc[9] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AS[q]], b[BS[q]], acc[9], 0, 0, 0);
       }
     }
+    stamp(4);
     __syncthreads();
+    stamp(5);
+  }
+  if constexpr (DBG) {
+    if (lane == 0) {
+      long long* o = geo.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int k = 0; k < 6; ++k) o[k] = tk[k];
+      o[6] = (band_hi - band_lo - local + nlocal - 1) / nlocal;
+    }
   }
 
   // ---- the four waves meet (fixed order) and the block writes its slab ws[block][co][k], k = tap * 16 + ci (operand 0), kbase1 + tap
@@ -428,11 +446,15 @@ int launch_lds3_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStrea
   geo.ntiles = p.N * geo.tilesX * geo.tilesY;
   geo.per_xcd = (geo.ntiles + 7) / 8;
   geo.slab = (long long)p.Npad * p.ph[0].nchunks * kChunk;
-  geo.dbg = nullptr;
-  geo.dbgmode = 0;
+  geo.dbg = knobs().lds3_dbg ? reinterpret_cast<long long*>(knobs().wino_dbgptr) : nullptr;
+  geo.dbgmode = knobs().lds3_dbg;
   const int blocks = lds3_wgrad_blocks(p);
   hipError_t e = hipSuccess;
-  if (form == 3) {
+  if (geo.dbg != nullptr && form == 2) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3_wgrad16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WG16_LDS);
+    if (e == hipSuccess) DN_LAUNCH((lds3_wgrad16_kernel<true, true>), dim3(blocks), dim3(256), (size_t)WG16_LDS, stream, p, geo);
+    set_last_kernel("dn::lds3_wgrad16_kernel<true>");
+  } else if (form == 3) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(lds3_wgrad_stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
     if (e == hipSuccess) DN_LAUNCH(lds3_wgrad_stem_kernel, dim3(blocks), dim3(256), (size_t)WGS_LDS, stream, p, geo);
     set_last_kernel("dn::lds3_wgrad_stem_kernel");

@@ -57,7 +57,9 @@ struct LkCfg {
   static constexpr int HALFC = (COLS + 1) / 2;
   static constexpr int COLSP = STRIDE == 2 ? 2 * HALFC : COLS;
   static constexpr int PLANE = ROWS * COLSP * 16;
-  static constexpr int CGSTRIDE = ((PLANE + 255) / 256) * 256 + 16;
+  // 16-byte bank group of a plane relative to its neighbour: 1 where the staging lanes run over the channel groups of one pixel, 4 where
+  // they run over (4 groups x 4 pixels) -- the two-operand form, whose waves each stage ONE operand (see the kernel)
+  static constexpr int CGSTRIDE = ((PLANE + 255) / 256) * 256 + (NOPS == 2 ? 64 : 16);
   static constexpr int PSTRIDE = CGT * CGSTRIDE;
   static constexpr int DPLANE = HAS1 ? ROWS * COLS * 4 : 0;
   static constexpr int PTB = TH * TW / 16;
@@ -144,7 +146,36 @@ __global__ void __launch_bounds__(512, 2) lds3k_conv_kernel(const IgemmParams p,
   const KOperand& SD = p.in[HAS1 ? NOPS : 0];
   const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SD.p), 0, 0x80000000u, 0x00020000);
 
-  constexpr int ITEMS = ROWS * COLS * CGT, ROUNDS = (ITEMS + 511) / 512;
+  // staging items: (pixel of the input tile, 8-channel group) -> two float4 loads, one split, three 16-byte LDS words.  With two main
+  // operands the items of operand 0 come first, padded to whole waves, so that every wave reads ONE operand through ONE descriptor (a
+  // per-lane choice took two loads with complementary predicates and an add that waited for both in the issue phase); within an operand
+  // sixteen consecutive lanes are 4 groups x 4 pixels: 128 contiguous bytes per pixel on the way in, sixteen bank groups on the way out.
+  constexpr int NPX = ROWS * COLS;
+  constexpr int ITEMS = NPX * CGT, ROUNDS = (ITEMS + (NOPS == 2 ? 63 : 0) + 511) / 512;
+  static_assert(NOPS == 1 || NPX % 4 == 0, "pixels in fours");
+  int item[ROUNDS];                                       // bit 31 live, bit 30 operand 1, group << 16, row << 8, column
+  {
+    const int n0pad = NOPS == 2 ? (NPX * geo.cg0 + 63) / 64 * 64 : 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = tid + 512 * r;
+      int cg, px, live, sec = 0;
+      if constexpr (NOPS == 2) {
+        sec = it >= n0pad;
+        const int i2 = sec ? it - n0pad : it, ncg = sec ? CGT - geo.cg0 : geo.cg0, ncgh = ncg >> 2;
+        const int hi = i2 >> 4, px_hi = hi / ncgh, cg_hi = hi - px_hi * ncgh;
+        cg = (sec ? geo.cg0 : 0) + 4 * cg_hi + (i2 & 3);
+        px = 4 * px_hi + ((i2 >> 2) & 3);
+        live = i2 < NPX * ncg;
+      } else {
+        cg = it % CGT;
+        px = it / CGT;
+        live = it < ITEMS;
+      }
+      const int row = px / COLS, col = px - row * COLS;
+      item[r] = (int)((unsigned)(live ? 1 : 0) << 31 | (unsigned)(sec << 30) | (unsigned)((cg & 0xff) << 16) | (unsigned)((row & 0xff) << 8) | (unsigned)(col & 0xff));
+    }
+  }
   f32x4 va[ROUNDS], vb[ROUNDS];
   float dv = 0.f;
   auto issue_loads = [&](int t) __attribute__((always_inline)) {
@@ -153,23 +184,15 @@ __global__ void __launch_bounds__(512, 2) lds3k_conv_kernel(const IgemmParams p,
     const int iy0 = tyb * TH * STRIDE + geo.dy0, ix0 = txb * TW * STRIDE + geo.dx0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      const int it = tid + 512 * r;
-      const int cg = it % CGT, px = it / CGT;
-      const int row = px / COLS, col = px - row * COLS;
+      const int cg = (item[r] >> 16) & 0xff, row = (item[r] >> 8) & 0xff, col = item[r] & 0xff;
       const int iy = iy0 + row, ix = ix0 + col;
-      const bool ok = it < ITEMS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      const bool second = NOPS == 2 && cg >= geo.cg0;
-      const int off0 = (n * (int)S0.sn + iy * (int)S0.sh + ix * (int)S0.sw + 8 * cg) * 4;
-      const int off1 = (n * (int)S1.sn + iy * (int)S1.sh + ix * (int)S1.sw + 8 * (cg - geo.cg0)) * 4;
-      if (NOPS == 2) {
-        // (two loads with complementary predicates: each buffer descriptor is wave-uniform, the operand choice is per lane)
-        const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, (ok && !second) ? off0 : -1, 0, 0));
-        const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, (ok && !second) ? off0 + 16 : -1, 0, 0));
-        const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, (ok && second) ? off1 : -1, 0, 0));
-        const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, (ok && second) ? off1 + 16 : -1, 0, 0));
-        va[r] = a0 + a1;                                   // (one of the two is the hardware's zero fill)
-        vb[r] = b0 + b1;
+      const bool ok = item[r] < 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      if (NOPS == 2 && ((__builtin_amdgcn_readfirstlane(item[r]) >> 30) & 1)) {          // (the operand is the wave's, dead lanes included)
+        const int off1 = (n * (int)S1.sn + iy * (int)S1.sh + ix * (int)S1.sw + 8 * (cg - geo.cg0)) * 4;
+        va[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? off1 : -1, 0, 0));
+        vb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? off1 + 16 : -1, 0, 0));
       } else {
+        const int off0 = (n * (int)S0.sn + iy * (int)S0.sh + ix * (int)S0.sw + 8 * cg) * 4;
         va[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? off0 : -1, 0, 0));
         vb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? off0 + 16 : -1, 0, 0));
       }
@@ -185,10 +208,8 @@ __global__ void __launch_bounds__(512, 2) lds3k_conv_kernel(const IgemmParams p,
   auto store_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      const int it = tid + 512 * r;
-      if (it < ITEMS) {
-        const int cg = it % CGT, px = it / CGT;
-        const int row = px / COLS, col = px - row * COLS;
+      if (item[r] < 0) {
+        const int cg = (item[r] >> 16) & 0xff, row = (item[r] >> 8) & 0xff, col = item[r] & 0xff;
         const int idx = STRIDE == 2 ? ((col & 1) * Cfg::HALFC + (col >> 1)) : col;
         const float v[8] = {va[r][0], va[r][1], va[r][2], va[r][3], vb[r][0], vb[r][1], vb[r][2], vb[r][3]};
         bf16x8 h, m, l;
@@ -371,6 +392,7 @@ static LkPick lk_pick(const dn_conv_desc* d, const IgemmParams& p) {
   r.geo.dy0 = dy0;
   r.geo.dx0 = dx0;
   r.geo.cg0 = p.in[0].C / 8;
+  if (nmain == 2 && ((r.geo.cg0 & 3) || ((cgt - r.geo.cg0) & 3))) r.cfg = 0;      // staging lanes: 4 groups x 4 pixels per operand
   return r;
 }
 
