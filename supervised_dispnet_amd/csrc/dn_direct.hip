@@ -149,13 +149,15 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const IgemmParams p, in
 }
 
 // one block per weight element: 256 threads fold the slabs in a fixed tree (deterministic), no serial 1024-long chain
-__global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const IgemmParams p, const float* __restrict__ slabs, int nslabs,
+// (cgs > 1: the slab of block b holds only the sixteen channels of group b % cgs -- head_wgrad2_kernel)
+__global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const IgemmParams p, const float* __restrict__ slabs, int nslabs, int cgs,
                                                                 float* __restrict__ dw) {
   __shared__ float part[4];
   const int C = p.in[0].C, ntaps = p.ph[0].ntaps;
   const int i = blockIdx.x;
   float s = 0.f;
-  for (int b = threadIdx.x; b < nslabs; b += 256) s += slabs[(long long)b * ntaps * C + i];
+  const int b0 = cgs > 1 ? ((i % C) >> 4) : 0;
+  for (int b = b0 + threadIdx.x * cgs; b < nslabs; b += 256 * cgs) s += slabs[(long long)b * ntaps * C + i];
   for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -178,59 +180,69 @@ __global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const IgemmParam
 //             pixels): a wave stages 64 pixels of x (float4 loads) and the three gradient rows it needs in LDS and feeds both
 //             operands from there -- 5 global + ~36 LDS instructions per 64 pixels instead of 40 global ones.
 // =====================================================================================================================
-constexpr int kH2TY = 8, kH2TX = 64, kH2LD = kH2TX + 4;          // forward tile; LDS row of a t plane (66 used)
-
-__global__ void __launch_bounds__(256) head_fwd2_kernel(const IgemmParams p, int tilesX, int tilesY) {
+// Forward tile TY x TX (8 x 64 on the large maps; 4 x 16 where that would leave fewer than ~4 blocks per CU: the 16 x 52 head ran 64
+// blocks of serial 128-channel dot products, 28 us for 60 MFLOP).  An item is (input pixel, 16-channel group), groups on adjacent lanes:
+// 64 contiguous bytes per lane, a pixel's channels contiguous across its lanes, the partial dot products folded by xor-shuffles.
+template <int TY, int TX>
+__global__ void __launch_bounds__(256) head_fwd2_kernel(const IgemmParams p, int tilesX, int tilesY, int LGc) {
+  constexpr int LD = TX + 4;
   extern __shared__ float sm[];
   const KOperand& S = p.in[0];
   const int C = S.C;
   float* wsm = sm;                                   // [9][C]
-  float* t = sm + 9 * C;                             // [9][kH2TY + 2][kH2LD]
+  float* t = sm + 9 * C;                             // [9][TY + 2][LD]
   for (int i = threadIdx.x; i < 9 * C; i += 256) wsm[i] = p.w[i];
   int b = blockIdx.x;
   const int tx = b % tilesX;
   b /= tilesX;
   const int ty = b % tilesY, n = b / tilesY;
-  const int y0 = ty * kH2TY, x0 = tx * kH2TX;
+  const int y0 = ty * TY, x0 = tx * TX;
   __syncthreads();
-  constexpr int IN_W = kH2TX + 2, IN_N = (kH2TY + 2) * IN_W;
-  for (int idx = threadIdx.x; idx < IN_N; idx += 256) {
+  constexpr int IN_W = TX + 2, IN_N = (TY + 2) * IN_W;
+  const int G = 1 << LGc;                            // 16-channel groups: C / 16
+  for (int base = 0; base < (IN_N << LGc); base += 256) {
+    const int it = base + (int)threadIdx.x;
+    const int grp = it & (G - 1), idx = it >> LGc;
     const int r = idx / IN_W, ci = idx - r * IN_W;
     const int iy = y0 - 1 + r, ix = x0 - 1 + ci;
     float tj[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) tj[j] = 0.f;
-    if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
-      const float* xp = S.p + (long long)n * S.sn + (long long)iy * S.sh + (long long)ix * S.sw;
-      for (int c0 = 0; c0 < C; c0 += 16) {
-        f32x4 xv[4];
+    if (idx < IN_N && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW) {
+      const float* xp = S.p + (long long)n * S.sn + (long long)iy * S.sh + (long long)ix * S.sw + 16 * grp;
+      f32x4 xv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const f32x4*>(xp + c0 + 4 * q);
+      for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const f32x4*>(xp + 4 * q);
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-          float a = tj[j];
+      for (int j = 0; j < 9; ++j) {
+        float a = 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + c0 + 4 * q);       // same address in every lane: broadcast
-            a += xv[q][0] * w[0] + xv[q][1] * w[1] + xv[q][2] * w[2] + xv[q][3] * w[3];
-          }
-          tj[j] = a;
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wsm + j * C + 16 * grp + 4 * q);
+          a += xv[q][0] * w[0] + xv[q][1] * w[1] + xv[q][2] * w[2] + xv[q][3] * w[3];
         }
+        tj[j] = a;
       }
     }
+    for (int d = 1; d < G; d <<= 1) {                 // (fixed order: deterministic)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) t[(j * (kH2TY + 2) + r) * kH2LD + ci] = tj[j];
+      for (int j = 0; j < 9; ++j) tj[j] += __shfl_xor(tj[j], d);
+    }
+    if (idx < IN_N && grp == 0) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) t[(j * (TY + 2) + r) * LD + ci] = tj[j];
+    }
   }
   __syncthreads();
   const KResult& R = p.out[0];
   const float bias = p.bias ? p.bias[0] : 0.f;
-  for (int o = threadIdx.x; o < kH2TY * kH2TX; o += 256) {
-    const int oy = o / kH2TX, ox = o - oy * kH2TX;
+  for (int o = threadIdx.x; o < TY * TX; o += 256) {
+    const int oy = o / TX, ox = o - oy * TX;
     const int gy = y0 + oy, gx = x0 + ox;
     if (gy < p.GH && gx < p.GW) {
       float acc = bias;
 #pragma unroll
-      for (int j = 0; j < 9; ++j) acc += t[(j * (kH2TY + 2) + oy + 1 + p.tdy[j]) * kH2LD + ox + 1 + p.tdx[j]];
+      for (int j = 0; j < 9; ++j) acc += t[(j * (TY + 2) + oy + 1 + p.tdy[j]) * LD + ox + 1 + p.tdx[j]];
       float v = head_act(acc, p.act, p.act_p0, p.act_p1);
       float* op = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
       if (R.accumulate) v += *op;
@@ -241,7 +253,9 @@ __global__ void __launch_bounds__(256) head_fwd2_kernel(const IgemmParams p, int
   }
 }
 
-__global__ void __launch_bounds__(256) head_dgrad2_kernel(const IgemmParams p, int Kp) {
+// one thread per (pixel, 16-channel group): 9 neighbour values of the 1-channel gradient, 16 channels x 9 taps from the LDS weights,
+// 64 contiguous bytes stored per lane (a pixel's groups on adjacent lanes)
+__global__ void __launch_bounds__(256) head_dgrad2_kernel(const IgemmParams p, int Kp, int LGc) {
   extern __shared__ float wsm[];                     // [9][C]   (transposed on the way in)
   const int C = p.Ntot;
   for (int i = threadIdx.x; i < 9 * C; i += 256) {
@@ -251,7 +265,10 @@ __global__ void __launch_bounds__(256) head_dgrad2_kernel(const IgemmParams p, i
   __syncthreads();
   const KOperand& G = p.in[0];
   const KResult& R = p.out[0];
-  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < p.M; pix += (long long)gridDim.x * 256) {
+  const long long items = (long long)p.M << LGc;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+    const int grp = (int)(it & ((1 << LGc) - 1));
+    const long long pix = it >> LGc;
     unsigned gx, gy;
     const unsigned tq = fastdiv_dev((unsigned)pix, (unsigned)p.GW, p.mGW, &gx);
     const int n = (int)fastdiv_dev(tq, (unsigned)p.GH, p.mGH, &gy);
@@ -262,32 +279,32 @@ __global__ void __launch_bounds__(256) head_dgrad2_kernel(const IgemmParams p, i
       const bool ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
       g[j] = ok ? G.p[(long long)n * G.sn + (long long)iy * G.sh + (long long)ix * G.sw] : 0.f;
     }
-    float* op = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw;
-    for (int c0 = 0; c0 < C; c0 += 16) {
-      f32x4 acc[4];
+    float* op = R.p + (long long)n * R.sn + (long long)gy * R.sh + (long long)gx * R.sw + 16 * grp;
+    f32x4 acc[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = R.accumulate ? *reinterpret_cast<const f32x4*>(op + c0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) acc[q] = R.accumulate ? *reinterpret_cast<const f32x4*>(op + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < 9; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += g[j] * *reinterpret_cast<const f32x4*>(wsm + j * C + c0 + 4 * q);
+      for (int q = 0; q < 4; ++q) acc[q] += g[j] * *reinterpret_cast<const f32x4*>(wsm + j * C + 16 * grp + 4 * q);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(op + c0 + 4 * q) = acc[q];
-    }
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(op + 4 * q) = acc[q];
   }
 }
 
 constexpr int kH2MaxCG = 8;                           // C <= 128
 constexpr int kH2DLD = 68;                            // LDS row of the staged gradient rows (66 used)
 
-template <int CG>
-__global__ void __launch_bounds__(256) head_wgrad2_kernel(const IgemmParams p, float* __restrict__ slabs) {
+// A block takes ONE 16-channel group (blockIdx % cgs) and every (gridDim / cgs)-th set of four row segments: C / 16 times the blocks of
+// a kernel that walks all groups per segment (the 16 x 52 head: 128 -> 1024 blocks); its slab holds that group's columns only.
+__global__ void __launch_bounds__(256) head_wgrad2_kernel(const IgemmParams p, int cgs, float* __restrict__ slabs) {
   __shared__ float xs[4][64 * 16];                    // per wave: 64 pixels x 16 channels
   __shared__ float ds[4][4 * kH2DLD];                 // per wave: gradient rows y+1, y, y-1 (columns x0-1 .. x0+64) and a zero row
-  __shared__ float red[4][9][CG * 16];
+  __shared__ float red[4][9][16];
   const KOperand& S = p.in[0];
   const int C = S.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 4, j = lane & 15;
+  const int q = (int)blockIdx.x % cgs, bq = (int)blockIdx.x / cgs, nbq = (int)gridDim.x / cgs;
   float* xw = xs[wave];
   float* dw_ = ds[wave];
   for (int i = lane; i < kH2DLD; i += 64) dw_[3 * kH2DLD + i] = 0.f;
@@ -296,12 +313,10 @@ __global__ void __launch_bounds__(256) head_wgrad2_kernel(const IgemmParams p, f
   const int tdy = tap_ok ? p.tdy[j] : 0, tdx = tap_ok ? p.tdx[j] : 0;
   // staged rows: index 0 <-> gradient row y-1, 1 <-> y, 2 <-> y+1; dy row needed = y - tdy -> index 1 - tdy; invalid taps -> zero row 3
   const int a_off = (tap_ok ? (1 - tdy) : 3) * kH2DLD + 1 + k - (tap_ok ? tdx : 0);
-  f32x4 acc[CG];
-#pragma unroll
-  for (int q = 0; q < CG; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   const int segX = (p.IW + 63) / 64;
   const long long nseg = (long long)p.N * p.IH * segX;
-  for (long long sg = (long long)blockIdx.x * 4 + wave; sg < nseg; sg += (long long)gridDim.x * 4) {
+  for (long long sg = (long long)bq * 4 + wave; sg < nseg; sg += (long long)nbq * 4) {
     const int sx = (int)(sg % segX);
     const long long ty = sg / segX;
     const int y = (int)(ty % p.IH), n = (int)(ty / p.IH);
@@ -320,37 +335,32 @@ __global__ void __launch_bounds__(256) head_wgrad2_kernel(const IgemmParams p, f
       }
     }
     const float* xrow = S.p + (long long)n * S.sn + (long long)y * S.sh;
+    // ---- 64 pixels x 16 channels of x into LDS: lane = (pixel 16 i + lane / 4, channel quad lane % 4)
 #pragma unroll
-    for (int q = 0; q < CG; ++q) {
-      // ---- 64 pixels x 16 channels of x into LDS: lane = (pixel 16 i + lane / 4, channel quad lane % 4)
+    for (int i = 0; i < 4; ++i) {
+      const int px = 16 * i + (lane >> 2);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (x0 + px < p.IW) v = *reinterpret_cast<const f32x4*>(xrow + (long long)(x0 + px) * S.sw + q * 16 + 4 * (lane & 3));
+      *reinterpret_cast<f32x4*>(xw + px * 16 + 4 * (lane & 3)) = v;
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int px = 16 * i + (lane >> 2);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (x0 + px < p.IW) v = *reinterpret_cast<const f32x4*>(xrow + (long long)(x0 + px) * S.sw + q * 16 + 4 * (lane & 3));
-        *reinterpret_cast<f32x4*>(xw + px * 16 + 4 * (lane & 3)) = v;
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float a = dw_[a_off + 4 * s];
-        const float b = xw[(4 * s + k) * 16 + j];
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
-      }
+    for (int s = 0; s < 16; ++s) {
+      const float a = dw_[a_off + 4 * s];
+      const float b = xw[(4 * s + k) * 16 + j];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
     }
   }
-  // ---- fold the four waves (fixed order), one slab [9][C] per block
+  // ---- fold the four waves (fixed order), one slab [9][C] per block (columns 16 q .. 16 q + 15)
 #pragma unroll
-  for (int q = 0; q < CG; ++q)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int tap = 4 * k + r;
-      if (tap < 9) red[wave][tap][q * 16 + j] = acc[q][r];
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int tap = 4 * k + r;
+    if (tap < 9) red[wave][tap][j] = acc[r];
+  }
   __syncthreads();
   float* slab = slabs + (long long)blockIdx.x * 9 * C;
-  for (int i = threadIdx.x; i < 9 * C; i += 256) {
-    const int tap = i / C, c = i - tap * C;
-    slab[i] = (red[0][tap][c] + red[1][tap][c]) + (red[2][tap][c] + red[3][tap][c]);
+  for (int i = threadIdx.x; i < 9 * 16; i += 256) {
+    const int tap = i >> 4, c = i & 15;
+    slab[tap * C + 16 * q + c] = (red[0][tap][c] + red[1][tap][c]) + (red[2][tap][c] + red[3][tap][c]);
   }
 }
 
@@ -380,9 +390,17 @@ static bool head2_geometry(const IgemmParams& p, int C) {
 
 int launch_head_fwd(const IgemmParams& p, hipStream_t stream) {
   if (head2_geometry(p, p.in[0].C) && p.GH == p.IH && p.GW == p.IW) {
-    const int tilesX = (p.GW + kH2TX - 1) / kH2TX, tilesY = (p.GH + kH2TY - 1) / kH2TY;
-    const size_t lds = (size_t)(9 * p.in[0].C + 9 * (kH2TY + 2) * kH2LD) * sizeof(float);
-    DN_LAUNCH(head_fwd2_kernel, dim3(p.N * tilesX * tilesY), dim3(256), lds, stream, p, tilesX, tilesY);
+    const int LGc = log2_exact(p.in[0].C / 16);
+    const int big = p.N * ((p.GW + 63) / 64) * ((p.GH + 7) / 8);
+    if (big >= 1024) {
+      const int tilesX = (p.GW + 63) / 64, tilesY = (p.GH + 7) / 8;
+      const size_t lds = (size_t)(9 * p.in[0].C + 9 * 10 * 68) * sizeof(float);
+      DN_LAUNCH((head_fwd2_kernel<8, 64>), dim3(p.N * tilesX * tilesY), dim3(256), lds, stream, p, tilesX, tilesY, LGc);
+    } else {
+      const int tilesX = (p.GW + 15) / 16, tilesY = (p.GH + 3) / 4;
+      const size_t lds = (size_t)(9 * p.in[0].C + 9 * 6 * 20) * sizeof(float);
+      DN_LAUNCH((head_fwd2_kernel<4, 16>), dim3(p.N * tilesX * tilesY), dim3(256), lds, stream, p, tilesX, tilesY, LGc);
+    }
     set_last_kernel("dn::head_fwd2_kernel");
     return check_launch("head_fwd2_kernel");
   }
@@ -408,9 +426,10 @@ bool head_dgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
 
 int launch_head_dgrad(const IgemmParams& p, hipStream_t stream) {
   if (head2_geometry(p, p.Ntot)) {
-    long long hb = ((long long)p.M + 255) / 256;
+    const int LGc = log2_exact(p.Ntot / 16);
+    long long hb = (((long long)p.M << LGc) + 255) / 256;
     if (hb > 4096) hb = 4096;
-    DN_LAUNCH(head_dgrad2_kernel, dim3((int)hb), dim3(256), 9 * p.Ntot * sizeof(float), stream, p, p.ph[0].nchunks * kChunk);
+    DN_LAUNCH(head_dgrad2_kernel, dim3((int)hb), dim3(256), 9 * p.Ntot * sizeof(float), stream, p, p.ph[0].nchunks * kChunk, LGc);
     set_last_kernel("dn::head_dgrad2_kernel");
     return check_launch("head_dgrad2_kernel");
   }
@@ -431,29 +450,20 @@ bool head_wgrad_eligible(const dn_conv_desc* fwd, const IgemmParams& p) {
 
 size_t head_wgrad_workspace_bytes(const IgemmParams& p) { return (size_t)kHeadSlabs * p.ph[0].ntaps * p.in[0].C * sizeof(float); }
 
-template <int CG>
-static void launch_head_wgrad2(const IgemmParams& p, float* workspace, int blocks, hipStream_t stream) {
-  DN_LAUNCH(head_wgrad2_kernel<CG>, dim3(blocks), dim3(256), 0, stream, p, workspace);
-}
-
 int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStream_t stream) {
   const KOperand& S0 = p.in[0];
   if (head2_geometry(p, S0.C) && p.GH == p.IH && p.GW == p.IW && S0.sw == S0.C) {
     const long long nseg = (long long)p.N * p.IH * ((p.IW + 63) / 64);
-    int blocks = (int)((nseg + 3) / 4);
-    if (blocks > kHeadSlabs) blocks = kHeadSlabs;
-    switch (S0.C / 16) {
-      case 1: launch_head_wgrad2<1>(p, workspace, blocks, stream); break;
-      case 2: launch_head_wgrad2<2>(p, workspace, blocks, stream); break;
-      case 4: launch_head_wgrad2<4>(p, workspace, blocks, stream); break;
-      case 8: launch_head_wgrad2<8>(p, workspace, blocks, stream); break;
-      default: blocks = 0; break;
-    }
+    const int cgs = S0.C / 16;
+    long long want = (nseg + 3) / 4 * cgs;
+    if (want > kHeadSlabs) want = kHeadSlabs;
+    const int blocks = (int)(want / cgs) * cgs;                       // a whole number of blocks per channel group
     if (blocks > 0) {
+      DN_LAUNCH(head_wgrad2_kernel, dim3(blocks), dim3(256), 0, stream, p, cgs, workspace);
       set_last_kernel("dn::head_wgrad2_kernel");
       int rc = check_launch("head_wgrad2_kernel");
       if (rc != DN_OK) return rc;
-      DN_LAUNCH(head_wgrad_reduce_kernel, dim3(9 * S0.C), dim3(256), 0, stream, p, workspace, blocks, dw);
+      DN_LAUNCH(head_wgrad_reduce_kernel, dim3(9 * S0.C), dim3(256), 0, stream, p, workspace, blocks, cgs, dw);
       return check_launch("head_wgrad_reduce_kernel");
     }
   }
@@ -467,7 +477,7 @@ int launch_head_wgrad(const IgemmParams& p, float* dw, float* workspace, hipStre
   int rc = check_launch("head_wgrad_kernel");
   if (rc != DN_OK) return rc;
   const int tot = p.ph[0].ntaps * p.in[0].C;
-  DN_LAUNCH(head_wgrad_reduce_kernel, dim3(tot), dim3(256), 0, stream, p, workspace, blocks, dw);
+  DN_LAUNCH(head_wgrad_reduce_kernel, dim3(tot), dim3(256), 0, stream, p, workspace, blocks, 1, dw);
   return check_launch("head_wgrad_reduce_kernel");
 }
 

@@ -47,6 +47,7 @@ struct LkGeo {
   int tilesX, tilesY, ntiles, per_xcd;
   int dy0, dx0;
   int cg0;                         // 8-channel groups of main operand 0 (operand 1 has CGT - cg0)
+  long long* dbg;                  // DN_LDS3_DBG (tools/lds3_timing.py): per-wave phase ticks, 8 per wave; nullptr otherwise
 };
 
 // CGT: 8-channel groups of the main operands together; NKS: K-steps per role; HAS1: trailing 1-channel operand; PH x MT x KQ = 8 roles;
@@ -70,7 +71,7 @@ struct LkCfg {
   static_assert(LDS <= 160 * 1024, "one block per CU");
 };
 
-template <int CGT, int NKS, bool HAS1, int PH, int MT, int KQ, int STRIDE, int TH, int TW, int ROWS, int COLS, int NOPS>
+template <int CGT, int NKS, bool HAS1, int PH, int MT, int KQ, int STRIDE, int TH, int TW, int ROWS, int COLS, int NOPS, bool DBG = false>
 __global__ void __launch_bounds__(512, 2) lds3k_conv_kernel(const IgemmParams p, const LkGeo geo) {
   using Cfg = LkCfg<CGT, NKS, HAS1, PH, MT, KQ, STRIDE, TH, TW, ROWS, COLS, NOPS>;
   extern __shared__ __align__(16) char lds[];
@@ -259,14 +260,23 @@ __global__ void __launch_bounds__(512, 2) lds3k_conv_kernel(const IgemmParams p,
 
   const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
   const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
+  long long tk[7] = {0, 0, 0, 0, 0, 0, 0}, c0t = 0, c1t = 0;   // DBG: load wait | split + LDS writes | barrier | load issue | matrix | exchange + stores | barrier
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if constexpr (DBG) { c1t = clock64(); tk[k] += c1t - c0t; c0t = c1t; }
+  };
   if (band_lo + local < band_hi) issue_loads(band_lo + local);
+  if constexpr (DBG) c0t = clock64();
   for (int t = band_lo + local; t < band_hi; t += nlocal) {
     const int txb = t % geo.tilesX, r1 = t / geo.tilesX;
     const int tyb = r1 % geo.tilesY, n = r1 / geo.tilesY;
     const int gy0 = tyb * TH, gx0 = txb * TW;
+    if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }
     store_lds();
+    stamp(1);
     __syncthreads();
+    stamp(2);
     if (t + nlocal < band_hi) issue_loads(t + nlocal);
+    stamp(3);
 
 #pragma unroll 1
     for (int i = 0; i < Cfg::PTB; i += 2) {
@@ -311,6 +321,7 @@ __global__ void __launch_bounds__(512, 2) lds3k_conv_kernel(const IgemmParams p,
 #pragma unroll
           for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][AS[q]], b[u][BS[q]], acc[u], 0, 0, 0);
       }
+      stamp(4);
       if constexpr (KQ == 1) {
         emit(n, gy0, gx0, i, acc[0]);
         emit(n, gy0, gx0, i + 1, acc[1]);
@@ -329,8 +340,17 @@ __global__ void __launch_bounds__(512, 2) lds3k_conv_kernel(const IgemmParams p,
           emit(n, gy0, gx0, i + kq, sum);
         }
       }
+      stamp(5);
     }
     __syncthreads();                                    // the next tile's staging overwrites the planes
+    stamp(6);
+  }
+  if constexpr (DBG) {
+    if (lane == 0) {
+      long long* o = geo.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int k = 0; k < 7; ++k) o[k] = tk[k];
+      o[7] = (band_hi - band_lo - local + nlocal - 1) / nlocal;
+    }
   }
 }
 
@@ -392,16 +412,17 @@ static LkPick lk_pick(const dn_conv_desc* d, const IgemmParams& p) {
   r.geo.dy0 = dy0;
   r.geo.dx0 = dx0;
   r.geo.cg0 = p.in[0].C / 8;
+  r.geo.dbg = nullptr;
   if (nmain == 2 && ((r.geo.cg0 & 3) || ((cgt - r.geo.cg0) & 3))) r.cfg = 0;      // staging lanes: 4 groups x 4 pixels per operand
   return r;
 }
 
 bool lds3k_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) { return lk_pick(d, p).cfg != 0; }
 
-template <int CGT, int NKS, bool HAS1, int PH, int MT, int KQ, int STRIDE, int TH, int TW, int ROWS, int COLS, int NOPS>
+template <int CGT, int NKS, bool HAS1, int PH, int MT, int KQ, int STRIDE, int TH, int TW, int ROWS, int COLS, int NOPS, bool DBG = false>
 static int lk_launch(const IgemmParams& p, const LkGeo& geo, hipStream_t stream) {
   using Cfg = LkCfg<CGT, NKS, HAS1, PH, MT, KQ, STRIDE, TH, TW, ROWS, COLS, NOPS>;
-  auto kernel = lds3k_conv_kernel<CGT, NKS, HAS1, PH, MT, KQ, STRIDE, TH, TW, ROWS, COLS, NOPS>;
+  auto kernel = lds3k_conv_kernel<CGT, NKS, HAS1, PH, MT, KQ, STRIDE, TH, TW, ROWS, COLS, NOPS, DBG>;
   const size_t lds = Cfg::LDS;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -419,7 +440,11 @@ static int lk_launch(const IgemmParams& p, const LkGeo& geo, hipStream_t stream)
 }
 
 int launch_lds3k_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t stream) {
-  const LkPick k = lk_pick(d, p);
+  LkPick k = lk_pick(d, p);
+  if (k.cfg == 1 && knobs().lds3_dbg) {                  // phase timestamps (tools/lds3_timing.py)
+    k.geo.dbg = reinterpret_cast<long long*>(knobs().wino_dbgptr);
+    return lk_launch<12, 7, true, 1, 2, 4, 1, 4, 32, 6, 34, 2, true>(p, k.geo, stream);
+  }
   switch (k.cfg) {
     case 1: return lk_launch<12, 7, true, 1, 2, 4, 1, 4, 32, 6, 34, 2>(p, k.geo, stream);
     case 2: return lk_launch<8, 8, false, 4, 2, 1, 1, 4, 32, 6, 34, 1>(p, k.geo, stream);

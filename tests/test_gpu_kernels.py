@@ -82,6 +82,9 @@ CONV_CASES = [
     ("3x3_head",          (32,),        (False,),          1, 3, 1, 1, False, 0, 2, 10, 14, ACT_SIGMOID_AFFINE, False),
     ("3x3_head_16",       (16,),        (False,),          1, 3, 1, 1, False, 0, 3, 17, 23, ACT_SIGMOID_AFFINE, False),
     ("3x3_head_128",      (128,),       (False,),          1, 3, 1, 1, False, 0, 2, 5, 9, ACT_SIGMOID_AFFINE, False),
+    ("3x3_head_64_tiles", (64,),        (False,),          1, 3, 1, 1, False, 0, 3, 21, 70, ACT_SIGMOID_AFFINE, False),    # 4 x 16 tiles, four channel groups per pixel, ragged
+    ("3x3_head_16_big",   (16,),        (False,),          1, 3, 1, 1, False, 0, 4, 125, 1000, ACT_SIGMOID_AFFINE, False), # 8 x 64 tiles (>= 1024 blocks)
+    ("3x3_head_32_big",   (32,),        (False,),          1, 3, 1, 1, False, 0, 4, 128, 1010, ACT_SIGMOID_AFFINE, False), # 8 x 64 tiles, two channel groups
     ("3x3_8_8",           (8,),         (False,),          24, 3, 1, 1, False, 0, 2, 9, 11, ACT_LEAKY, False),
     ("7x7_s2",            (3,),         (False,),          32, 7, 2, 3, False, 0, 2, 20, 28, ACT_RELU, False),
     ("5x5_s2",            (32,),        (False,),          64, 5, 2, 2, False, 0, 2, 18, 22, ACT_RELU, False),

@@ -26,13 +26,20 @@ else:                       # iconv0
 layer = engine.ConvLayer(mod)
 dy = torch.randn(N, H, W, cout, device=dev)
 names = ["load wait", "split + LDS writes", "barrier A", "load issue", "matrix loop", "barrier B"]
+fwd = len(sys.argv) > 3 and sys.argv[3] == "fwd"
+if fwd:
+    names = ["load wait", "split + LDS writes", "barrier A", "load issue", "matrix", "exchange + stores", "barrier B"]
 for it in range(3):
-    engine.conv_wgrad(layer, pieces, dy, (H, W))
+    if fwd:
+        engine.conv_forward(layer, pieces)
+    else:
+        engine.conv_wgrad(layer, pieces, dy, (H, W))
 torch.cuda.synchronize()
 print("kernel:", _lib.load().dn_last_kernel().decode())
 t = buf[: nblk * 8 * 8].view(nblk, 8, 8).cpu().double()[:, :nw]
-tiles = t[:, :, 6].clamp(min=1)
-per = t[:, :, :6] / tiles[:, :, None]
+nk = len(names)
+tiles = t[:, :, 7 if fwd else 6].clamp(min=1)
+per = t[:, :, :nk] / tiles[:, :, None]
 print("tiles per block: %.1f" % tiles.mean().item())
 print("%-22s" % "wave" + "".join("%10d" % w for w in range(nw)) + "      mean")
 for k, n in enumerate(names):
