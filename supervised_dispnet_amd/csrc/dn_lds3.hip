@@ -28,6 +28,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lds3_act(float v, int act, float p0, float p1) {
   switch (act) {
@@ -37,6 +38,31 @@ __device__ __forceinline__ float lds3_act(float v, int act, float p0, float p1) 
     case DN_ACT_SIGMOID_AFFINE: return p0 / (1.f + expf(-v)) + p1;
     default: return v;
   }
+}
+
+// four values at once: ONE (wave-uniform) branch on the activation instead of one per element
+__device__ __forceinline__ f32x4 lds3_act4(f32x4 v, int act, float p0, float p1) {
+  f32x4 r = v;
+  switch (act) {
+    case DN_ACT_RELU:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = v[e] > 0.f ? v[e] : 0.f;
+      break;
+    case DN_ACT_LEAKY:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = v[e] > 0.f ? v[e] : v[e] * p0;
+      break;
+    case DN_ACT_ELU:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = v[e] > 0.f ? v[e] : (expf(v[e]) - 1.f);
+      break;
+    case DN_ACT_SIGMOID_AFFINE:
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = p0 / (1.f + expf(-v[e])) + p1;
+      break;
+    default: break;
+  }
+  return r;
 }
 
 // x = h + m + l exactly (round to bf16, subtract, round, subtract: the last residual has <= 8 significant bits)
@@ -59,6 +85,8 @@ struct Lds3Geo {
   int tilesX, tilesY, ntiles;      // tiles per image along x / y, total (N * tilesY * tilesX)
   int dy0, dx0;                    // smallest tap offsets over all phases: the input tile starts at grid * stride + (dy0, dx0)
   int per_xcd;                     // tiles per XCD band (ceil(ntiles / 8))
+  long long* dbg;                  // DN_LDS3_DBG (tools/lds3_timing.py): per-wave phase ticks, 8 per wave; nullptr otherwise
+  int dbgmode;                     // its value: 2 = no prefetch loads, 3 = no result stores (timing ablations, wrong results)
 };
 
 // CG: 8-channel groups of the main operand (2: 16 channels, 4: 32); NKS: K-steps of 32 per role; HAS1: trailing 1-channel operand;
@@ -79,7 +107,7 @@ struct Lds3Cfg {
   static_assert(TW % 16 == 0 && PT_PER_WAVE % 2 == 0, "pixel tiles are processed in pairs");
 };
 
-template <int CG, int NKS, bool HAS1, int ROLES, int STRIDE, int TH, int TW, int ROWS, int COLS, bool PIPE>
+template <int CG, int NKS, bool HAS1, int ROLES, int STRIDE, int TH, int TW, int ROWS, int COLS, int PIPE>       // PIPE 2: 1 + phase timestamps
 __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, const Lds3Geo geo) {
   using Cfg = Lds3Cfg<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS>;
   constexpr int C = 8 * CG;
@@ -162,22 +190,46 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
   const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
   // The global loads of tile t + 1 are issued before tile t is computed and land in registers under its matrix instructions; split +
   // LDS writes follow the compute phase (one barrier each side).  Without the prefetch a block sat through a full memory latency per tile.
+  // The staging items of a thread never change: their tile-relative global offset, (row, column) for the bounds test and LDS address are
+  // computed once (per tile that leaves one add, two compares and a select per load; re-deriving them cost as many vector instructions
+  // as the split itself: tools/lds3_timing.py, 1.4 k of a tile's 12.7 k ticks in the load issue alone).
   constexpr int ITEMS = ROWS * COLS * CG, ROUNDS = (ITEMS + 255) / 256;
   f32x4 va[ROUNDS], vb[ROUNDS];
   float dv[2] = {0.f, 0.f};
+  int goff[ROUNDS], rowcol[ROUNDS], ldst[ROUNDS];          // rowcol: row << 16 | column, or -1 for a dead slot
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int it = tid + 256 * r;
+    const int cg = it % CG, px = it / CG;
+    const int row = px / COLS, col = px - row * COLS;
+    const int idx = STRIDE == 2 ? ((col & 1) * Cfg::HALFC + (col >> 1)) : col;
+    goff[r] = (row * (int)S.sh + col * (int)S.sw + 8 * cg) * 4;
+    rowcol[r] = it < ITEMS ? (row << 16 | col) : -1;
+    ldst[r] = cg * Cfg::CGSTRIDE + (row * Cfg::COLSP + idx) * 16;
+  }
+  int goff1[2] = {0, 0}, rowcol1[2] = {-1, -1};
+  int sh1 = 0, up1 = 0;
+  if constexpr (HAS1) {
+    const KOperand& S1 = p.in[1];
+    sh1 = (int)S1.sh;
+    up1 = S1.up;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int it = tid + 256 * r;
+      const int row = it / COLS, col = it - row * COLS;
+      rowcol1[r] = it < ROWS * COLS ? (row << 16 | col) : -1;
+    }
+  }
   auto issue_loads = [&](int t) __attribute__((always_inline)) {
     const int txb = t % geo.tilesX, r1 = t / geo.tilesX;
     const int tyb = r1 % geo.tilesY, n = r1 / geo.tilesY;
     const int iy0 = tyb * TH * STRIDE + geo.dy0, ix0 = txb * TW * STRIDE + geo.dx0;
-    const int nbase = n * (int)S.sn;
+    const int tbase = (n * (int)S.sn + iy0 * (int)S.sh + ix0 * (int)S.sw) * 4;                // (scalar)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      const int it = tid + 256 * r;
-      const int cg = it % CG, px = it / CG;
-      const int row = px / COLS, col = px - row * COLS;
-      const int iy = iy0 + row, ix = ix0 + col;
-      const bool ok = it < ITEMS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      const int off = (nbase + iy * (int)S.sh + ix * (int)S.sw + 8 * cg) * 4;
+      const int iy = iy0 + (rowcol[r] >> 16), ix = ix0 + (rowcol[r] & 0xffff);
+      const bool ok = rowcol[r] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const int off = tbase + goff[r];
       va[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : -1, 0, 0));
       vb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off + 16 : -1, 0, 0));
     }
@@ -185,11 +237,9 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
       const KOperand& S1 = p.in[1];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int it = tid + 256 * r;
-        const int row = it / COLS, col = it - row * COLS;
-        const int iy = iy0 + row, ix = ix0 + col;
-        const bool ok = it < ROWS * COLS && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-        const int off = (n * (int)S1.sn + (iy >> S1.up) * (int)S1.sh + (ix >> S1.up) * (int)S1.sw) * 4;
+        const int iy = iy0 + (rowcol1[r] >> 16), ix = ix0 + (rowcol1[r] & 0xffff);
+        const bool ok = rowcol1[r] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int off = (n * (int)S1.sn + (iy >> up1) * sh1 + (ix >> up1) * (int)S1.sw) * 4;
         dv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc1, ok ? off : -1, 0, 0));
       }
     }
@@ -197,15 +247,11 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
   auto store_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      const int it = tid + 256 * r;
-      if (it < ITEMS) {
-        const int cg = it % CG, px = it / CG;
-        const int row = px / COLS, col = px - row * COLS;
-        const int idx = STRIDE == 2 ? ((col & 1) * Cfg::HALFC + (col >> 1)) : col;
+      if (rowcol[r] >= 0) {
         const float v[8] = {va[r][0], va[r][1], va[r][2], va[r][3], vb[r][0], vb[r][1], vb[r][2], vb[r][3]};
         bf16x8 h, m, l;
         split3(v, h, m, l);
-        char* dst = lds + cg * Cfg::CGSTRIDE + (row * Cfg::COLSP + idx) * 16;
+        char* dst = lds + ldst[r];
         *reinterpret_cast<bf16x8*>(dst) = h;
         *reinterpret_cast<bf16x8*>(dst + Cfg::PSTRIDE) = m;
         *reinterpret_cast<bf16x8*>(dst + 2 * Cfg::PSTRIDE) = l;
@@ -218,14 +264,38 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
         if (tid + 256 * r < ROWS * COLS) dpl[tid + 256 * r] = dv[r];
     }
   };
+  constexpr bool DBG = PIPE == 2;
+  long long tk[6] = {0, 0, 0, 0, 0, 0}, c0t = 0, c1t = 0;             // DBG: load wait | split + LDS writes | barrier | load issue | matrix + stores | barrier
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if constexpr (DBG) { c1t = clock64(); tk[k] += c1t - c0t; c0t = c1t; }
+  };
+  // Everything the epilogue reads that came through a vector-memory load (the per-lane result descriptor, the bias) is CONSUMED here,
+  // ahead of the loop: the compiler waits for a loaded register at its first use, the counter is in order, and a first use inside the
+  // loop put an s_waitcnt vmcnt(0) between the issue of the next tile's loads and this tile's matrix instructions -- the prefetch never
+  // ran under the compute (found in the ISA, round 4; tools/lds3_timing.py).
+  asm volatile("" ::"v"(R.p), "v"(R.sn), "v"(R.sh), "v"(R.sw), "v"(R.accumulate), "v"(bias[0]), "v"(bias[1]), "v"(bias[2]), "v"(bias[3]));
+  // Fast result path (ONE plain result tensor, float4-addressable, below 2 GB -- every layer of the metric's nets): a raw buffer store per
+  // 16-pixel tile whose out-of-range lanes carry offset -1 (dropped by the hardware), the tile's scalar base + a per-lane constant as
+  // the address.  The general path below walks the result segments per element under exec masks: ~150 instructions and ten branches
+  // per pixel tile, 2.5 k of a tile's 9 k matrix-phase ticks (tools/lds3_timing.py).
+  const KResult& R0 = p.out[0];
+  const bool fast_out = p.n_out == 1 && !R0.accumulate && R0.n_begin == 0 && (p.Ntot & 3) == 0 && ((R0.sw | R0.sh | R0.sn) & 3) == 0 &&
+                        (reinterpret_cast<uintptr_t>(R0.p) & 15) == 0 && (long long)p.N * R0.sn * 4 < (1ll << 31);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(R0.p, 0, 0x80000000u, 0x00020000);
+  const int lane_out = (j * p.osx * (int)R0.sw + n0) * 4;
   if (band_lo + local < band_hi) issue_loads(band_lo + local);
+  if constexpr (DBG) c0t = clock64();
   for (int t = band_lo + local; t < band_hi; t += nlocal) {
     const int txb = t % geo.tilesX, r1 = t / geo.tilesX;
     const int tyb = r1 % geo.tilesY, n = r1 / geo.tilesY;
     const int gy0 = tyb * TH, gx0 = txb * TW;
+    if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }
     store_lds();
+    stamp(1);
     __syncthreads();
-    if (t + nlocal < band_hi) issue_loads(t + nlocal);
+    stamp(2);
+    if (t + nlocal < band_hi && !(DBG && geo.dbgmode == 2)) issue_loads(t + nlocal);
+    stamp(3);
 
     // ---- the wave's pixel tiles, two at a time (independent accumulators)
 #pragma unroll 1
@@ -247,7 +317,7 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
 #pragma unroll
           for (int P = 0; P < 3; ++P) b[u][P] = *reinterpret_cast<const bf16x8*>(lds + P * Cfg::PSTRIDE + lbase[u] + boff[ks]);
         if constexpr (HAS1) {
-          if (ks == NKS - 1) {
+          if (ks == NKS - 1 && !(DBG && geo.dbgmode == 4)) {
             const float* dpl = reinterpret_cast<const float*>(lds + 3 * Cfg::PSTRIDE);
             const int t0 = (g & 1) * 8;
 #pragma unroll
@@ -294,13 +364,28 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
         }
       }
       // ---- epilogue: lane (j, g) holds output channels n0 .. n0 + 3 of grid point (gy, gx0 + 16 * tx16 + j)
+      if (fast_out) {
+        const int tbase = (n * (int)R0.sn + (gy0 * p.osy + ph.ooy) * (int)R0.sh + (gx0 * p.osx + ph.oox) * (int)R0.sw) * 4;      // (scalar)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pt = sub + Cfg::WAVES_PER_ROLE * (i + u);
+          const int ty = pt / (TW / 16), tx16 = pt - ty * (TW / 16);
+          const int gy = gy0 + ty, gx = gx0 + tx16 * 16 + j;
+          const int oy = gy * p.osy + ph.ooy, ox = gx * p.osx + ph.oox;
+          const bool ok = gy < p.GH && gx < p.GW && oy < p.OH && ox < p.OW && n0 < p.Ntot && !(DBG && geo.dbgmode == 3 && acc[u][0] != 12345.678f);
+          const f32x4 w4 = lds3_act4(acc[u] + f32x4{bias[0], bias[1], bias[2], bias[3]}, p.act, p.act_p0, p.act_p1);
+          const int off = tbase + (ty * p.osy * (int)R0.sh + tx16 * 16 * p.osx * (int)R0.sw) * 4 + lane_out;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w4), rout, ok ? off : -1, 0, 0);
+        }
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int pt = sub + Cfg::WAVES_PER_ROLE * (i + u);
         const int ty = pt / (TW / 16), tx16 = pt - ty * (TW / 16);
         const int gy = gy0 + ty, gx = gx0 + tx16 * 16 + j;
         const int oy = gy * p.osy + ph.ooy, ox = gx * p.osx + ph.oox;
-        if (gy < p.GH && gx < p.GW && oy < p.OH && ox < p.OW && n0 < p.Ntot) {
+        if (gy < p.GH && gx < p.GW && oy < p.OH && ox < p.OW && n0 < p.Ntot && !(DBG && geo.dbgmode == 3 && acc[u][0] != 12345.678f)) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = lds3_act(acc[u][e] + bias[e], p.act, p.act_p0, p.act_p1);
@@ -326,7 +411,16 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
         }
       }
     }
+    stamp(4);
     __syncthreads();                                   // the next tile's staging overwrites the planes
+    stamp(5);
+  }
+  if constexpr (DBG) {
+    if (lane == 0) {
+      long long* o = geo.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int k = 0; k < 6; ++k) o[k] = tk[k];
+      o[6] = (band_hi - band_lo - local + nlocal - 1) / nlocal;
+    }
   }
 }
 
@@ -590,6 +684,8 @@ static Lds3Pick lds3_pick(const dn_conv_desc* d, const IgemmParams& p) {
   r.geo.dy0 = dy0;
   r.geo.dx0 = dx0;
   r.geo.per_xcd = (r.geo.ntiles + 7) / 8;
+  r.geo.dbg = knobs().lds3_dbg ? reinterpret_cast<long long*>(knobs().wino_dbgptr) : nullptr;
+  r.geo.dbgmode = knobs().lds3_dbg;
   return r;
 }
 
@@ -599,7 +695,10 @@ template <int CG, int NKS, bool HAS1, int ROLES, int STRIDE, int TH, int TW, int
 static int lds3_launch(const IgemmParams& p, const Lds3Geo& geo, hipStream_t stream) {
   using Cfg = Lds3Cfg<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS>;
   static const bool nopipe = getenv("DN_LDS3_NOPIPE") != nullptr;
-  auto kernel = nopipe ? lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, false> : lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, true>;
+  auto kernel = nopipe ? lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, 0> : lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, 1>;
+  if constexpr (CG == 2 && HAS1) {                                  // phase timestamps of the iconv0 forward form (tools/lds3_timing.py)
+    if (geo.dbg != nullptr) kernel = lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, 2>;
+  }
   const size_t lds = Cfg::LDS;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -609,6 +708,7 @@ static int lds3_launch(const IgemmParams& p, const Lds3Geo& geo, hipStream_t str
     }
   }
   int blocks = geo.ntiles < 512 ? geo.ntiles : 512;            // two resident blocks per CU, persistent over the tiles
+  if (geo.dbg != nullptr && geo.dbgmode == 5) blocks = 256;     // (timing: one block per CU)
   blocks = (blocks + 7) / 8 * 8;
   DN_LAUNCH(kernel, dim3(blocks), dim3(256), lds, stream, p, geo);
   set_last_kernel("dn::lds3_conv_kernel<%d, %d, %s, %d, %d, %d, %d, %d, %d, %s>", CG, NKS, HAS1 ? "true" : "false", ROLES, STRIDE, TH, TW, ROWS, COLS,

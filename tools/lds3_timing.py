@@ -27,8 +27,10 @@ layer = engine.ConvLayer(mod)
 dy = torch.randn(N, H, W, cout, device=dev)
 names = ["load wait", "split + LDS writes", "barrier A", "load issue", "matrix loop", "barrier B"]
 fwd = len(sys.argv) > 3 and sys.argv[3] == "fwd"
-if fwd:
+if fwd and which == "iconv1":
     names = ["load wait", "split + LDS writes", "barrier A", "load issue", "matrix", "exchange + stores", "barrier B"]
+elif fwd:
+    names = ["load wait", "split + LDS writes", "barrier A", "load issue", "matrix + stores", "barrier B"]
 for it in range(3):
     if fwd:
         engine.conv_forward(layer, pieces)
@@ -38,7 +40,7 @@ torch.cuda.synchronize()
 print("kernel:", _lib.load().dn_last_kernel().decode())
 t = buf[: nblk * 8 * 8].view(nblk, 8, 8).cpu().double()[:, :nw]
 nk = len(names)
-tiles = t[:, :, 7 if fwd else 6].clamp(min=1)
+tiles = t[:, :, 7 if nk == 7 else 6].clamp(min=1)
 per = t[:, :, :nk] / tiles[:, :, None]
 print("tiles per block: %.1f" % tiles.mean().item())
 print("%-22s" % "wave" + "".join("%10d" % w for w in range(nw)) + "      mean")
