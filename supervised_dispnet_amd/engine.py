@@ -570,7 +570,7 @@ class ConvLayer:
             wc = wc.contiguous()
         _lib.call("dn_conv_pack_weights", C.byref(desc), wc.data_ptr(), buf.data_ptr(), _stream())
         self._packed[(kind, layout)] = (key, buf)
-        if table is not None and contiguous:
+        if table is not None and contiguous and not getattr(self.m, "no_batch_pack", False):
             table.register((id(self), kind, layout) + split, desc, w, buf, self)
         elif table is not None and table.rows.pop((id(self), kind, layout) + split, None) is not None:
             table.dirty = True                   # a row of this layer must never outlive the buffer it points at
@@ -1477,6 +1477,9 @@ class _CompositeConvT(object):
     """Stand-in for the nn.ConvTranspose2d(6x6, stride 2, padding 2) that one branch of FCRN's up-projection amounts to; `.weight` is a
     plain tensor [Cin][Cout][6][6] rebuilt from the branch's four nn.Conv2d weights before every use (assemble / scatter_grad)."""
     kernel_size, stride, padding, output_padding, dilation, bias = (6, 6), (2, 2), (2, 2), (0, 0), (1, 1), None
+    # `.weight` is scratch rebuilt in place before every use: a row in the batched re-lay table would re-lay STALE contents on the side
+    # stream every step, mark the table dirty (a blocking host-to-device upload) and race the ordinary re-pack that follows (ADVICE r3)
+    no_batch_pack = True
 
     def __init__(self, convs):
         self.convs = convs                                  # phase order (0,0), (0,1), (1,0), (1,1)
