@@ -13,7 +13,7 @@ import sys
 HERE = pathlib.Path(__file__).resolve().parent
 PKG = HERE.parent
 ROOT = PKG.parent
-SOURCES = ["dn_plan.hip", "dn_conv.hip", "dn_pointwise.hip", "dn_loss.hip", "dn_warp.hip", "dn_ordinal.hip", "dn_ordhead.hip", "dn_direct.hip", "dn_winograd.hip", "dn_winograd8.hip", "dn_winograd_wgrad.hip", "dn_thin.hip", "dn_lds3.hip", "dn_lds3k.hip", "dn_lds3_wgrad.hip", "dn_wgrad_x3.hip", "dn_input.hip", "dn_zoo.hip", "dn_ubench.hip", "dn_tape.hip"]
+SOURCES = ["dn_plan.hip", "dn_conv.hip", "dn_pointwise.hip", "dn_loss.hip", "dn_warp.hip", "dn_ordinal.hip", "dn_ordhead.hip", "dn_direct.hip", "dn_winograd.hip", "dn_winograd8.hip", "dn_winograd_wgrad.hip", "dn_thin.hip", "dn_lds3.hip", "dn_lds3k.hip", "dn_lds3_wgrad.hip", "dn_stemk.hip", "dn_wgrad_x3.hip", "dn_input.hip", "dn_zoo.hip", "dn_ubench.hip", "dn_tape.hip"]
 OUT = PKG / "libdispnet_hip.so"
 ARCH = "gfx950"
 

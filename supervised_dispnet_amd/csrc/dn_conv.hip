@@ -2287,6 +2287,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     return launch_wino_conv(p, s);
   }
   if (stem3_conv_eligible(d, p)) return launch_stem3_conv(p, s);
+  if (stemk_conv_eligible(d, p)) return launch_stemk_conv(d, p, s);
   if (stem_eligible(d, p)) return launch_stem(p, s);
   if (lds3_conv_eligible(d, p)) return launch_lds3_conv(d, p, s);
   if (lds3k_conv_eligible(d, p)) return launch_lds3k_conv(d, p, s);

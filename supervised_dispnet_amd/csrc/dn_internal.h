@@ -234,6 +234,8 @@ int launch_wgrad_x3(const IgemmParams& p, hipStream_t stream);
 bool lds3k_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
 int launch_lds3k_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t stream);
 bool stem3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
+bool stemk_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);      // dn_stemk.hip: 7x7 / stride-2 first layers
+int launch_stemk_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t stream);
 int launch_stem3_conv(const IgemmParams& p, hipStream_t stream);
 
 }  // namespace dn

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) lds3_conv_kernel(const IgemmParams p, 
     rowcol[r] = it < ITEMS ? (row << 16 | col) : -1;
     ldst[r] = cg * Cfg::CGSTRIDE + (row * Cfg::COLSP + idx) * 16;
   }
-  int goff1[2] = {0, 0}, rowcol1[2] = {-1, -1};
+  int rowcol1[2] = {-1, -1};
   int sh1 = 0, up1 = 0;
   if constexpr (HAS1) {
     const KOperand& S1 = p.in[1];

@@ -104,6 +104,8 @@ CONV_CASES = [
     ("convT_k4s2p1_32_16", (32,),       (False,),          16, 4, 2, 1, True, 0, 2, 9, 21, ACT_LEAKY, False),     # lds3: upconv0 (four phases / stride-2 gather)
     ("convT_k4s2p1_32_16_tiles", (32,), (False,),          16, 4, 2, 1, True, 0, 3, 20, 70, ACT_LEAKY, False),
     ("convT_k3s2p1op1",   (32,),        (False,),          16, 3, 2, 1, True, 1, 2, 5, 7, ACT_RELU, False),
+    ("7x7_s2_res_first_nchw", (3,),     (False,),          64, 7, 2, 3, False, 0, 4, 128, 512, ACT_NONE, False),   # stemk: ResNet conv1 form (16 x 32 tiles)
+    ("7x7_s2_pose_first_nchw", (3, 3, 3), (False, False, False), 16, 7, 2, 3, False, 0, 2, 128, 512, ACT_LEAKY, False),   # stemk: PoseExpNet conv1 form, three NCHW operands
 ]
 
 
@@ -213,6 +215,42 @@ def test_conv_bn_pool_block(shape):
     # conv bias in front of BN: exact zeros here, rounding noise in the reference
     assert float(sink.get(dev_mods[0].bias).abs().max()) == 0.0
     assert float(ref[0].bias.grad.abs().max()) < 1e-3      # pure rounding noise; its size depends on ATen's summation order
+
+
+@pytest.mark.parametrize("form", ["res", "pose"])
+def test_stemk_first_layers(form):
+    """The 7x7 / stride-2 first layers on NCHW images (dn::stemk_conv_kernel): ResNet conv1 (3 -> 64) with the BatchNorm partial
+    statistics of its epilogue -- BatchNorm(train) + ReLU of the result and the running statistics against torch --, and PoseExpNet
+    conv1 (three 3-channel images -> 16, ReLU).  The kernel that ran is named."""
+    torch.manual_seed(11)
+    N, H, W, cins, cout = (4, 128, 512, (3,), 64) if form == "res" else (2, 128, 512, (3, 3, 3), 16)
+    mod = nn.Conv2d(sum(cins), cout, 7, 2, 3)
+    xs = [rnd(N, c, H, W, seed=30 + i) for i, c in enumerate(cins)]
+    mod_d = nn.Conv2d(sum(cins), cout, 7, 2, 3).to(DEV)
+    mod_d.load_state_dict(mod.state_dict())
+    layer = engine.ConvLayer(mod_d)
+    pieces = [engine.Piece(engine.Act.from_nchw_image(x.to(DEV))) for x in xs]
+    act = ACT_NONE if form == "res" else ACT_RELU
+    y_t, _, _ = engine.conv_forward(layer, pieces, act)
+    assert "stemk_conv_kernel" in _lib.load().dn_last_kernel().decode()
+    pre = mod(torch.cat(xs, 1))
+    close(form + ":y", nchw(y_t), pre if form == "res" else F.relu(pre))
+    if form == "res":
+        bn = nn.BatchNorm2d(cout)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.2, 0.2)
+        bn_d = nn.BatchNorm2d(cout).to(DEV)
+        bn_d.load_state_dict(bn.state_dict())
+        bn.train()
+        ref = F.relu(bn(pre))
+        tape, sink = engine.Tape(True), engine.GradSink()
+        y = engine.block_conv_bn(tape, sink, pieces[0], layer, bn_d, True)
+        torch.cuda.synchronize()
+        out = torch.relu(y.t * y.scale + y.shift)
+        close("res:bn_relu", nchw(out), ref, rtol=1e-3, atol_rel=1e-4)
+        close("res:running_mean", bn_d.running_mean, bn.running_mean, rtol=1e-4)
+        close("res:running_var", bn_d.running_var, bn.running_var, rtol=1e-4)
 
 
 def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
