@@ -2585,6 +2585,7 @@ size_t dn_conv_wgrad_workspace_bytes(const dn_conv_desc* fwd) {
   if (thin_wgrad_eligible(fwd, p) && thin_wgrad_workspace_bytes(p) > need) need = thin_wgrad_workspace_bytes(p);
   if (lds3_wgrad_eligible(fwd, p) && lds3_wgrad_workspace_bytes(p) > need) need = lds3_wgrad_workspace_bytes(p);
   if (lds3k_wgrad_eligible(fwd, p) && lds3k_wgrad_workspace_bytes(p) > need) need = lds3k_wgrad_workspace_bytes(p);
+  if (stemk_wgrad_workspace_bytes(fwd, p) > need) need = stemk_wgrad_workspace_bytes(fwd, p);
   {
     dn_conv_desc d1, d2;
     IgemmParams p1, p2;
@@ -2630,6 +2631,12 @@ int dn_conv2d_wgrad(const dn_conv_desc* fwd, const float* dy, float* dw, void* w
     p.g = dy;
     p.ws = reinterpret_cast<float*>(workspace);
     return launch_lds3k_wgrad(fwd, p, dw, as_stream(stream));
+  }
+  if (stemk_wgrad_eligible(fwd, p) && workspace_bytes >= stemk_wgrad_workspace_bytes(fwd, p) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+    for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);
+    p.g = dy;
+    p.ws = reinterpret_cast<float*>(workspace);
+    return launch_stemk_wgrad(fwd, p, dw, as_stream(stream));        // 7x7 / stride-2 first layers on NCHW images (dn_stemk.hip)
   }
   if (thin_wgrad_eligible(fwd, p) && workspace_bytes >= thin_wgrad_workspace_bytes(p)) {
     for (int i = 0; i < p.n_in; ++i) DN_REQUIRE(p.in[i].p != nullptr, DN_ERR_BAD_ARG, "operand %d has no data", i);

@@ -236,6 +236,9 @@ int launch_lds3k_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t s
 bool stem3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);
 bool stemk_conv_eligible(const dn_conv_desc* d, const IgemmParams& p);      // dn_stemk.hip: 7x7 / stride-2 first layers
 int launch_stemk_conv(const dn_conv_desc* d, const IgemmParams& p, hipStream_t stream);
+bool stemk_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p);
+size_t stemk_wgrad_workspace_bytes(const dn_conv_desc* d, const IgemmParams& p);
+int launch_stemk_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStream_t stream);
 int launch_stem3_conv(const IgemmParams& p, hipStream_t stream);
 
 }  // namespace dn

@@ -299,6 +299,188 @@ __global__ void __launch_bounds__(512, 1) stemk_conv_kernel(const IgemmParams p,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- weight gradient
+// dW[co][k] = sum over pixels of dy[pixel][co] * x[2 pixel + tap][c], k in the kernel's (plane, tap row, tap column + 1) order: 8 x 7 x planes
+// columns in N tiles of 16, the contraction over PIXELS in K-steps of 32 (lane group g = eight consecutive output pixels of one row).
+//   * dy (NHWC) is transposed by the staging threads into channel-planar three-piece planes (8 pixels per 16-byte word), as in
+//     lds3_wgrad_stem_kernel; x is fetched like the forward kernel's tile (aligned 16-byte loads along x) and stored with its columns
+//     de-interleaved by PARITY, so that the eight stride-2 samples of a lane are eight consecutive floats (8 ds_read_b32, split in registers);
+//   * a wave owns whole N tiles (columns) for ALL pixels: accumulators stay in registers across the persistent block's tiles, no wave meets
+//     another; one slab per block in the packed-weight K order, folded by wgrad_reduce_kernel in a fixed order.
+template <int MT, int TW, int NPL>
+struct SkwCfg {
+  static constexpr int TH = 4;
+  static constexpr int ROWS = 2 * (TH - 1) + 7;                 // 13 input rows
+  static constexpr int COLS4 = (2 * TW + 8) / 4;
+  static constexpr int COLSP = 4 * COLS4, HALF = COLSP / 2;
+  static constexpr int PLANE = ROWS * COLSP;                    // floats
+  static constexpr int NCOMBO = 7 * NPL;
+  static constexpr int NT = (8 * NCOMBO + 15) / 16;             // N tiles of 16 columns
+  static constexpr int NTW = (NT + 3) / 4;                      // per wave
+  static constexpr int PX = TH * TW;                            // pixels per tile
+  static constexpr int KSTEPS = PX / 32;
+  static constexpr int GSTR = PX * 2 + 16;                      // bytes between the dy planes of two output channels
+  static constexpr int GPIECE = 16 * MT * GSTR;
+  static constexpr size_t G_B = (size_t)3 * GPIECE;
+  static constexpr size_t LDS = G_B + (size_t)NPL * PLANE * 4;
+  static constexpr int XITEMS = NPL * ROWS * COLS4, XROUNDS = (XITEMS + 255) / 256;
+  static constexpr int GITEMS = 4 * MT * (PX / 8);              // (channel quad, 8-pixel group)
+  static_assert(GITEMS <= 256, "one dy item per thread");
+  static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
+};
+
+template <int MT, int TW, int NPL>
+__global__ void __launch_bounds__(256, 2) stemk_wgrad_kernel(const IgemmParams p, const SkGeo geo, long long slab_floats) {
+  using Cfg = SkwCfg<MT, TW, NPL>;
+  constexpr int COLSP = Cfg::COLSP, HALF = Cfg::HALF, PLANE = Cfg::PLANE, NTW = Cfg::NTW;
+  extern __shared__ __align__(16) char lds[];
+  char* Gp = lds;
+  float* Ip = reinterpret_cast<float*>(lds + Cfg::G_B);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const KOperand& S = p.in[0];                              // (all operands have the strides of the first: stemk_form)
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+  __amdgpu_buffer_rsrc_t rin[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) rin[o] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in[o < p.n_in ? o : 0].p), 0, 0x80000000u, 0x00020000);
+
+  f32x4 acc[NTW][MT];
+#pragma unroll
+  for (int u = 0; u < NTW; ++u)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[u][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's column of N tile wave + 4 u: (combination, slot e) -> offset of its sample for pixel (row 0, column 0) in the planes
+  int ioff[NTW];
+  bool ilive[NTW];
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    const int col = 16 * (wave + 4 * u) + j, combo = col >> 3, e = col & 7;
+    ilive[u] = combo < Cfg::NCOMBO && e != 0 && wave + 4 * u < Cfg::NT;
+    const int plane = ilive[u] ? combo / 7 : 0, r = ilive[u] ? combo % 7 : 0;
+    ioff[u] = plane * PLANE + r * COLSP + (e & 1) * HALF + (e >> 1);
+  }
+
+  // ---- staging roles
+  f32x4 vg[8], vx[Cfg::XROUNDS];
+  const int gq = tid % (4 * MT), gpx = tid / (4 * MT);            // dy item: channel quad, 8-pixel group (linear pixel index / 8)
+  int xofs[Cfg::XROUNDS], xrc[Cfg::XROUNDS], xdst[Cfg::XROUNDS], xop[Cfg::XROUNDS];
+#pragma unroll
+  for (int r = 0; r < Cfg::XROUNDS; ++r) {
+    const int it = tid + 256 * r;
+    const int q4 = it % Cfg::COLS4, rr = it / Cfg::COLS4;
+    const int row = rr % Cfg::ROWS, plane = rr / Cfg::ROWS;
+    const bool live = it < Cfg::XITEMS;
+    const int op = live ? geo.plane_op[plane] : 0, c = live ? geo.plane_c[plane] : 0;
+    xofs[r] = (row * (int)S.sh + 4 * q4 + c * (int)S.sc) * 4;
+    xrc[r] = live ? (row << 16 | (4 * q4)) : -1;
+    xdst[r] = plane * PLANE + row * COLSP + 2 * q4;             // parity 0 half; parity 1 at + HALF
+    xop[r] = op;
+  }
+  auto issue_loads = [&](int t) __attribute__((always_inline)) {
+    const int txb = t % geo.tilesX, q1 = t / geo.tilesX;
+    const int tyb = q1 % geo.tilesY, n = q1 / geo.tilesY;
+    {
+      const int lin = 8 * gpx, row = lin / TW, col = lin - row * TW;
+      const int gy = tyb * Cfg::TH + row, gx = txb * TW + col;
+      const int base = (((n * p.GH + gy) * p.GW + gx) * p.Ntot + 4 * gq) * 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        vg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, tid < Cfg::GITEMS ? base + i * p.Ntot * 4 : -1, 0, 0));
+    }
+    const int iy0 = 2 * tyb * Cfg::TH - 3, ix0 = 2 * txb * TW - 4;
+#pragma unroll
+    for (int r = 0; r < Cfg::XROUNDS; ++r) {
+      const int iy = iy0 + (xrc[r] >> 16), ix = ix0 + (xrc[r] & 0xffff);
+      const bool ok = xrc[r] >= 0 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const int off = (n * (int)S.sn + iy0 * (int)S.sh + ix0) * 4 + xofs[r];
+      f32x4 v;
+      if (xop[r] == 0) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin[0], ok ? off : -1, 0, 0));
+      else if (xop[r] == 1) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin[1], ok ? off : -1, 0, 0));
+      else v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin[2], ok ? off : -1, 0, 0));
+      vx[r] = v;
+    }
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+    if (tid < Cfg::GITEMS) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v[8] = {vg[0][e], vg[1][e], vg[2][e], vg[3][e], vg[4][e], vg[5][e], vg[6][e], vg[7][e]};
+        bf16x8 h, m, l;
+        sk_split3(v, h, m, l);
+        char* dst = Gp + (4 * gq + e) * Cfg::GSTR + gpx * 16;
+        *reinterpret_cast<bf16x8*>(dst) = h;
+        *reinterpret_cast<bf16x8*>(dst + Cfg::GPIECE) = m;
+        *reinterpret_cast<bf16x8*>(dst + 2 * Cfg::GPIECE) = l;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < Cfg::XROUNDS; ++r) {
+      if (xrc[r] >= 0) {
+        *reinterpret_cast<f32x2*>(Ip + xdst[r]) = f32x2{vx[r][0], vx[r][2]};
+        *reinterpret_cast<f32x2*>(Ip + xdst[r] + HALF) = f32x2{vx[r][1], vx[r][3]};
+      }
+    }
+  };
+
+  const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
+  const int band_lo = xcd * geo.per_xcd, band_hi = min(band_lo + geo.per_xcd, geo.ntiles);
+  constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
+  if (band_lo + local < band_hi) issue_loads(band_lo + local);
+  for (int t = band_lo + local; t < band_hi; t += nlocal) {
+    store_lds();
+    __syncthreads();
+    if (t + nlocal < band_hi) issue_loads(t + nlocal);
+#pragma unroll 1
+    for (int ks = 0; ks < Cfg::KSTEPS; ++ks) {
+      const int lin = 32 * ks + 8 * g, orow = lin / TW, ox0 = lin - orow * TW;     // this lane group's eight pixels
+      bf16x8 a[MT][3];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int P = 0; P < 3; ++P) a[m][P] = *reinterpret_cast<const bf16x8*>(Gp + P * Cfg::GPIECE + (16 * m + j) * Cfg::GSTR + lin * 2);
+      const float* xb = Ip + 2 * orow * COLSP + ox0;
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        if (wave + 4 * u < Cfg::NT) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float x = xb[ioff[u] + i];
+            v[i] = ilive[u] ? x : 0.f;
+          }
+          bf16x8 b[3];
+          sk_split3(v, b[0], b[1], b[2]);
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][AS[q]], b[BS[q]], acc[u][m], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- every wave owns its columns: straight into the block's slab ws[block][co][k] (k = packed-weight order)
+  const int Kp = p.ph[0].nchunks * kChunk;
+  float* slab = p.ws + (long long)blockIdx.x * slab_floats;
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    if (ilive[u]) {
+      const int col = 16 * (wave + 4 * u) + j, combo = col >> 3, e = col & 7;
+      const int plane = combo / 7, r = combo - 7 * plane;
+      const int op = geo.plane_op[plane], c = geo.plane_c[plane];
+      const int k = geo.kbase[op] + (7 * r + (e - 1)) * p.in[op].C + c;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = 16 * m + 4 * g + q;
+          if (co < p.Ntot) slab[(long long)co * Kp + k] = acc[u][m][q];
+        }
+    }
+  }
+}
+
 // 0: none, 1: ResNet conv1 form <4, 32, 3>, 2: PoseExpNet conv1 form <1, 16, 9>
 static int stemk_form(const dn_conv_desc* d, const IgemmParams& p, SkGeo* geo) {
   static const bool off = getenv("DN_NO_STEMK") != nullptr;
@@ -336,6 +518,86 @@ static int stemk_form(const dn_conv_desc* d, const IgemmParams& p, SkGeo* geo) {
   geo->per_xcd = (geo->ntiles + 7) / 8;
   if (geo->ntiles < 128) return 0;
   return form;
+}
+
+// the weight-gradient plan of the same layers (p.g = dy, p.in = the images, grid = output pixels)
+static int stemk_wgrad_form(const dn_conv_desc* d, const IgemmParams& p, SkGeo* geo) {
+  static const bool off = getenv("DN_NO_STEMK") != nullptr;
+  if (off || knobs().no_lds3_wgrad || d->compute != DN_COMPUTE_F32X3) return 0;
+  if (d->kind != DN_CONV_FWD || d->R != 7 || d->S != 7 || d->stride != 2 || d->pad != 3 || d->pad_mode != 0 || d->dilation > 1) return 0;
+  if (p.n_in < 1 || p.n_in > 3 || p.ph[0].ntaps != 49) return 0;
+  if ((d->IH & 1) || (d->IW & 3) || p.GH * 2 != d->IH || p.GW * 2 != d->IW) return 0;
+  if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.g) & 15) || (p.Ntot & 3)) return 0;
+  for (int t = 0; t < 49; ++t)
+    if (p.tdy[t] != t / 7 - 3 || p.tdx[t] != t % 7 - 3) return 0;
+  int npl = 0, kb = 0;
+  for (int i = 0; i < p.n_in; ++i) {
+    const KOperand& o = p.in[i];
+    if (!(o.C >= 1 && o.C <= 3 && o.up == 0 && o.scale == nullptr && o.small && o.sw == 1)) return 0;
+    if ((o.sh & 3) || (o.sc & 3) || (o.sn & 3) || (reinterpret_cast<uintptr_t>(o.p) & 15)) return 0;
+    if (o.sh != p.in[0].sh || o.sc != p.in[0].sc || o.sn != p.in[0].sn) return 0;
+    geo->kbase[i] = kb;
+    kb += (49 * o.C + kChunk - 1) / kChunk * kChunk;
+    for (int c = 0; c < o.C && npl < 9; ++c) {
+      geo->plane_op[npl] = i;
+      geo->plane_c[npl] = c;
+      ++npl;
+    }
+  }
+  int form = 0, TW = 0;
+  if (npl == 3 && p.n_in == 1 && p.Ntot == 64 && p.GW % 32 == 0) { form = 1; TW = 32; }
+  else if (npl == 9 && p.n_in == 3 && p.Ntot == 16 && p.GW % 16 == 0) { form = 2; TW = 16; }
+  if (!form || p.GH % 4 != 0) return 0;
+  geo->tilesX = p.GW / TW;
+  geo->tilesY = p.GH / 4;
+  geo->ntiles = p.N * geo->tilesX * geo->tilesY;
+  geo->per_xcd = (geo->ntiles + 7) / 8;
+  if (geo->ntiles < 512) return 0;
+  return form;
+}
+
+static int stemk_wgrad_blocks(const SkGeo& geo) {
+  int blocks = geo.ntiles < 512 ? geo.ntiles : 512;
+  return (blocks + 7) / 8 * 8;
+}
+
+bool stemk_wgrad_eligible(const dn_conv_desc* d, const IgemmParams& p) {
+  SkGeo geo;
+  return stemk_wgrad_form(d, p, &geo) != 0;
+}
+
+size_t stemk_wgrad_workspace_bytes(const dn_conv_desc* d, const IgemmParams& p) {
+  SkGeo geo;
+  if (!stemk_wgrad_form(d, p, &geo)) return 0;
+  return (size_t)stemk_wgrad_blocks(geo) * p.Npad * p.ph[0].nchunks * kChunk * sizeof(float);
+}
+
+template <int MT, int TW, int NPL>
+static int stemk_wgrad_launch(IgemmParams& p, const SkGeo& geo, float* dw, hipStream_t stream) {
+  using Cfg = SkwCfg<MT, TW, NPL>;
+  auto kernel = stemk_wgrad_kernel<MT, TW, NPL>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(stemk_wgrad_kernel, %zu): %s", (size_t)Cfg::LDS, hipGetErrorString(e));
+    return DN_ERR_LAUNCH;
+  }
+  const int blocks = stemk_wgrad_blocks(geo);
+  const long long slab = (long long)p.Npad * p.ph[0].nchunks * kChunk;
+  DN_LAUNCH(kernel, dim3(blocks), dim3(256), (size_t)Cfg::LDS, stream, p, geo, slab);
+  set_last_kernel("dn::stemk_wgrad_kernel<%d, %d, %d>", MT, TW, NPL);
+  int rc = check_launch("stemk_wgrad_kernel");
+  if (rc != DN_OK) return rc;
+  p.splits = blocks;
+  return launch_wgrad_reduce(p, dw, stream);
+}
+
+int launch_stemk_wgrad(const dn_conv_desc* d, IgemmParams& p, float* dw, hipStream_t stream) {
+  SkGeo geo;
+  switch (stemk_wgrad_form(d, p, &geo)) {
+    case 1: return stemk_wgrad_launch<4, 32, 3>(p, geo, dw, stream);
+    case 2: return stemk_wgrad_launch<1, 16, 9>(p, geo, dw, stream);
+    default: set_error("launch_stemk_wgrad: no form"); return DN_ERR_UNSUPPORTED;
+  }
 }
 
 bool stemk_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) {

@@ -235,6 +235,12 @@ def test_stemk_first_layers(form):
     assert "stemk_conv_kernel" in _lib.load().dn_last_kernel().decode()
     pre = mod(torch.cat(xs, 1))
     close(form + ":y", nchw(y_t), pre if form == "res" else F.relu(pre))
+    # weight gradient of the same layer: dn::stemk_wgrad_kernel + the fixed-order slab fold
+    g = rnd(*pre.shape, seed=40)
+    (pre * g).sum().backward()
+    dw = engine.conv_wgrad(layer, pieces, nhwc(g), (H // 2, W // 2))
+    assert "stemk_wgrad_kernel" in _lib.load().dn_last_kernel().decode()
+    close(form + ":dw", dw, mod.weight.grad, rtol=5e-4, atol_rel=5e-5)
     if form == "res":
         bn = nn.BatchNorm2d(cout)
         with torch.no_grad():
