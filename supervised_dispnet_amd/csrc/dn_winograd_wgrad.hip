@@ -132,6 +132,12 @@ __global__ void wino_wgrad_fold_kernel(const float* __restrict__ ws, float* __re
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ f32x2 wg_buffer_load2s(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) {      // soffset: wave-uniform
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, 0);
+  return __builtin_bit_cast(f32x2, v);
+}
+
 __device__ __forceinline__ f32x2 wg_buffer_load2(__amdgpu_buffer_rsrc_t r, int voffset) {
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voffset, 0, 0);
@@ -407,7 +413,7 @@ typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool HA, int DBG = 0>     // DBG (timing ablations, wrong results): 1 no transform + stores, 2 no split arithmetic, 4 no global loads, 8 no LDS fragment reads
+template <bool HA, int DBG = 0>     // DBG (timing ablations, wrong results): 1 no transform + stores, 2 no split arithmetic, 4 no global loads, 8 no LDS fragment reads (the split of the never-changing registers is hoisted too), 16 no LDS stores (arithmetic kept), 32 no barrier
 __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams p) {
   extern __shared__ __align__(16) float smem[];
   char* smemB = reinterpret_cast<char*>(smem);
@@ -474,43 +480,55 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
     *n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, ty);
     return live;
   };
+  // Patch addressing: four row offsets AT PATCH COLUMN 1 (always inside the image when the row is) with the row's validity folded in
+  // (sign bit = past num_records: the load returns 0); columns 2 and 3 ride in the scalar offset, which the range check ignores -- so
+  // the vector offset itself must be a valid one (column 0 of a patch at px = -1 would be negative: it gets its own offsets).  At most
+  // two vector instructions per load; selecting every offset from a 16-bit mask cost five.
   auto load_patch = [&](int target) {
     unsigned tx, ty;
     int n;
     const bool live = decode_tile(target, &tx, &ty, &n);
     const int py = 2 * (int)ty - 1, px = 2 * (int)tx - 1;
-    const int off0 = (n * (int)S.sn + py * (int)S.sh + px * (int)S.sw + c_in_op + item_c) * 4;
-    unsigned cols = 0x6u | (px >= 0 ? 1u : 0u) | (px + 3 < p.IW ? 8u : 0u);
-    cols = live ? cols : 0u;
-    pm = (py >= 0 ? cols : 0u) | (cols << 4) | (cols << 8) | (py + 3 < p.IH ? cols << 12 : 0u);
+    const int off1 = (n * (int)S.sn + py * (int)S.sh + (px + 1) * (int)S.sw + c_in_op + item_c) * 4;
+    const bool r0 = live && py >= 0, r3 = live && py + 3 < p.IH;
+    const bool c0 = px >= 0, c3 = px + 3 < p.IW;
+    pm = (live ? 1u : 0u) | (r0 ? 2u : 0u) | (r3 ? 4u : 0u) | (c0 ? 8u : 0u) | (c3 ? 16u : 0u);
+    constexpr int kOut = (int)0x80000000;
+    const int m3 = c3 ? 0 : kOut;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int off = off0 + (i >> 2) * shB + (i & 3) * swB;
-      asm volatile("" : "+v"(off));
-      off = ((pm >> i) & 1u) ? off : -1;
-      v[i] = wg_buffer_load2(rsrcX, off);
+    for (int r = 0; r < 4; ++r) {
+      const bool rv = r == 0 ? r0 : r == 3 ? r3 : live;
+      const int rb = off1 + r * shB;
+      const int o1 = rv ? rb : kOut;
+      v[4 * r + 0] = wg_buffer_load2s(rsrcX, (rv && c0) ? rb - swB : kOut, 0);
+      v[4 * r + 1] = wg_buffer_load2s(rsrcX, o1, 0);
+      v[4 * r + 2] = wg_buffer_load2s(rsrcX, o1, swB);
+      v[4 * r + 3] = wg_buffer_load2s(rsrcX, o1 | m3, 2 * swB);
     }
   };
   auto load_grad = [&](int target) {
     unsigned tx, ty;
     int n;
     const bool live = decode_tile(target, &tx, &ty, &n);
-    const int off0 = (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 64 + item_c) * 4;
+    int off0 = (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 64 + item_c) * 4;
+    off0 = live ? off0 : (int)0x80000000;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int off = off0 + (i >> 1) * growB + (i & 1) * gpixB;
-      asm volatile("" : "+v"(off));
-      off = live ? off : -1;
-      gv[i] = wg_buffer_load2(rsrcG, off);
-    }
+    for (int i = 0; i < 4; ++i) gv[i] = wg_buffer_load2s(rsrcG, off0, (i >> 1) * growB + (i & 1) * gpixB);
   };
   auto affine_piece = [&](int i) {
     if constexpr (HA) {
       unsigned pmv = pm;
       asm volatile("" : "+v"(pmv));
-      const float cap = ((pmv >> i) & 1u) ? __builtin_huge_valf() : 0.f;
+      constexpr unsigned kInf = 0x7f800000u;
+      const int r = i >> 2, c = i & 3;
+      // cap = +inf inside the image, 0 on the zero halo: row bit AND column bit, sign-extended from the 5-bit mask
+      int ok = __builtin_amdgcn_sbfe(pmv, r == 0 ? 1 : r == 3 ? 2 : 0, 1);
+      if (c == 0) ok &= __builtin_amdgcn_sbfe(pmv, 3, 1);
+      if (c == 3) ok &= __builtin_amdgcn_sbfe(pmv, 4, 1);
+      const float cap = __builtin_bit_cast(float, (unsigned)ok & kInf);
+      const f32x2 t = __builtin_elementwise_fma(v[i], sc2, sh2);      // (one v_pk_fma_f32; fused like fmaf)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) v[i][e] = __builtin_amdgcn_fmed3f(fmaf(v[i][e], sc2[e], sh2[e]), relu_floor, cap);
+      for (int e = 0; e < 2; ++e) v[i][e] = __builtin_amdgcn_fmed3f(t[e], relu_floor, cap);
     }
   };
   auto row_piece = [&](int b) {
@@ -520,12 +538,16 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
     v[8 + b] = d2 - d1;
     v[12 + b] = d1 - v[12 + b];
   };
+  auto put2 = [&](char* dst, f32x2 val) {
+    if constexpr (DBG & 16) asm volatile("" ::"v"(val));      // (ablation: the arithmetic without the LDS store)
+    else *reinterpret_cast<f32x2*>(dst) = val;
+  };
   auto col_piece = [&](int b2, int i) {
     char* dst = smemB + b2 * G_BUFB + G_OPB + stB + (4 * i) * G_PLANE;
-    *reinterpret_cast<f32x2*>(dst + 0 * G_PLANE) = v[4 * i + 0] - v[4 * i + 2];
-    *reinterpret_cast<f32x2*>(dst + 1 * G_PLANE) = v[4 * i + 1] + v[4 * i + 2];
-    *reinterpret_cast<f32x2*>(dst + 2 * G_PLANE) = v[4 * i + 2] - v[4 * i + 1];
-    *reinterpret_cast<f32x2*>(dst + 3 * G_PLANE) = v[4 * i + 1] - v[4 * i + 3];
+    put2(dst + 0 * G_PLANE, v[4 * i + 0] - v[4 * i + 2]);
+    put2(dst + 1 * G_PLANE, v[4 * i + 1] + v[4 * i + 2]);
+    put2(dst + 2 * G_PLANE, v[4 * i + 2] - v[4 * i + 1]);
+    put2(dst + 3 * G_PLANE, v[4 * i + 1] - v[4 * i + 3]);
   };
   auto g_cols = [&](int b2, int i) {
     char* dst = smemB + b2 * G_BUFB + stB + (4 * i) * G_PLANE;
@@ -534,10 +556,10 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
     else if (i == 1) { u0 = gv[0] + gv[2]; u1 = gv[1] + gv[3]; }
     else if (i == 2) { u0 = gv[0] - gv[2]; u1 = gv[1] - gv[3]; }
     else { u0 = gv[2]; u1 = gv[3]; }
-    *reinterpret_cast<f32x2*>(dst + 0 * G_PLANE) = u0;
-    *reinterpret_cast<f32x2*>(dst + 1 * G_PLANE) = u0 + u1;
-    *reinterpret_cast<f32x2*>(dst + 2 * G_PLANE) = u0 - u1;
-    *reinterpret_cast<f32x2*>(dst + 3 * G_PLANE) = u1;
+    put2(dst + 0 * G_PLANE, u0);
+    put2(dst + 1 * G_PLANE, u0 + u1);
+    put2(dst + 2 * G_PLANE, u0 - u1);
+    put2(dst + 3 * G_PLANE, u1);
   };
 
   // ---- operands of the matrix instructions: per co half h  A1 = (x0, x1), A3 = (x0, x2);  per ci half nn  B1 = (y0, y0),
@@ -664,7 +686,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
           if constexpr (m < 4) g_cols(buf ^ 1, m);
           if constexpr (m >= 4 && m < 12 && (m % 2) == 0) col_piece(buf ^ 1, (m - 4) / 2);
         }
-        if constexpr (m == 12) __syncthreads();                   // all reads of `cur` are out (build 5's at slot 11), all stores into `nxt` are done (slot 10)
+        if constexpr (m == 12 && !(DBG & 32)) __syncthreads();                   // all reads of `cur` are out (build 5's at slot 11), all stores into `nxt` are done (slot 10)
         if constexpr (m == 14) issue_reads(6, cur, nxt);          // (its raw set is build 4's until that build's last part)
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -786,6 +808,9 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
       case 1005: kernel = wino_wgrad_x3_kernel<true, 5>; break;
       case 1008: kernel = wino_wgrad_x3_kernel<true, 8>; break;
       case 1015: kernel = wino_wgrad_x3_kernel<true, 15>; break;
+      case 1016: kernel = wino_wgrad_x3_kernel<true, 16>; break;
+      case 1032: kernel = wino_wgrad_x3_kernel<true, 32>; break;
+      case 1024: kernel = wino_wgrad_x3_kernel<true, 24>; break;
       default: break;
     }
   }
