@@ -73,7 +73,19 @@ __global__ void __launch_bounds__(256) ordinal_loss_fwd_kernel(const float* __re
     const long long n = i / HW, p = i - n * HW;
     const float* O = ord + n * K * HW + p;
     const int t = target[i];
-    for (int k = 0; k < K; ++k) {
+    // eight planes in flight per thread (one load at a time ran at 1.65 TB/s); the sum keeps its plane order
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+      float P[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) P[e] = O[(long long)(k + e) * HW];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (k + e <= t - 1) ? P[e] : 1.f - P[e];
+        s += logf(fminf(fmaxf(v, 1e-8f), 1e8f));
+      }
+    }
+    for (; k < K; ++k) {
       const float P = O[(long long)k * HW];
       const float v = (k <= t - 1) ? P : 1.f - P;
       s += logf(fminf(fmaxf(v, 1e-8f), 1e8f));
