@@ -516,7 +516,7 @@ def main():
         # multiply-accumulates x 2 the algorithm needs in fp32 terms (Winograd: 16/36 of the direct ones) ...
         execf = lambda k, fl: fl * (WINO_EXEC if "wino_" in k else 1.0)
         # ... and what the matrix pipe the kernel runs on executes for them (f32x3: six bf16 partial products per fp32 multiply)
-        is_x3 = lambda k: ("wino_conv_kernel" in k and k.endswith(", 3>")) or "wino_conv8_kernel" in k or "wino_wgrad_x3_kernel" in k
+        is_x3 = lambda k: ("wino_conv_kernel" in k and k.endswith(", 3>")) or "wino_conv8_kernel" in k or "wino_wgrad_x3" in k
         is_bf = lambda k: "wino_conv_kernel" in k and k.endswith(", 1>")
         pipef = lambda k, fl: execf(k, fl) * (X3_PRODUCTS if is_x3(k) else 1.0)
         step_credited_flops = sum(v[0] for v in mf.values()) / nps

@@ -40,6 +40,7 @@ static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_
 struct Knobs {
   bool no_winograd, no_winograd_wgrad, no_direct, no_stem, no_u32, no_bm64, no_thin, no_thin_conv, no_tile_store, no_splitk, no_head2;
   int extra_lds;            // DN_DEBUG_EXTRA_LDS: bytes added to the tiled kernels' LDS request (lowers blocks per CU)
+  int wino_wgw;                          // DN_WINO_WGW: 0 = keep the 64 x 64 x 16-position weight-gradient block where 128 x 64 x 8 would run
   int wino_dbg, wino_mtw, wino_wg_dbg;   // DN_WINO_DBG / DN_WINO_MTW / DN_WINO_WG_DBG: ablation variants (tools/wino_timing.py)
   unsigned long long wino_dbgptr;
   int lds3_dbg;                          // DN_LDS3_DBG: phase timestamps of the LDS-resident kernels into DN_WINO_DBGPTR (tools/lds3_timing.py)

@@ -99,6 +99,7 @@ static void read_knobs(Knobs* k) {
   k->wino_dbg = num("DN_WINO_DBG", 0);
   k->wino_mtw = num("DN_WINO_MTW", 1);
   k->wino_wg_dbg = num("DN_WINO_WG_DBG", 0);
+  k->wino_wgw = num("DN_WINO_WGW", 1);
   k->lds3_dbg = num("DN_LDS3_DBG", 0);
   k->wino_dbgptr = getenv("DN_WINO_DBGPTR") ? strtoull(getenv("DN_WINO_DBGPTR"), nullptr, 0) : 0ull;
   k->wino_min_tiles = num("DN_WINO_MIN_TILES", 192);

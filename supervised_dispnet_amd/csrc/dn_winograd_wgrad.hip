@@ -710,6 +710,301 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3_kernel(const IgemmParams
         }
 }
 
+// ------------------------------------------------------------------------------------------------ 128 co x 64 ci x 8 positions (round 4)
+// wino_wgrad_x3_kernel splits (64 + 64) x 16 positions x 8 tiles values per chunk and spends twelve vector instructions per matrix
+// instruction doing it (profiles/r04_sq_counters_wgrad.txt: vector issue port 0.59 busy, matrix pipe 0.40).  A 128 x 64 block over all
+// 16 positions would need 256 accumulator registers per lane; this variant takes 128 output channels x 64 input channels for HALF of
+// the positions -- transform rows i = 2 ih, 2 ih + 1, block pairs (ih = 0, 1) adjacent in the grid so that the second finds its inputs
+// in L2.  Per block and chunk: (128 + 64) x 8 x 8 values to split instead of (64 + 64) x 16 x 8 (-25 %), the input transform only for
+// the rows it needs (three of the four patch rows are fetched: the same number of loads per matrix instruction as before), half the
+// LDS bytes.  A wave owns ONE position: 4 x 2 tiles of 32 x 32 = 128 accumulators, 24 matrix instructions per chunk as before, but 6
+// operand builds (four A, two B) instead of 8.  Same workspace layout and reduce kernel; needs C_out % 128 == 0.
+//   chunk schedule of a wave (24 slots, matrix instruction m: h = m / 6, nn = (m / 3) % 2, piece pairing t = m % 3):
+//     build 0 = B(nn 1) slots 0-2 | 1 = A(h 1) 3-5 | 2 = A(h 2) 6-8 | 3 = A(h 3) 12-14 | 4 = A(h 0) of the NEXT chunk 18-20 | 5 = B(nn 0) of the
+//     next chunk 21-23; the fragment reads of the current buffer are all out by slot 5, those of the next buffer follow the barrier (slot 12)
+constexpr int W_GROWB = 128 * 4;                  // one tile row of G: 128 output channels
+constexpr int W_VROWB = 64 * 4;
+constexpr int W_GPLANE = GTC * W_GROWB;           // one local position of G: 4 KiB
+constexpr int W_VPLANE = GTC * W_VROWB;           // 2 KiB
+constexpr int W_GOPB = 8 * W_GPLANE;              // 32 KiB
+constexpr int W_VOPB = 8 * W_VPLANE;              // 16 KiB
+constexpr int W_BUFB = W_GOPB + W_VOPB;
+constexpr size_t kWgwLds = (size_t)2 * W_BUFB;    // 96 KiB
+
+template <bool HA>
+__global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParams p) {
+  extern __shared__ __align__(16) float smem[];
+  char* smemB = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Ktot = p.D1, Cout = p.Ntot;
+  const int CB = Cout / 128, KB = Ktot / 64;
+  const int total = CB * KB * 2 * p.splits;
+  const int per = (total + 7) >> 3;
+  const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || q >= total) return;
+  const int ih = q & 1, q2 = q >> 1;
+  const int cib = q2 % KB, cob = (q2 / KB) % CB, split = q2 / (KB * CB);
+  const int T = p.T;
+  const int t_begin = split * p.m_per_split;
+  const int t_end = min(T, t_begin + p.m_per_split);
+  const int nchunks = (t_end - t_begin + GTC - 1) / GTC;
+
+  int s_op = 0;
+#pragma unroll
+  for (int i = 1; i < DN_MAX_OPERANDS; ++i)
+    if (i < p.n_in && cib * 64 >= p.in[i].ch_off) s_op = i;
+  const KOperand& S = p.in[s_op];
+  const int c_in_op = cib * 64 - S.ch_off;
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, 0x80000000u, 0x00020000);
+
+  const int group = wave >> 2;                          // waves 0-3 stage the even chunks, waves 4-7 the odd ones
+  const int item_t = (tid & 255) >> 5;
+  const int item_c = (tid & 31) * 2;
+  const int stV = W_GOPB + item_t * W_VROWB + item_c * 4;
+  const int stG = item_t * W_GROWB + item_c * 4;          // (+ 256 for the thread's second gradient item: channels 64 + item_c)
+  const int frA = wave * W_GPLANE + (lane >> 5) * W_GROWB + (lane & 31) * 4;
+  const int frB = W_GOPB + wave * W_VPLANE + (lane >> 5) * W_VROWB + (lane & 31) * 4;
+
+  f32x16 acc[4][2];          // [h (32 output channels)][nn (32 input channels)]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  f32x2 v[3][4], gv[2][4];
+  unsigned pm = 0;
+  f32x2 sc2, sh2;
+  const int shB = (int)S.sh * 4, swB = (int)S.sw * 4;
+  const int gpixB = Cout * 4, growB = p.OW * Cout * 4;
+  if constexpr (HA) {
+    const bool op_aff = S.scale != nullptr;
+    const f32x2 l1 = *reinterpret_cast<const f32x2*>((op_aff ? S.scale : S.p) + (op_aff ? c_in_op + item_c : 0));
+    const f32x2 l2 = *reinterpret_cast<const f32x2*>((op_aff ? S.shift : S.p) + (op_aff ? c_in_op + item_c : 0));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      sc2[e] = op_aff ? l1[e] : 1.f;
+      sh2[e] = op_aff ? l2[e] : 0.f;
+    }
+  }
+  const float relu_floor = (HA && S.scale != nullptr) ? 0.f : -__builtin_huge_valf();
+
+  // one tile per thread and chunk: its input patch rows ih .. ih + 2 (2 channels) and its output-gradient tile (2 x 2 channels)
+  auto load_chunk = [&](int target) {
+    const int t = t_begin + target * GTC + item_t;
+    const bool live = t < t_end;
+    unsigned tx, ty;
+    const unsigned r = fastdiv_dev(live ? (unsigned)t : 0u, (unsigned)p.TW, p.mTW, &tx);
+    const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
+    const int py = 2 * (int)ty - 1 + ih, px = 2 * (int)tx - 1;        // py: image row of the first FETCHED patch row
+    const int off1 = (n * (int)S.sn + py * (int)S.sh + (px + 1) * (int)S.sw + c_in_op + item_c) * 4;
+    const bool rv0 = live && py >= 0, rv2 = live && py + 2 < p.IH;        // (the middle row is inside the image whenever the tile exists)
+    const bool c0 = px >= 0, c3 = px + 3 < p.IW;
+    pm = (live ? 1u : 0u) | (rv0 ? 2u : 0u) | (rv2 ? 4u : 0u) | (c0 ? 8u : 0u) | (c3 ? 16u : 0u);
+    constexpr int kOut = (int)0x80000000;
+    const int m3 = c3 ? 0 : kOut;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bool rv = k == 0 ? rv0 : k == 2 ? rv2 : live;
+      const int rb = off1 + k * shB;
+      const int o1 = rv ? rb : kOut;
+      v[k][0] = wg_buffer_load2s(rsrcX, (rv && c0) ? rb - swB : kOut, 0);
+      v[k][1] = wg_buffer_load2s(rsrcX, o1, 0);
+      v[k][2] = wg_buffer_load2s(rsrcX, o1, swB);
+      v[k][3] = wg_buffer_load2s(rsrcX, o1 | m3, 2 * swB);
+    }
+    int goff = (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 128 + item_c) * 4;
+    goff = live ? goff : kOut;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gv[e][i] = wg_buffer_load2s(rsrcG, goff, (i >> 1) * growB + (i & 1) * gpixB + e * 256);
+  };
+  auto affine_piece = [&](int k, int c) {
+    if constexpr (HA) {
+      unsigned pmv = pm;
+      asm volatile("" : "+v"(pmv));
+      int ok = __builtin_amdgcn_sbfe(pmv, k == 0 ? 1 : k == 2 ? 2 : 0, 1);
+      if (c == 0) ok &= __builtin_amdgcn_sbfe(pmv, 3, 1);
+      if (c == 3) ok &= __builtin_amdgcn_sbfe(pmv, 4, 1);
+      const float cap = __builtin_bit_cast(float, (unsigned)ok & 0x7f800000u);
+      const f32x2 t = __builtin_elementwise_fma(v[k][c], sc2, sh2);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) v[k][c][e] = __builtin_amdgcn_fmed3f(t[e], relu_floor, cap);
+    }
+  };
+  // rows 2 ih, 2 ih + 1 of B^T d (fetched rows e0 e1 e2 = d[ih .. ih + 2]):  ih 0: d0 - d2, d1 + d2;  ih 1: d2 - d1, d1 - d3
+  auto row_piece = [&](int c) {
+    const f32x2 e0 = v[0][c], e1 = v[1][c], e2 = v[2][c];
+    if (ih == 0) {                                        // (block-uniform: a scalar branch)
+      v[0][c] = e0 - e2;
+      v[1][c] = e1 + e2;
+    } else {
+      v[0][c] = e1 - e0;
+      v[1][c] = e0 - e2;
+    }
+  };
+  auto col_piece = [&](int b2, int il) {               // local positions 4 il .. 4 il + 3 of V
+    char* dst = smemB + b2 * W_BUFB + stV + (4 * il) * W_VPLANE;
+    *reinterpret_cast<f32x2*>(dst + 0 * W_VPLANE) = v[il][0] - v[il][2];
+    *reinterpret_cast<f32x2*>(dst + 1 * W_VPLANE) = v[il][1] + v[il][2];
+    *reinterpret_cast<f32x2*>(dst + 2 * W_VPLANE) = v[il][2] - v[il][1];
+    *reinterpret_cast<f32x2*>(dst + 3 * W_VPLANE) = v[il][1] - v[il][3];
+  };
+  auto g_cols = [&](int b2, int e, int il) {           // gradient item e, local positions 4 il .. 4 il + 3 of G (row i = 2 ih + il of A dY A^T)
+    char* dst = smemB + b2 * W_BUFB + stG + e * 256 + (4 * il) * W_GPLANE;
+    f32x2 u0, u1;
+    if (ih == 0) {
+      if (il == 0) { u0 = gv[e][0]; u1 = gv[e][1]; }
+      else { u0 = gv[e][0] + gv[e][2]; u1 = gv[e][1] + gv[e][3]; }
+    } else {
+      if (il == 0) { u0 = gv[e][0] - gv[e][2]; u1 = gv[e][1] - gv[e][3]; }
+      else { u0 = gv[e][2]; u1 = gv[e][3]; }
+    }
+    *reinterpret_cast<f32x2*>(dst + 0 * W_GPLANE) = u0;
+    *reinterpret_cast<f32x2*>(dst + 1 * W_GPLANE) = u0 + u1;
+    *reinterpret_cast<f32x2*>(dst + 2 * W_GPLANE) = u0 - u1;
+    *reinterpret_cast<f32x2*>(dst + 3 * W_GPLANE) = u1;
+  };
+
+  // ---- operands: A1 = (x0, x1), A3 = (x0, x2) of 32 output channels; B1 = (y0, y0), B2 = (y1, y1), B3 = (y2, y0) of 32 input channels
+  wg_u32x4 Aop[2][2], Bop[2][3];
+  float raw[2][4];
+  unsigned Pk[3][2];
+  // builds of a chunk: id 0 = B(nn 1), 1 = A(h 1), 2 = A(h 2), 3 = A(h 3) read the current buffer; 4 = A(h 0), 5 = B(nn 0) of the next chunk read
+  // the next buffer; raw register set = id & 1
+  auto issue_reads = [&](int id, const char* cur, const char* nxt) {
+    const bool isB = id == 0 || id == 5;
+    const char* buf = id >= 4 ? nxt : cur;
+    if (isB) {
+      const char* base = buf + frB + (id == 0 ? 128 : 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) raw[id & 1][ks] = *reinterpret_cast<const float*>(base + ks * 2 * W_VROWB);
+    } else {
+      const int h = id == 4 ? 0 : id;
+      const char* base = buf + frA + h * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) raw[id & 1][ks] = *reinterpret_cast<const float*>(base + ks * 2 * W_GROWB);
+    }
+  };
+  auto split_half = [&](int id, int hf) {              // tiles (2 hf, 2 hf + 1) of the fragment: x = P0 + P1 + P2 exactly
+    const f32x2 x = f32x2{raw[id & 1][2 * hf], raw[id & 1][2 * hf + 1]};
+    const wg_bf16x2 h = __builtin_convertvector(x, wg_bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+    const wg_bf16x2 m = __builtin_convertvector(r1, wg_bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    const wg_bf16x2 l = __builtin_convertvector(r2, wg_bf16x2);
+    Pk[0][hf] = __builtin_bit_cast(unsigned, h);
+    Pk[1][hf] = __builtin_bit_cast(unsigned, m);
+    Pk[2][hf] = __builtin_bit_cast(unsigned, l);
+  };
+  auto finish_build = [&](int id, int part) {
+    if (part == 0) split_half(id, 0);
+    else if (part == 1) split_half(id, 1);
+    else if (id == 0 || id == 5) {
+      const int nn = id == 0 ? 1 : 0;
+      Bop[nn][0] = wg_u32x4{Pk[0][0], Pk[0][1], Pk[0][0], Pk[0][1]};      // (y0, y0)
+      Bop[nn][1] = wg_u32x4{Pk[1][0], Pk[1][1], Pk[1][0], Pk[1][1]};      // (y1, y1)
+      Bop[nn][2] = wg_u32x4{Pk[2][0], Pk[2][1], Pk[0][0], Pk[0][1]};      // (y2, y0)
+    } else {
+      const int a = id == 4 ? 0 : (id & 1);                                // A(h) lives in Aop[h & 1]
+      Aop[a][0] = wg_u32x4{Pk[0][0], Pk[0][1], Pk[1][0], Pk[1][1]};       // (x0, x1)
+      Aop[a][1] = wg_u32x4{Pk[0][0], Pk[0][1], Pk[2][0], Pk[2][1]};       // (x0, x2)
+    }
+  };
+
+  // ---- prologue: group 0 stages chunk 0 completely; group 1 requests chunk 1 (it column-transforms + stores it during chunk 0)
+  load_chunk(group);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) affine_piece(k, c);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) row_piece(c);
+  if (group == 0) {
+#pragma unroll
+    for (int il = 0; il < 2; ++il) {
+      col_piece(0, il);
+      g_cols(0, 0, il);
+      g_cols(0, 1, il);
+    }
+  }
+  __syncthreads();
+  {
+    const char* b0 = smemB;
+    issue_reads(4, b0, b0);
+    finish_build(4, 0); finish_build(4, 1); finish_build(4, 2);
+    issue_reads(5, b0, b0);
+    finish_build(5, 0); finish_build(5, 1); finish_build(5, 2);
+    issue_reads(0, b0, b0);
+    issue_reads(1, b0, b0);
+  }
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    const char* cur = smemB + buf * W_BUFB;
+    const char* nxt = smemB + (buf ^ 1) * W_BUFB;
+    auto body = [&](auto req_tag) __attribute__((always_inline)) {
+      constexpr bool REQ = decltype(req_tag)::value;       // request phase (loads for chunk c + 2), else transform + store phase (chunk c + 1)
+      if constexpr (REQ) load_chunk(c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      wg_static_for<24>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int h = m / 6, nn = (m / 3) % 2, t = m % 3;
+        const wg_u32x4 ao = Aop[h & 1][t == 2 ? 1 : 0], bo = Bop[nn][t];
+        acc[h][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, ao), __builtin_bit_cast(wg_bf16x8, bo), acc[h][nn], 0, 0, 0);
+        // ---- side work: operand builds (three slots each) and the fragment reads that follow them
+        constexpr int bid = m < 9 ? m / 3 : (m >= 12 && m < 15) ? 3 : (m >= 18 && m < 21) ? 4 : m >= 21 ? 5 : -1;
+        constexpr int part = m % 3;
+        if constexpr (bid >= 0) finish_build(bid, part);
+        if constexpr (m == 2) issue_reads(2, cur, nxt);
+        if constexpr (m == 5) issue_reads(3, cur, nxt);
+        if constexpr (m == 13) issue_reads(4, cur, nxt);
+        if constexpr (m == 15) issue_reads(5, cur, nxt);
+        if constexpr (m == 20) issue_reads(0, nxt, nxt);
+        if constexpr (m == 23) issue_reads(1, nxt, nxt);
+        // ---- staging of the wave's next chunk
+        // ---- staging of the wave's next chunk: the request phase clamps + row-transforms what it asked for at the top of this chunk in
+        //      its second half, the store phase column-transforms + stores before the barrier.  (Measured: everything in the store phase
+        //      +3 %; the clamp in the build-free slots 9-11 / 15-17 +-0.)
+        if constexpr (REQ) {
+          if constexpr (m >= 13 && m < 19) {
+            affine_piece((2 * (m - 13)) / 4, (2 * (m - 13)) % 4);
+            affine_piece((2 * (m - 13) + 1) / 4, (2 * (m - 13) + 1) % 4);
+          }
+          if constexpr (m >= 19 && m < 23) row_piece(m - 19);
+        } else {
+          if constexpr (m == 0) g_cols(buf ^ 1, 0, 0);
+          if constexpr (m == 2) g_cols(buf ^ 1, 1, 0);
+          if constexpr (m == 4) g_cols(buf ^ 1, 0, 1);
+          if constexpr (m == 6) g_cols(buf ^ 1, 1, 1);
+          if constexpr (m == 8) col_piece(buf ^ 1, 0);
+          if constexpr (m == 10) col_piece(buf ^ 1, 1);
+        }
+        if constexpr (m == 12) __syncthreads();      // all reads of `cur` are out (slot 5), all stores into `nxt` are done (slot 10)
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    if (((c - group) & 1) == 0) body(std::true_type{});
+    else body(std::false_type{});
+  }
+
+  const int pos = 4 * (2 * ih + (wave >> 2)) + (wave & 3);
+  float* ws = p.ws + ((size_t)split * 16 + pos) * (size_t)Cout * Ktot;
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = cob * 128 + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = cib * 64 + 32 * nn + (lane & 31);
+        ws[(size_t)row * Ktot + col] = acc[h][nn][r];
+      }
+}
+
 // dU = sum over splits (with the sign of A's last row restored), dW = G^T dU G, written in the framework layout [co][ci][3][3].
 // Four threads per 4 consecutive ci, one per transform row i: each sums its 4 positions over the splits (the 16 positions x splits
 // reads are independent float4 streams; with one thread per quad the big layers ran 256 blocks of 64 dependent-free but serial loads
@@ -822,15 +1117,20 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
     case 118: kernel = wino_wgrad_kernel<true, 118>; break;
     default: break;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLds);
+  // 128 x 64 x 8-position blocks when the output channels allow it (DN_WINO_WGW=0 keeps the 64 x 64 x 16 kernel)
+  const bool wide = x3 && dbg == 0 && (p.Ntot % 128) == 0 && knobs().wino_wgw != 0;
+  if (wide) kernel = p.any_affine ? wino_wgrad_x3w_kernel<true> : wino_wgrad_x3w_kernel<false>;
+  const size_t lds = wide ? kWgwLds : kWgLds;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
-    set_error("hipFuncSetAttribute(wino_wgrad_kernel, %zu): %s", kWgLds, hipGetErrorString(e));
+    set_error("hipFuncSetAttribute(wino_wgrad_kernel, %zu): %s", lds, hipGetErrorString(e));
     return DN_ERR_LAUNCH;
   }
   const int Ktot = wg_ktot(p);
-  const int total = (p.Ntot / 64) * (Ktot / 64) * splits;
-  DN_LAUNCH(kernel, dim3((total + 7) / 8 * 8), dim3(512), kWgLds, stream, p);
-  if (x3) set_last_kernel("dn::wino_wgrad_x3_kernel<%s, 0>", p.any_affine ? "true" : "false");
+  const int total = (p.Ntot / 64) * (Ktot / 64) * splits;          // (the wide kernel: Ntot / 128 x 2 position halves -- the same count)
+  DN_LAUNCH(kernel, dim3((total + 7) / 8 * 8), dim3(512), lds, stream, p);
+  if (wide) set_last_kernel("dn::wino_wgrad_x3w_kernel<%s>", p.any_affine ? "true" : "false");
+  else if (x3) set_last_kernel("dn::wino_wgrad_x3_kernel<%s, 0>", p.any_affine ? "true" : "false");
   else set_last_kernel("dn::wino_wgrad_kernel<%s, %d>", p.any_affine ? "true" : "false", (dbg == 2 || dbg == 6 || dbg == 22 || dbg == 54 || dbg == 118) ? dbg : 0);
   int rc = check_launch("wino_wgrad_kernel");
   if (rc != DN_OK) return rc;

@@ -121,7 +121,7 @@ def test_three_piece_kernels_vs_fp64_at_metric_size(shape, what):
         for mode in ("f32", "f32x3"):
             out, name = _run(mode, mod, x, dy, N, H, W, cin, cout, what)
             if what == "wgrad":
-                assert ("wino_wgrad_x3_kernel" in name) == (mode == "f32x3") and "wino_wgrad" in name, name
+                assert ("wino_wgrad_x3" in name) == (mode == "f32x3") and "wino_wgrad" in name, name      # (x3: the 64 x 64 x 16 or the 128 x 64 x 8-position block)
                 got = out[:, ci_idx]
             else:
                 assert ("wino_conv8_kernel" in name or ("wino_conv_kernel" in name and name.endswith(", 3>"))) if mode == "f32x3" else ("wino_conv_kernel" in name and name.endswith(", 0>")), name
