@@ -292,6 +292,46 @@ def test_winograd_path_is_taken_and_matches_direct(monkeypatch):
     close("wino_vs_direct:dw", res["wino"][4], res["direct"][4], rtol=1e-4, atol_rel=1e-5)
 
 
+@pytest.mark.parametrize("cfg", [(3, 18, 22, (128,), 128, False), (6, 8, 26, (256, 512), 256, True), (2, 20, 30, (64, 128), 128, True)],
+                         ids=["128_128", "cat768_256_aff", "cat192_128_aff"])
+def test_wide_winograd_wgrad_block_is_bitwise_the_narrow_one(monkeypatch, cfg):
+    """dn::wino_wgrad_x3w_kernel (128 output x 64 input channels x 8 positions per block, round 4) against dn::wino_wgrad_x3_kernel
+    (64 x 64 x 16 positions, DN_WINO_WGW=0): another partition of the same work -- every (position, co, ci) sum runs over the same
+    tiles in the same chunk order with the same three-piece arithmetic -- so the two agree BIT FOR BIT, borders, ragged last chunk,
+    virtual concat and pending BatchNorm + ReLU included."""
+    N, H, W, cins, cout, aff = cfg
+    torch.manual_seed(11)
+    cin = sum(cins)
+    mod = nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+    xs = [torch.randn(N, H, W, c, device=DEV) for c in cins]
+    dy = torch.randn(N, H, W, cout, device=DEV)
+    res = {}
+    for tag, env in (("wide", None), ("narrow", "0")):
+        if env is None:
+            monkeypatch.delenv("DN_WINO_WGW", raising=False)
+        else:
+            monkeypatch.setenv("DN_WINO_WGW", env)
+        _lib.load().dn_reload_knobs()
+        engine.bump_param_epoch()
+        layer = engine.ConvLayer(mod)
+        pieces = []
+        for i, (x, c) in enumerate(zip(xs, cins)):
+            a = engine.Act(x.clone(), N, H, W, c)
+            if aff and i == 0:
+                g = torch.Generator(device="cpu").manual_seed(5)
+                a.scale = (torch.rand(c, generator=g) + 0.5).to(DEV)
+                a.shift = (torch.rand(c, generator=g) - 0.5).to(DEV)
+            pieces.append(engine.Piece(a))
+        dw = engine.conv_wgrad(layer, pieces, dy, (H, W))
+        name = _lib.load().dn_last_kernel().decode()
+        torch.cuda.synchronize()
+        res[tag] = (dw.clone(), name)
+    monkeypatch.delenv("DN_WINO_WGW", raising=False)
+    _lib.load().dn_reload_knobs()
+    assert "wino_wgrad_x3w_kernel" in res["wide"][1] and "wino_wgrad_x3_kernel" in res["narrow"][1], (res["wide"][1], res["narrow"][1])
+    assert torch.equal(res["wide"][0], res["narrow"][0]), float((res["wide"][0] - res["narrow"][0]).abs().max())
+
+
 @pytest.mark.parametrize("kind", ["iconv0", "upconv0", "iconv0_dgrad", "upconv0_dgrad"])
 def test_thin_conv_matches_tiled_kernel(monkeypatch, kind):
     """The thin full-resolution layers at the metric's resolution on their three implementations: dn::lds3_conv_kernel (round 4: input
