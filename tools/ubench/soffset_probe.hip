@@ -1,4 +1,4 @@
-// Probe: raw buffer loads with a scalar offset -- address and range check (gfx950).  hipcc --offload-arch=gfx950 soffset_probe.hip -o soffset_probe
+// Probe: raw buffer loads with a scalar offset -- address and range check (gfx950).  hipcc --offload-arch=gfx950 tools/ubench/soffset_probe.hip -o tools/ubench/bin/soffset_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef int i32x2 __attribute__((ext_vector_type(2)));
