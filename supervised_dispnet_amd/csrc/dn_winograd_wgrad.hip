@@ -889,21 +889,27 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
       for (int ks = 0; ks < 4; ++ks) raw[id & 1][ks] = *reinterpret_cast<const float*>(base + ks * 2 * W_GROWB);
     }
   };
-  auto split_half = [&](int id, int hf) {              // tiles (2 hf, 2 hf + 1) of the fragment: x = P0 + P1 + P2 exactly
-    const f32x2 x = f32x2{raw[id & 1][2 * hf], raw[id & 1][2 * hf + 1]};
-    const wg_bf16x2 h = __builtin_convertvector(x, wg_bf16x2);
-    const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
-    const wg_bf16x2 m = __builtin_convertvector(r1, wg_bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
-    const wg_bf16x2 l = __builtin_convertvector(r2, wg_bf16x2);
-    Pk[0][hf] = __builtin_bit_cast(unsigned, h);
-    Pk[1][hf] = __builtin_bit_cast(unsigned, m);
-    Pk[2][hf] = __builtin_bit_cast(unsigned, l);
+  // The split of a fragment's four values (two tile pairs) runs LEVEL by level over the three slots of its build, both pairs side by side:
+  // a wave alone on its SIMD issues a dependent vector instruction every 8 cycles and an independent one every 4
+  // (profiles/r02_valu_rates_ubench.txt), and one pair after the other is a single chain of ten.  Residuals stay in the raw registers.
+  auto split_level = [&](int id, int level) {
+    float* x = raw[id & 1];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const f32x2 v2 = f32x2{x[2 * hf], x[2 * hf + 1]};
+      const wg_bf16x2 pc = __builtin_convertvector(v2, wg_bf16x2);
+      Pk[level][hf] = __builtin_bit_cast(unsigned, pc);
+      if (level < 2) {
+        const f32x2 r = v2 - __builtin_convertvector(pc, f32x2);
+        x[2 * hf] = r[0];
+        x[2 * hf + 1] = r[1];
+      }
+    }
   };
   auto finish_build = [&](int id, int part) {
-    if (part == 0) split_half(id, 0);
-    else if (part == 1) split_half(id, 1);
-    else if (id == 0 || id == 5) {
+    split_level(id, part);
+    if (part < 2) return;
+    if (id == 0 || id == 5) {
       const int nn = id == 0 ? 1 : 0;
       Bop[nn][0] = wg_u32x4{Pk[0][0], Pk[0][1], Pk[0][0], Pk[0][1]};      // (y0, y0)
       Bop[nn][1] = wg_u32x4{Pk[1][0], Pk[1][1], Pk[1][0], Pk[1][1]};      // (y1, y1)
