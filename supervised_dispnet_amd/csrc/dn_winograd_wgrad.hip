@@ -731,7 +731,8 @@ constexpr int W_VOPB = 8 * W_VPLANE;              // 16 KiB
 constexpr int W_BUFB = W_GOPB + W_VOPB;
 constexpr size_t kWgwLds = (size_t)2 * W_BUFB;    // 96 KiB
 
-template <bool HA>
+template <bool HA, int DBG = 0>     // DBG (timing ablations, wrong results; DN_WINO_WG_DBG = 2000 + bits): 1 no fragment reads (the split runs on registers the compiler
+                                    // cannot see through), 2 no split arithmetic, 4 no staging (loads, clamp, transforms, stores), 8 no barrier
 __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParams p) {
   extern __shared__ __align__(16) float smem[];
   char* smemB = reinterpret_cast<char*>(smem);
@@ -871,31 +872,42 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
 
   // ---- operands: A1 = (x0, x1), A3 = (x0, x2) of 32 output channels; B1 = (y0, y0), B2 = (y1, y1), B3 = (y2, y0) of 32 input channels
   wg_u32x4 Aop[2][2], Bop[2][3];
-  float raw[2][4];
+  float raw[4][4];
   unsigned Pk[3][2];
   // builds of a chunk: id 0 = B(nn 1), 1 = A(h 1), 2 = A(h 2), 3 = A(h 3) read the current buffer; 4 = A(h 0), 5 = B(nn 0) of the next chunk read
-  // the next buffer; raw register set = id & 1
+  // the next buffer; raw register set = id & 3.
+  // Every fragment read is issued in the second half of a chunk (after the barrier), away from the store-phase waves' 12 x 1 KB stores
+  // of the first half (measured: -1 %; the reads cost what they cost wherever they are issued, ablation 2001)
   auto issue_reads = [&](int id, const char* cur, const char* nxt) {
+    if constexpr (DBG & 1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(raw[id & 3][ks]));
+      return;
+    }
     const bool isB = id == 0 || id == 5;
     const char* buf = id >= 4 ? nxt : cur;
     if (isB) {
       const char* base = buf + frB + (id == 0 ? 128 : 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) raw[id & 1][ks] = *reinterpret_cast<const float*>(base + ks * 2 * W_VROWB);
+      for (int ks = 0; ks < 4; ++ks) raw[id & 3][ks] = *reinterpret_cast<const float*>(base + ks * 2 * W_VROWB);
     } else {
       const int h = id == 4 ? 0 : id;
       const char* base = buf + frA + h * 128;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) raw[id & 1][ks] = *reinterpret_cast<const float*>(base + ks * 2 * W_GROWB);
+      for (int ks = 0; ks < 4; ++ks) raw[id & 3][ks] = *reinterpret_cast<const float*>(base + ks * 2 * W_GROWB);
     }
   };
   // The split of a fragment's four values (two tile pairs) runs LEVEL by level over the three slots of its build, both pairs side by side:
   // a wave alone on its SIMD issues a dependent vector instruction every 8 cycles and an independent one every 4
   // (profiles/r02_valu_rates_ubench.txt), and one pair after the other is a single chain of ten.  Residuals stay in the raw registers.
   auto split_level = [&](int id, int level) {
-    float* x = raw[id & 1];
+    float* x = raw[id & 3];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      if constexpr (DBG & 2) {
+        Pk[level][hf] = __builtin_bit_cast(unsigned, x[2 * hf]) ^ (unsigned)level;
+        continue;
+      }
       const f32x2 v2 = f32x2{x[2 * hf], x[2 * hf + 1]};
       const wg_bf16x2 pc = __builtin_convertvector(v2, wg_bf16x2);
       Pk[level][hf] = __builtin_bit_cast(unsigned, pc);
@@ -946,6 +958,8 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
     finish_build(5, 0); finish_build(5, 1); finish_build(5, 2);
     issue_reads(0, b0, b0);
     issue_reads(1, b0, b0);
+    issue_reads(2, b0, b0);
+    issue_reads(3, b0, b0);
   }
 
   for (int c = 0; c < nchunks; ++c) {
@@ -954,7 +968,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
     const char* nxt = smemB + (buf ^ 1) * W_BUFB;
     auto body = [&](auto req_tag) __attribute__((always_inline)) {
       constexpr bool REQ = decltype(req_tag)::value;       // request phase (loads for chunk c + 2), else transform + store phase (chunk c + 1)
-      if constexpr (REQ) load_chunk(c + 2);
+      if constexpr (REQ && !(DBG & 4)) load_chunk(c + 2);
       __builtin_amdgcn_sched_barrier(0);
       wg_static_for<24>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
@@ -965,17 +979,18 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
         constexpr int bid = m < 9 ? m / 3 : (m >= 12 && m < 15) ? 3 : (m >= 18 && m < 21) ? 4 : m >= 21 ? 5 : -1;
         constexpr int part = m % 3;
         if constexpr (bid >= 0) finish_build(bid, part);
-        if constexpr (m == 2) issue_reads(2, cur, nxt);
-        if constexpr (m == 5) issue_reads(3, cur, nxt);
         if constexpr (m == 13) issue_reads(4, cur, nxt);
         if constexpr (m == 15) issue_reads(5, cur, nxt);
+        if constexpr (m == 17) issue_reads(2, nxt, nxt);          // (the next chunk's builds 2, 3, 0, 1: its current buffer is this one's next)
+        if constexpr (m == 19) issue_reads(3, nxt, nxt);
         if constexpr (m == 20) issue_reads(0, nxt, nxt);
         if constexpr (m == 23) issue_reads(1, nxt, nxt);
         // ---- staging of the wave's next chunk
         // ---- staging of the wave's next chunk: the request phase clamps + row-transforms what it asked for at the top of this chunk in
         //      its second half, the store phase column-transforms + stores before the barrier.  (Measured: everything in the store phase
         //      +3 %; the clamp in the build-free slots 9-11 / 15-17 +-0.)
-        if constexpr (REQ) {
+        if constexpr (DBG & 4) {
+        } else if constexpr (REQ) {
           if constexpr (m >= 13 && m < 19) {
             affine_piece((2 * (m - 13)) / 4, (2 * (m - 13)) % 4);
             affine_piece((2 * (m - 13) + 1) / 4, (2 * (m - 13) + 1) % 4);
@@ -989,7 +1004,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
           if constexpr (m == 8) col_piece(buf ^ 1, 0);
           if constexpr (m == 10) col_piece(buf ^ 1, 1);
         }
-        if constexpr (m == 12) __syncthreads();      // all reads of `cur` are out (slot 5), all stores into `nxt` are done (slot 10)
+        if constexpr (m == 12 && !(DBG & 8)) __syncthreads();      // all reads of `cur` are long out (previous chunk), all stores into `nxt` are done (slot 10)
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -1124,8 +1139,23 @@ int launch_wino_wgrad(IgemmParams& p, float* dw, hipStream_t stream) {
     default: break;
   }
   // 128 x 64 x 8-position blocks when the output channels allow it (DN_WINO_WGW=0 keeps the 64 x 64 x 16 kernel)
-  const bool wide = x3 && dbg == 0 && (p.Ntot % 128) == 0 && knobs().wino_wgw != 0;
+  bool wide = x3 && dbg == 0 && (p.Ntot % 128) == 0 && knobs().wino_wgw != 0;
   if (wide) kernel = p.any_affine ? wino_wgrad_x3w_kernel<true> : wino_wgrad_x3w_kernel<false>;
+  if (x3 && dbg >= 2000 && (p.Ntot % 128) == 0) {            // ablations of the wide block (tools/wgw_ablate.sh)
+    wide = true;
+    switch (dbg - 2000) {
+      case 1: kernel = wino_wgrad_x3w_kernel<true, 1>; break;
+      case 2: kernel = wino_wgrad_x3w_kernel<true, 2>; break;
+      case 3: kernel = wino_wgrad_x3w_kernel<true, 3>; break;
+      case 4: kernel = wino_wgrad_x3w_kernel<true, 4>; break;
+      case 5: kernel = wino_wgrad_x3w_kernel<true, 5>; break;
+      case 6: kernel = wino_wgrad_x3w_kernel<true, 6>; break;
+      case 7: kernel = wino_wgrad_x3w_kernel<true, 7>; break;
+      case 8: kernel = wino_wgrad_x3w_kernel<true, 8>; break;
+      case 15: kernel = wino_wgrad_x3w_kernel<true, 15>; break;
+      default: kernel = wino_wgrad_x3w_kernel<true>; break;
+    }
+  }
   const size_t lds = wide ? kWgwLds : kWgLds;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
