@@ -792,17 +792,22 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
   }
   const float relu_floor = (HA && S.scale != nullptr) ? 0.f : -__builtin_huge_valf();
 
+  // The scalars of the address arithmetic, pinned in SGPRs: left to itself the compiler re-reads some of them from the kernel-argument
+  // segment inside the loop (58 of 102 SGPRs in use), and the s_waitcnt lgkmcnt(0) behind such a load also drains the LDS reads in flight.
+  int kTW = p.TW, kTH = p.TH, kIH = p.IH, kIW = p.IW, kOH = p.OH, kOW = p.OW, kSn = (int)S.sn, kSh = (int)S.sh, kSw = (int)S.sw;
+  unsigned kmTW = p.mTW, kmTH = p.mTH;
+  asm volatile("" : "+s"(kTW), "+s"(kTH), "+s"(kIH), "+s"(kIW), "+s"(kOH), "+s"(kOW), "+s"(kSn), "+s"(kSh), "+s"(kSw), "+s"(kmTW), "+s"(kmTH));
   // one tile per thread and chunk: its input patch rows ih .. ih + 2 (2 channels) and its output-gradient tile (2 x 2 channels)
   auto load_chunk = [&](int target) {
     const int t = t_begin + target * GTC + item_t;
     const bool live = t < t_end;
     unsigned tx, ty;
-    const unsigned r = fastdiv_dev(live ? (unsigned)t : 0u, (unsigned)p.TW, p.mTW, &tx);
-    const int n = (int)fastdiv_dev(r, (unsigned)p.TH, p.mTH, &ty);
+    const unsigned r = fastdiv_dev(live ? (unsigned)t : 0u, (unsigned)kTW, kmTW, &tx);
+    const int n = (int)fastdiv_dev(r, (unsigned)kTH, kmTH, &ty);
     const int py = 2 * (int)ty - 1 + ih, px = 2 * (int)tx - 1;        // py: image row of the first FETCHED patch row
-    const int off1 = (n * (int)S.sn + py * (int)S.sh + (px + 1) * (int)S.sw + c_in_op + item_c) * 4;
-    const bool rv0 = live && py >= 0, rv2 = live && py + 2 < p.IH;        // (the middle row is inside the image whenever the tile exists)
-    const bool c0 = px >= 0, c3 = px + 3 < p.IW;
+    const int off1 = (n * kSn + py * kSh + (px + 1) * kSw + c_in_op + item_c) * 4;
+    const bool rv0 = live && py >= 0, rv2 = live && py + 2 < kIH;         // (the middle row is inside the image whenever the tile exists)
+    const bool c0 = px >= 0, c3 = px + 3 < kIW;
     pm = (live ? 1u : 0u) | (rv0 ? 2u : 0u) | (rv2 ? 4u : 0u) | (c0 ? 8u : 0u) | (c3 ? 16u : 0u);
     constexpr int kOut = (int)0x80000000;
     const int m3 = c3 ? 0 : kOut;
@@ -816,7 +821,7 @@ __global__ void __launch_bounds__(512, 1) wino_wgrad_x3w_kernel(const IgemmParam
       v[k][2] = wg_buffer_load2s(rsrcX, o1, swB);
       v[k][3] = wg_buffer_load2s(rsrcX, o1 | m3, 2 * swB);
     }
-    int goff = (((n * p.OH + 2 * (int)ty) * p.OW + 2 * (int)tx) * Cout + cob * 128 + item_c) * 4;
+    int goff = (((n * kOH + 2 * (int)ty) * kOW + 2 * (int)tx) * Cout + cob * 128 + item_c) * 4;
     goff = live ? goff : kOut;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
