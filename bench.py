@@ -114,12 +114,56 @@ def host_description():
     return model, len(phys) or None, os.cpu_count() or 1
 
 
-def cpu_baseline(h, w, batch, steps, warmup, threads=None):
-    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (b8, warm-up + timed steps), at
-    32, 64 and 128 torch threads (capped at the logical CPU count; DN_CPU_THREADS=n[,n..] overrides): the BEST is `value`, all of them
-    are in `sample`.  Every logical CPU of the 2-socket GPU host oversubscribes oneDNN at this problem size (round 1: 0.04 img/s with
-    256 threads), so the sweep stops at 128."""
+def _cpu_oracle_rate(h, w, batch, steps, warmup, threads, cpus=None, seed=0, start_at=None):
+    """img/s of the oracle's Disp_vgg_BN + l1_loss + Adam training step with `threads` torch threads (optionally pinned to `cpus`;
+    `start_at`: a wall-clock time all replicas of a multi-process sample begin their timed steps at)."""
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
     from oracle import losses as OL, nets as ON
+    torch.set_num_threads(threads)
+    img, gt = synthetic_batch(batch, h, w, "cpu", seed)
+    sd = ON.xavier_init_(ON.disp_vgg_bn_state_dict(), torch.Generator().manual_seed(0))
+    params = []
+    for k, v in sd.items():
+        if torch.is_floating_point(v) and "running" not in k:
+            v.requires_grad_(True)
+            params.append(v)
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
+    t0 = None
+    for it in range(warmup + steps):
+        if it == warmup:
+            if start_at is not None:
+                time.sleep(max(0.0, start_at - time.time()))
+            t0 = time.perf_counter()
+        depth = [1 / d for d in ON.disp_vgg_bn(sd, img, training=True)]
+        loss = OL.l1_loss(gt, depth, "kitti")
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    dt = time.perf_counter() - t0
+    return batch * steps / dt, dt
+
+
+def _cpu_replica_main(spec):
+    """`python bench.py --cpu-replica JSON`: one pinned replica of the CPU baseline; prints one JSON line."""
+    j = json.loads(spec)
+    rate, dt = _cpu_oracle_rate(j["h"], j["w"], j["batch"], j["steps"], j["warmup"], j["threads"], set(j["cpus"]), j["seed"], j["start_at"])
+    print(json.dumps({"rate": rate, "dt": dt}), flush=True)
+
+
+def cpu_baseline(h, w, batch, steps, warmup, threads=None):
+    """The oracle's Disp_vgg_BN + l1_loss + Adam training step on the host cores (b8, warm-up + timed steps; kind "port").
+    Two layouts are timed and the better one is `value`:
+      * one process at 32 / 64 / 128 torch threads (DN_CPU_THREADS=n[,n..] overrides): a quick look at every count with the SAME
+        short budget (1 warm-up + 2 steps), then the winner re-measured with the full sample (ADVICE r4);
+      * data-parallel replicas -- what the GPU side does, and what a 2-socket host needs to use its cores at this problem size (one
+        process's oneDNN threads stop scaling at ~32; round 1 measured 0.04 img/s with every logical CPU in one pool): P processes of
+        the winning thread count, each pinned to its own block of physical cores, each stepping its own batch, started together;
+        aggregate img/s = P * batch * steps / the slowest replica's time (DN_CPU_REPLICAS=0 skips it).
+    `cores` = the threads the reported layout actually used."""
     model, physical, logical = host_description()
     if threads:
         sweep = [int(threads)]
@@ -127,38 +171,56 @@ def cpu_baseline(h, w, batch, steps, warmup, threads=None):
         sweep = [int(t) for t in os.environ["DN_CPU_THREADS"].split(",")]
     else:
         sweep = sorted({min(t, logical) for t in (32, 64, 128)})
-    img, gt = synthetic_batch(batch, h, w, "cpu", 0)
-    rates = {}
-    for ci, cores in enumerate(sweep):
-        # the first (smallest) thread count gets the full sample; the larger ones -- slower on this host, there to show that more
-        # threads do not help -- a shorter one, so that the whole baseline stays within ~30 s of CPU work
-        n_warm, n_steps = (warmup, steps) if ci == 0 else (1, max(2, steps // 2))
-        torch.set_num_threads(cores)
-        sd = ON.xavier_init_(ON.disp_vgg_bn_state_dict(), torch.Generator().manual_seed(0))
-        params = []
-        for k, v in sd.items():
-            if torch.is_floating_point(v) and "running" not in k:
-                v.requires_grad_(True)
-                params.append(v)
-        opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
-        t0 = None
-        for it in range(n_warm + n_steps):
-            if it == n_warm:
-                t0 = time.perf_counter()
-            depth = [1 / d for d in ON.disp_vgg_bn(sd, img, training=True)]
-            loss = OL.l1_loss(gt, depth, "kitti")
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-        rates[cores] = batch * n_steps / (time.perf_counter() - t0)
-    best = max(rates, key=rates.get)
-    return {"value": rates[best], "unit": "images/sec", "cores": best, "kind": "port",
+    quick = {}
+    for cores in sweep:
+        quick[cores] = _cpu_oracle_rate(h, w, batch, 2, 1, cores)[0] if len(sweep) > 1 else 0.0
+    best = max(quick, key=quick.get)
+    single = _cpu_oracle_rate(h, w, batch, steps, warmup, best)[0]
+    layouts = {"1x%d" % best: single}
+    value, used = single, best
+    want = os.environ.get("DN_CPU_REPLICAS")
+    phys = physical or logical // 2 or 1
+    nrep = int(want) if want else max(1, min(phys // best, 8))
+    if nrep > 1:
+        import subprocess
+        procs = []
+        try:
+            try:
+                avail = sorted(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = list(range(logical))
+            per = max(1, len(avail) // nrep)
+            rsteps = max(2, steps // 2)
+            start_at = time.time() + 30.0                          # (interpreter + import torch + one warm-up step of every replica)
+            for r in range(nrep):
+                spec = {"h": h, "w": w, "batch": batch, "steps": rsteps, "warmup": 1, "threads": min(best, per),
+                        "cpus": avail[r * per:(r + 1) * per], "seed": r, "start_at": start_at}
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-replica", json.dumps(spec)],
+                                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+            budget = 45.0 + 4.0 * rsteps * batch / max(single, 0.05)   # start delay + several times the single-process time of the sample
+            out = []
+            for pr in procs:
+                o, _ = pr.communicate(timeout=max(5.0, start_at + budget - time.time()))
+                out.append(json.loads(o.strip().splitlines()[-1]))
+            slowest = max(o["dt"] for o in out)
+            agg = nrep * batch * rsteps / slowest
+            layouts["%dx%d" % (nrep, min(best, per))] = agg
+            if agg > value:
+                value, used = agg, nrep * min(best, per)
+        except Exception as e:                                     # noqa: BLE001 -- the baseline must never take the bench line down
+            layouts["replicas_error"] = "%s: %s" % (type(e).__name__, str(e)[:120])
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+    return {"value": value, "unit": "images/sec", "cores": used, "kind": "port",
             "host_cpu": model, "host_physical_cores": physical, "host_logical_cpus": logical,
-            "by_threads": {str(k): v for k, v in rates.items()},
-            "sample": "oracle Disp_vgg_BN+L1+Adam, %dx%d, batch %d, %d timed steps (%d warm-up) at the first thread count, half of that at the others; img/s at %s torch threads "
-                      "(best: %d) on a host with %s physical cores / %d logical CPUs (all-logical-CPU run measured 0.04 img/s in round 1: "
-                      "oversubscribed)" % (h, w, batch, steps, warmup, ", ".join("%d: %.2f" % kv for kv in rates.items()), best,
-                                           physical, logical)}
+            "by_threads_quick": {str(k): v for k, v in quick.items()}, "by_layout": layouts,
+            "sample": "oracle Disp_vgg_BN+L1+Adam, %dx%d, batch %d per process; one process: 1 warm-up + 2 steps at each of %s torch threads, the "
+                      "winner (%d) re-measured with %d warm-up + %d timed steps = %.2f img/s; replicas (processes x threads, pinned, started "
+                      "together, %d timed steps each): %s; host: %s physical cores / %d logical CPUs" % (
+                          h, w, batch, sorted(quick), best, warmup, steps, single, max(2, steps // 2),
+                          ", ".join("%s: %s" % (k, ("%.2f" % v) if isinstance(v, float) else v) for k, v in layouts.items()), physical, logical)}
 
 
 def measured_peaks(dev):
@@ -779,4 +841,7 @@ def _quiet_init(net):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-replica":
+        _cpu_replica_main(sys.argv[2])
+    else:
+        main()

@@ -135,6 +135,10 @@ static void read_knobs(Knobs* k) {
   k->no_tap_windows = on("DN_NO_TAP_WINDOWS");
   k->wino8 = num("DN_WINO8", -1);
   k->wino8_min_k = num("DN_WINO8_MIN_K", 128);
+  k->wino8_fullsplit = num("DN_WINO8_FULLSPLIT", 0);
+  k->wino8_fullsplit_minch = num("DN_WINO8_FULLSPLIT_MINCH", 4);
+  if (k->wino8_fullsplit_minch < 1) k->wino8_fullsplit_minch = 1;
+  k->wino8_fullsplit_maxblocks = num("DN_WINO8_FULLSPLIT_MAXBLOCKS", 128);
 }
 
 const Knobs& knobs() {

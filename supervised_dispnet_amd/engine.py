@@ -1139,7 +1139,9 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
     self.bn1(conv1); relu1 = self.relu(conv1)`): only its running statistics are updated, from the conv epilogue's sums."""
     a0 = pieces[0].act
     in_hw = (a0.H * (2 if pieces[0].up else 1), a0.W * (2 if pieces[0].up else 1))
-    want_recip = [] if (FUSE_RECIP and act == ACT_SIGMOID_AFFINE and layer.Cout == 1 and stat_bn is None) else None
+    # (a DISPARITY head: alpha * sigmoid + beta with beta > 0, in training or eval; PoseExpNet's explainability masks are sigmoid heads
+    #  with beta = 0 -- nobody reads 1 / mask, and it is inf where the mask underflows: ADVICE r4)
+    want_recip = [] if (FUSE_RECIP and act == ACT_SIGMOID_AFFINE and layer.Cout == 1 and stat_bn is None and p1 > 0) else None
     y_t, partial, prow = conv_forward(layer, pieces, act, p0, p1, out_hw=out_hw, bn_stats=stat_bn is not None, recip=want_recip)
     OH, OW = y_t.shape[1], y_t.shape[2]
     y = Act(y_t, a0.N, OH, OW, layer.Cout)

@@ -57,6 +57,9 @@ def reciprocal(disp):
     network of this package carries its reciprocal with it (models/_common.run_net): the head kernel wrote both."""
     fused = getattr(disp, "_dn_recip", None)
     if fused is not None and fused[1] == disp._version and fused[0].shape == disp.shape:
+        # handed out ONCE: the buffer becomes the caller's depth tensor, so a second reciprocal(disp) -- or one after an in-place
+        # operation on the depth this call returned -- takes the plain kernel and gets a tensor of its own (ADVICE r4)
+        disp._dn_recip = None
         return _ReciprocalFused.apply(disp, _Holder(fused[0]))
     return _Reciprocal.apply(disp)
 

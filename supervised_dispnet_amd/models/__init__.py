@@ -34,3 +34,20 @@ for _n in ("Disp_res", "Disp_vgg", "Disp_vgg_feature", "FCRN", "deeplab_depth", 
            "res50_aspp", "Disp_res_18", "PoseExpNet", "Disp_vgg_BN_DORN", "Disp_res_50", "monodepth2"):
     if _n not in globals():
         globals()[_n] = _out_of_scope(_n)
+
+
+def _no_replication(self):
+    """nn.DataParallel(net) on ONE device calls the wrapped module directly (torch/nn/parallel/data_parallel.py: `if len(self.device_ids)
+    == 1: return self.module(...)`), so the reference's `disp_net = torch.nn.DataParallel(disp_net)` / `disp_net.module.state_dict()`
+    (train.py:316-317,378) keep working on a one-GPU box.  Beyond one device DataParallel replicates the module per forward: the
+    engine's per-module runtime state (packed-weight caches, the launch schedule, arena-backed gradients) is per process, not per
+    replica -- data parallelism here is one process per GPU (supervised_dispnet_amd.distributed.GradReducer)."""
+    raise RuntimeError(
+        "supervised_dispnet_amd models cannot be replicated by nn.DataParallel across several devices: run one process per GPU "
+        "(python -m torch.distributed.run --nproc-per-node N train.py ...; gradients are summed by distributed.GradReducer over RCCL). "
+        "nn.DataParallel(net, device_ids=[one device]) works.")
+
+
+for _n, _c in list(globals().items()):
+    if isinstance(_c, type) and hasattr(_c, "_hip_forward"):
+        _c._replicate_for_data_parallel = _no_replication

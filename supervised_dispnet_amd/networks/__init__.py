@@ -16,3 +16,13 @@ def _out_of_scope(name):
 
 PoseDecoder = _out_of_scope("PoseDecoder")
 PoseCNN = _out_of_scope("PoseCNN")
+
+
+def _no_replication(self):
+    """See supervised_dispnet_amd.models._no_replication: nn.DataParallel over ONE device works, replicas over several do not."""
+    from ..models import _no_replication as f
+    return f(self)
+
+
+for _c in (DepthDecoder, ResnetEncoder, vggEncoder):
+    _c._replicate_for_data_parallel = _no_replication

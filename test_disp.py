@@ -47,6 +47,9 @@ def build_parser():
     p.add_argument("--output-dir", default=None, type=str, help="Output directory for saving predictions in a big 3D numpy file")
     p.add_argument("--gt-type", default="KITTI", type=str, help="GroundTruth data type", choices=["npy", "png", "KITTI", "NYU", "stillbox"])
     p.add_argument("--img-exts", default=["png", "jpg", "bmp"], nargs="*", type=str, help="images extensions to glob")
+    # extension (not in the reference)
+    p.add_argument("--compute", choices=["f32x3", "f32", "bf16"], default=None,
+                   help="arithmetic of the matrix-core convolution kernels (see train.py --compute); default: the library's f32x3")
     return p
 
 
@@ -145,7 +148,9 @@ def main(argv=None):
     import supervised_dispnet_amd.models as models
     import supervised_dispnet_amd.networks as networks
     import supervised_dispnet_amd.utils as U
-    from supervised_dispnet_amd import kitti_eval as KE
+    from supervised_dispnet_amd import engine, kitti_eval as KE
+    if args.compute is not None:
+        engine.set_compute(args.compute)
     if args.gt_type not in ("KITTI", "NYU"):
         raise ValueError("gt-type '{}' is outside this path (KITTI and NYU are supported)".format(args.gt_type))
     if args.pretrained_posenet is not None:

@@ -48,6 +48,38 @@ def test_train_cli_surface_matches_reference():
     assert name.split(os.sep)[0] == "DATA,b32,lr0.0003,p2.0,networkdisp_vgg_BN,lossL1"
 
 
+def test_additive_flags_of_survey_section_5():
+    """SURVEY.md section 5's additive flags: --legacy-align-corners (torch 1.0.1's grid_sample semantics at the reference's
+    inverse_warp.py:191) and --compute (config 5's mixed precision from the command line); both default to the reference's behaviour."""
+    import test_disp
+    import train
+    p = train.build_parser()
+    a = p.parse_args(["DATA"])
+    assert a.legacy_align_corners is False and a.compute is None
+    a = p.parse_args(["DATA", "--legacy-align-corners", "--compute", "bf16"])
+    assert a.legacy_align_corners is True and a.compute == "bf16"
+    with pytest.raises(SystemExit):
+        p.parse_args(["DATA", "--compute", "fp8"])
+    # neither flag enters the run-folder name (utils.py:11-43 lists its keys explicitly)
+    assert train.save_path_formatter(a, p).split(os.sep)[0] == "DATA"
+    t = test_disp.build_parser().parse_args(["--network", "disp_vgg_BN", "--pretrained-dispnet", "CKPT", "--compute", "f32"])
+    assert t.compute == "f32"
+
+
+def test_models_refuse_multi_device_dataparallel_replication():
+    """Reference train.py:316-317 wraps the net in nn.DataParallel.  On one device DataParallel calls the module itself (GPU test
+    test_dataparallel_wrapper_on_one_device_equals_the_bare_module); beyond one device it replicates the module per forward, which the
+    engine's per-process runtime state does not support: every drop-in model says so instead of silently sharing caches."""
+    import supervised_dispnet_amd.models as models
+    import supervised_dispnet_amd.networks as networks
+    net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        net._replicate_for_data_parallel()
+    for cls in (models.DispNetS, models.Disp_res_50, models.Disp_vgg_BN_DORN, models.PoseExpNet, models.FCRN, networks.DepthDecoder,
+                networks.ResnetEncoder):
+        assert cls._replicate_for_data_parallel is not torch.nn.Module._replicate_for_data_parallel, cls
+
+
 def test_train_rejects_unknown_selectors():
     import train
     a = train.build_parser().parse_args(["DATA", "--loss", "nope"])

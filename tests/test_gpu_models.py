@@ -765,3 +765,10 @@ def test_heads_emit_the_reciprocal_with_the_disparity():
         d = net(x)
         d.mul_(2.0)
         assert torch.equal(reciprocal(d), 1.0 / d)
+        # the cached buffer is handed out once: an in-place operation on the depth it became must not leak into a second call
+        d = net(x)
+        z1 = reciprocal(d)
+        assert getattr(d, "_dn_recip", None) is None
+        z1.clamp_(max=1.0)
+        z2 = reciprocal(d)
+        assert z2.data_ptr() != z1.data_ptr() and torch.equal(z2, 1.0 / d)

@@ -30,7 +30,11 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in args.layers.split(","):
-        cin, cout, H, W, tr = LAYERS[name]
+        if name in LAYERS:
+            cin, cout, H, W, tr = LAYERS[name]
+        else:                                   # free form: c<cin>_<cout>_<H>x<W> / t<cin>_<cout>_<H>x<W>
+            a, b, hw = name[1:].split("_")
+            cin, cout, (H, W), tr = int(a), int(b), map(int, hw.split("x")), name[0] == "t"
         mod = (nn.ConvTranspose2d(cin, cout, 4, 2, 1) if tr else nn.Conv2d(cin, cout, 3, 1, 1)).to(dev)
         layer = engine.ConvLayer(mod, transposed=tr)
         x = engine.Act(torch.randn(args.batch, H, W, cin, device=dev), args.batch, H, W, cin)
@@ -61,7 +65,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
-            print("%-18s %-6s %8.3f ms  %7.1f TFLOP/s" % (name, kind, ms, flops / ms / 1e9))
+            print("%-18s %-6s %8.3f ms  %7.1f TFLOP/s  %s" % (name, kind, ms, flops / ms / 1e9, engine._lib.load().dn_last_kernel().decode()))
 
 if __name__ == "__main__":
     main()

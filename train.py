@@ -92,6 +92,13 @@ def build_parser():
                         "them with one call per step (supervised_dispnet_amd.graph.TapedStep); the second batch checks the replay against "
                         "the eager step bit for bit, a mismatch or an unsupported setting falls back to eager launches with a message")
     p.add_argument("--save-root", default="checkpoints", help="directory under which the run folder is created")
+    p.add_argument("--legacy-align-corners", action="store_true",
+                   help="photometric warp with F.grid_sample(align_corners=True): the sampling the reference's pinned torch 1.0.1 did at "
+                        "inverse_warp.py:191 (current torch, and this path by default, sample with align_corners=False; SURVEY.md section 5)")
+    p.add_argument("--compute", choices=["f32x3", "f32", "bf16"], default=None,
+                   help="arithmetic of the matrix-core convolution kernels (tensors, statistics, losses and Adam are fp32 in every mode): "
+                        "f32x3 (library default) fp32 products from three exact bf16 pieces per operand; f32 the fp32 matrix instruction; "
+                        "bf16 operands ROUNDED to bf16 with fp32 accumulation = the mixed-precision run of BASELINE configs[4]")
     return p
 
 
@@ -217,9 +224,12 @@ def main(argv=None):
     from supervised_dispnet_amd.functional import reciprocal
     from supervised_dispnet_amd.optim import FusedAdam
 
+    if args.compute is not None:
+        engine.set_compute(args.compute)
     save_path = os.path.join(args.save_root, save_path_formatter(args, parser))
     if rank == 0:
         print("=> will save everything to {}".format(save_path))
+        print("=> matrix-core arithmetic: {}{}".format(engine.compute_mode(), ", warp sampling align_corners=True" if args.legacy_align_corners else ""))
         os.makedirs(save_path, exist_ok=True)
     torch.manual_seed(args.seed)
     if args.evaluate:
@@ -446,22 +456,25 @@ class TapedTrainer(object):
         else:
             self.img.copy_(img)
             self.gt.copy_(gt)
+        agreed = False                 # this call's agreement collective has completed (never issue a second, unmatched one)
         try:
             if self.state == "new":
                 self.ts = TapedStep(self._step, optimizer=self.opt, warmup=0, static_inputs=(self.img, self.gt))
                 loss = self.ts()                                   # recorded = executed
                 self.state = "recorded"
-                if not self._agree(True):
+                ok = self._agree(True)
+                agreed = True
+                if not ok:
                     self._off("the recording failed on another rank")
                 return float(loss.item())
             if self.state == "recorded":
                 st = [self.opt.arena.flat_p, self.opt.exp_avg, self.opt.exp_avg_sq, self.opt._dev["step"], self.opt._dev["derived"]]
                 st += [b for b in self.net.buffers() if b.is_cuda]
                 same, worst = self.ts.verify(st)                   # (leaves the state one step further: this batch's eager step)
-                if same and not self._agree(True):
+                ok = self._agree(bool(same))
+                agreed = True
+                if same and not ok:
                     same, worst = False, float("nan")              # (another rank's check failed: all ranks leave the tape together)
-                elif not same:
-                    self._agree(False)
                 if same:
                     self.state = "verified"
                     if self.rank == 0:
@@ -474,8 +487,15 @@ class TapedTrainer(object):
         except Exception as e:          # noqa: BLE001 -- a setting the tape refuses
             if self.state == "verified":
                 raise
-            if self.state in ("new", "recorded"):
-                self._agree(False)       # (the peers wait in the agreement that follows their recording / their check)
+            from supervised_dispnet_amd.distributed import data_parallel_world
+            if data_parallel_world() > 1:
+                # Beyond one rank a failed recording cannot be retried eagerly by THIS rank alone: its peers have taken the step (their
+                # all-reduces are issued), so an eager re-run here would pair this step's buckets with their next step's.  Tell the peers
+                # (if they still wait in this call's agreement) and stop the job.
+                if not agreed:
+                    self._agree(False)
+                raise RuntimeError("--tape: recording / check failed on rank {} of a data-parallel run ({}: {}); restart without --tape"
+                                   .format(self.rank, type(e).__name__, str(e)[:160])) from e
             self._off("{}: {}".format(type(e).__name__, str(e)[:160]))
             return None
 
@@ -531,7 +551,7 @@ def train(ctx, loader, disp_net, pose_exp_net, optimizer, epoch_size, n_iter):
             loss_1 = supervised_loss(args, LF, gt_depth, depth, pred_ord, target_c)
         else:
             loss_1 = LF.photometric_reconstruction_loss(tgt_img, ref_imgs, intrinsics, intrinsics_inv, depth, explainability_mask, pose,
-                                                        args.rotation_mode, args.padding_mode)
+                                                        args.rotation_mode, args.padding_mode, align_corners=args.legacy_align_corners)
         loss_2 = LF.explainability_loss(explainability_mask) if w2 > 0 else 0
         # the reference evaluates the smoothness term unconditionally and multiplies it by -s (train.py:483-488);
         # with -s 0 (the README recipe) the product is exactly 0 for the finite values it takes, so it is skipped
@@ -603,7 +623,7 @@ def validate_without_gt(ctx, loader, disp_net, pose_exp_net):
         depth = 1 / disp
         explainability_mask, pose = pose_exp_net(tgt_img, ref_imgs)
         l1 = float(LF.photometric_reconstruction_loss(tgt_img, ref_imgs, intrinsics, intrinsics_inv, depth, explainability_mask, pose,
-                                                      args.rotation_mode, args.padding_mode).item())
+                                                      args.rotation_mode, args.padding_mode, align_corners=args.legacy_align_corners).item())
         l2 = float(LF.explainability_loss(explainability_mask).item()) if w2 > 0 else 0.0
         l3 = float(LF.smooth_loss(depth).item())
         losses.update([w1 * l1 + w2 * l2 + w3 * l3, l1, l2], tgt_img.size(0))
