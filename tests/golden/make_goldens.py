@@ -813,6 +813,75 @@ def gold_worst_pixels(ref_kitti):
     save("worst_pixels", **arrays)
 
 
+def eval_chain_image(h, w):
+    """A float32 H x W x 3 image in [0, 255] by formula (what test_framework_KITTI hands out as sample['tgt'], already at the network's
+    input size so that the reference's removed scipy.misc.imresize is not needed)."""
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    img = np.stack([127.5 + 120.0 * np.sin(0.021 * xx + 0.3) * np.cos(0.047 * yy),
+                    127.5 + 110.0 * np.cos(0.013 * xx - 0.029 * yy + 1.1),
+                    255.0 * ((xx * 7 + yy * 13) % 97) / 96.0], axis=2)
+    return img.clip(0, 255).astype(np.float32)
+
+
+def gold_eval_chain(ref_vgg, ref_kitti):
+    """The per-image evaluation chain of the reference's test_disp.py main() (it is inline there, :178-398): image -> transpose ->
+    normalise -> Disp_vgg_BN.eval() -> 1 / disp -> scipy zoom to the ground-truth size -> clip -> Garg-crop mask -> scale factor ->
+    compute_errors.  The reference's own statements are executed (slices of its source, nothing stored) on a deterministic sample: a
+    closed-form image at the network's input size (the `imresize` branch at :193-194 is not taken), the synthetic KITTI scene's ground
+    truth and mask from the reference's generate_depth_map / generate_mask, a detgen-filled reference Disp_vgg_BN.  torchvision's
+    Normalize(mean 0.5, std 0.5) at :214 is (x - 0.5) / 0.5 -- the one line restated here (torchvision is not in the container)."""
+    from scipy.ndimage import zoom
+    ns = {"np": np}
+    exec(_reference_slice("test_disp.py", 453, 469, ["def compute_errors(gt, pred):", "return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3"]), ns)
+    pre = _reference_slice("test_disp.py", 192, 200, ["h,w,_ = tgt_img.shape", "tgt_img = np.transpose(tgt_img, (2, 0, 1))", "torch.from_numpy(tgt_img)"])
+    fwd = _reference_slice("test_disp.py", 242, 242, ["pred_disp = disp_net(tgt_img).cpu().numpy()[0,0]"])
+    post = _reference_slice("test_disp.py", 254, 266, ["gt_depth = sample['gt_depth']", "pred_depth = 1/pred_disp", "zoom(pred_depth,", ").clip(min_depth, max_depth)"])
+    msk = _reference_slice("test_disp.py", 307, 308, ["pred_depth_zoomed = pred_depth_zoomed[sample['mask']]", "gt_depth = gt_depth[sample['mask']]"])
+    fin = _reference_slice("test_disp.py", 391, 398, ["scale_factor = np.median(gt_depth)/np.median(pred_depth_zoomed)", "scale_factor = 5.4",
+                                                      "errors[1,:,j] = compute_errors(gt_depth, pred_depth_zoomed*scale_factor)"])
+    net = ref_vgg.Disp_vgg_BN(datasets="kitti")
+    detgen.fill_state_dict(net.state_dict(), "vggbn")
+    net.eval()
+    p_rect, r_rect, r, t, velo = synthetic_kitti_scene()
+    arrays = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = pathlib.Path(tmp)
+        fmt = lambda a: " ".join("%.6e" % v for v in a)
+        (tmp / "calib_cam_to_cam.txt").write_text(
+            "calib_time: 09-Jan-2012 13:57:47\nR_rect_00: %s\nP_rect_02: %s\n" % (fmt(r_rect), fmt(p_rect)))
+        (tmp / "calib_velo_to_cam.txt").write_text(
+            "calib_time: 15-Mar-2012 11:37:16\nR: %s\nT: %s\n" % (fmt(r), fmt(t)))
+        velo.tofile(str(tmp / "scan.bin"))
+        gt = ref_kitti.generate_depth_map(tmp, tmp / "scan.bin", (375, 1242), cam=2)
+    mask = ref_kitti.generate_mask(gt, 1e-3, 80)
+    for name, flags in (("supervised", {}), ("median", {"unsupervised": True}), ("stereo", {"stereo": True})):
+        args = types.SimpleNamespace(no_resize=False, gt_type="KITTI", unsupervised=False, mono=False, stereo=False)
+        for k, v in flags.items():
+            setattr(args, k, v)
+        loc = {"np": np, "torch": torch, "zoom": zoom, "args": args, "img_height": 128, "img_width": 416, "min_depth": 1e-3, "max_depth": 80,
+               "sample": {"tgt": eval_chain_image(128, 416), "gt_depth": gt.copy(), "mask": mask}, "disp_net": net,
+               "compute_errors": ns["compute_errors"], "errors": np.zeros((2, 7, 1), np.float32), "j": 0, "seq_length": 0}
+        loc["tgt_img"] = loc["sample"]["tgt"]
+        exec(pre, loc)
+        loc["tgt_img"] = ((loc["tgt_img"] / 255 - 0.5) / 0.5).unsqueeze(0)          # test_disp.py:214,219 for KITTI
+        with torch.no_grad():
+            exec(fwd, loc)
+        exec(post, loc)
+        if name == "supervised":
+            arrays["pred_depth_samples"] = loc["pred_depth"].reshape(-1)[::97].astype(np.float32)
+            arrays["pred_depth_sum"] = np.float64(loc["pred_depth"].astype(np.float64).sum())
+            z = loc["pred_depth_zoomed"]
+            arrays["zoomed_shape"] = np.array(z.shape)
+            arrays["zoomed_samples"] = z.reshape(-1)[::9973].astype(np.float32)
+            arrays["zoomed_sum"] = np.float64(z.astype(np.float64).sum())
+        exec(msk, loc)
+        exec(fin, loc)
+        arrays["errors:" + name] = loc["errors"][1, :, 0].astype(np.float64)
+        arrays["scale:" + name] = np.float64(loc["scale_factor"])
+        arrays["n_valid"] = np.int64(loc["gt_depth"].size)
+    save("eval_chain", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -849,6 +918,7 @@ def main():
         "zoo": lambda: gold_zoo(ref_loss),
         "zoo2": lambda: gold_zoo2(ref_loss),
         "worst": lambda: gold_worst_pixels(ref_kitti),
+        "evalchain": lambda: gold_eval_chain(ref_vgg, ref_kitti),
     }
     for name, fn in sections.items():
         if not want or name in want:

@@ -202,6 +202,36 @@ def test_abs_rel_per_pixel_and_worst_300_match_reference_golden(golden, tmp_path
         KE.worst_pixels(np.full((20, 30), -1.0), 300)
 
 
+def test_evaluation_chain_matches_reference_golden_on_cpu(golden, tmp_path):
+    """SURVEY 8 f-2, the chain between the network and "Abs Rel" (reference test_disp.py:178-398, inline in its main()):
+    test_disp.evaluate_sample -- transpose, /255, normalise, forward, 1/disp, scipy zoom to the ground-truth size, clip, Garg-crop mask,
+    scale factor (1 / median ratio / 5.4), compute_errors -- against numbers the reference's own statements produced on the same
+    deterministic sample (tests/golden/make_goldens.py::gold_eval_chain).  Here the forward is the ORACLE's eval-mode Disp_vgg_BN on
+    the CPU (the checker standing in for the network, so the host chain is pinned without a GPU); tests/test_gpu_cli.py runs the same
+    check through the HIP network."""
+    import test_disp
+    import supervised_dispnet_amd.utils as U
+    from cases import check_eval_chain, eval_chain_sample
+    from oracle import detgen, nets as ON
+    from supervised_dispnet_amd import kitti_eval as KE
+    g = golden("eval_chain")
+    sample = eval_chain_sample(tmp_path)
+    assert int(sample["mask"].sum()) == int(g["n_valid"])
+    sd = ON.disp_vgg_bn_state_dict()
+    detgen.fill_state_dict(sd, "vggbn")
+
+    class _OracleNet(object):
+        def __call__(self, t):
+            with torch.no_grad():
+                return ON.disp_vgg_bn(sd, t, training=False)
+
+    def evaluate(flags):
+        args = test_disp.build_parser().parse_args(["--network", "disp_vgg_BN", "--pretrained-dispnet", "CKPT"] + flags)
+        return test_disp.evaluate_sample(args, _OracleNet(), sample, torch.device("cpu"), 1e-3, 80, KE, U)
+
+    check_eval_chain(g, evaluate, rtol=2e-5)                      # same fp32 CPU arithmetic as the reference's forward: near-exact
+
+
 def test_scene_folder_readers_and_rank_sampler(tmp_path):
     from PIL import Image
     from supervised_dispnet_amd import data as D
