@@ -560,9 +560,9 @@ def main():
             for name, flops, e0, e1, tag, nbytes, _ab in prof:
                 r = seen.setdefault((name, tag), [0.0, 0.0, 0, 0])
                 r[0] += flops; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += 1; r[3] += nbytes
-            print("%-46s %-58s %9s %9s %8s %8s" % ("kernel", "layer / entry", "ms/launch", "GFLOP", "TFLOP/s", "GB/s"), file=sys.stderr)
+            print("%-46s %-58s %9s %9s %8s %8s %6s %8s" % ("kernel", "layer / entry", "ms/launch", "GFLOP", "TFLOP/s", "GB/s", "n/step", "ms/step"), file=sys.stderr)
             for (name, tag), (fl, sec, n, nb) in seen.items():
-                print("%-46s %-58s %9.3f %9.2f %8.1f %8.0f" % (name, tag, sec / n * 1e3, fl / n / 1e9, fl / sec / 1e12, nb / sec / 1e9), file=sys.stderr)
+                print("%-46s %-58s %9.3f %9.2f %8.1f %8.0f %6.1f %8.3f" % (name, tag, sec / n * 1e3, fl / n / 1e9, fl / sec / 1e12, nb / sec / 1e9, n / nps, sec / nps * 1e3), file=sys.stderr)
         mf, hb, thin = {}, {}, {}
         for name, flops, e0, e1, _tag, nbytes, abytes in prof:
             sec = e0.elapsed_time(e1) * 1e-3

@@ -540,6 +540,11 @@ int dn_ubench_store(float* dst, int64_t n, int32_t mode, dn_stream_t stream);
  * nobody.  The caller runs this probe once per device before it hands out a split workspace and leaves splitk_ws NULL (no split,
  * same results) if the placement is anything else. */
 int dn_xcd_probe(int32_t* out, int32_t gx, int32_t gy, int32_t gz, dn_stream_t stream);
+/* Probe (round 5): a reduction finished by the LAST block of a grid, across XCDs, without an agent-scope fence -- records written with
+ * agent-scope relaxed atomic stores, an agent-scope counter, records read back with agent-scope relaxed atomic loads by the block that
+ * arrives last (mode 0; mode 1 = plain stores / loads, the control).  data: blocks * rec floats, counter: one zeroed int (left zero),
+ * result: 3 ints (+= mismatching floats, last block, += 1 per launch).  tools/exp/last_arrival_probe.py. */
+int dn_last_arrival_probe(float* data, int32_t* counter, int32_t* result, int32_t blocks, int32_t rec, int32_t round, int32_t mode, dn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -175,6 +175,7 @@ SIGNATURES = {
     "dn_ubench_mfma_f32": (C.c_int, [_vp, _i32, _i32, _vp]),
     "dn_ubench_store": (C.c_int, [_vp, _i64, _i32, _vp]),
     "dn_xcd_probe": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
+    "dn_last_arrival_probe": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     # diagnostic hook (host only)
     "dn_debug_conv_plan": (C.c_int, [_P(ConvDesc), C.c_int, _P(_i32), C.c_int]),
 }

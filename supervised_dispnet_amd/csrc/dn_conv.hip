@@ -2231,8 +2231,7 @@ static int launch_conv_x3(const IgemmParams& p, hipStream_t stream) {
 }
 
 static bool conv_x3b_eligible(const IgemmParams& p) {
-  static const bool off = getenv("DN_NO_X3B") != nullptr;
-  if (off || p.compute != DN_COMPUTE_F32X3 || !p.uni32 || p.n_in != 1 || p.BN != 128 || p.reflect) return false;
+  if (p.compute != DN_COMPUTE_F32X3 || !p.uni32 || p.n_in != 1 || p.BN != 128 || p.reflect) return false;
   const KOperand& S = p.in[0];
   if (!(S.vec && S.small && S.up == 0 && S.C % kChunk == 0)) return false;
   if (S.scale != nullptr && ((reinterpret_cast<uintptr_t>(S.scale) | reinterpret_cast<uintptr_t>(S.shift)) & 15)) return false;
@@ -2304,7 +2303,7 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
     if (conv_x3b_eligible(p)) return launch_conv_x3b(p, s);       // 128 x 128 tile: one operand with C % 32 == 0, enough tiles (round 4)
     switch (p.BN) {
       case 128: return p.bn_partial == nullptr ? launch_conv_x3<64, 128, 32, 64>(p, s) : launch_conv_x3<128, 64, 64, 32>(p, s);   // (statistics rows are per 128-row tile)
-      case 64: return (small_m || p.bn_partial == nullptr && blocks128 <= 416) ? launch_conv_x3<64, 64, 32, 32>(p, s) : launch_conv_x3<128, 64, 64, 32>(p, s);
+      case 64: return (small_m || (p.bn_partial == nullptr && blocks128 <= 416)) ? launch_conv_x3<64, 64, 32, 32>(p, s) : launch_conv_x3<128, 64, 64, 32>(p, s);
       default: return launch_conv_x3<128, 32, 32, 32>(p, s);
     }
   }
@@ -2458,13 +2457,9 @@ static bool wgrad_split_plans(const dn_conv_desc* fwd, dn_conv_desc* d1, dn_conv
   if (wino_wgrad_eligible(d1, *p1)) {
     p1->dw_cin_total = cin_total;
     *w1 = (wino_wgrad_workspace_bytes(*p1) + 255) / 256 * 256;
-  } else if (wgrad_x3_eligible(*p1) && getenv("DN_WGRAD_SPLIT_X3") != nullptr) {
-    // (round 4, opt-in: measured SLOWER -- iconv1 97 -> 32 @64x208 0.375 -> 0.508 ms, a 32-wide n tile is bound by its staging) the pieces
-    // in front on the three-piece tiled kernel -- the trailing scalar piece is what keeps the whole layer off it
-    p1->D1 = cin_total;                          // packed_to_framework: row stride of the full weight tensor
-    choose_splits(p1);
-    *w1 = ((size_t)p1->splits * p1->Npad * p1->ph[0].nchunks * kChunk * sizeof(float) + 255) / 256 * 256;
   } else {
+    // (round 4 measured the pieces in front on the three-piece tiled kernel: SLOWER -- iconv1 97 -> 32 @64x208 0.375 -> 0.508 ms, a 32-wide
+    //  n tile is bound by its staging; the switch that kept that path alive was removed in round 5)
     return false;
   }
   p2->in[0].ch_off = cin_total - 1;              // (packed_to_framework: the column block of this channel in the full weight tensor)

@@ -62,7 +62,6 @@ struct Knobs {
   int pack_blocks;          // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
   int wino_min_n, wino_pad_pct;   // DN_WINO_MIN_N (64): fewest output channels of a Winograd layer; DN_WINO_PAD_PCT (60): least live share of its padded tile x channel grid
   bool no_lds3, no_lds3_wgrad, no_stem3, no_x3_wgrad, no_tap_windows;   // DN_NO_LDS3 / DN_NO_LDS3_WGRAD / DN_NO_STEM3 / DN_NO_X3_WGRAD / DN_NO_TAP_WINDOWS (round 4 kernels, A/B)
-  int wino8_fullsplit, wino8_fullsplit_minch, wino8_fullsplit_maxblocks;   // DN_WINO8_FULLSPLIT (1): grids below 192 blocks of 64 tiles split EVERY tile along K (dn_winograd8.hip)
   int wino8, wino8_min_k;   // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel; DN_WINO8_MIN_K: its rule's channel floor
 };
 const Knobs& knobs();

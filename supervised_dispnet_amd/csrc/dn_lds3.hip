@@ -694,8 +694,7 @@ bool lds3_conv_eligible(const dn_conv_desc* d, const IgemmParams& p) { return ld
 template <int CG, int NKS, bool HAS1, int ROLES, int STRIDE, int TH, int TW, int ROWS, int COLS>
 static int lds3_launch(const IgemmParams& p, const Lds3Geo& geo, hipStream_t stream) {
   using Cfg = Lds3Cfg<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS>;
-  static const bool nopipe = getenv("DN_LDS3_NOPIPE") != nullptr;
-  auto kernel = nopipe ? lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, 0> : lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, 1>;
+  auto kernel = lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, 1>;
   if constexpr (CG == 2 && HAS1) {                                  // phase timestamps of the iconv0 forward form (tools/lds3_timing.py)
     if (geo.dbg != nullptr) kernel = lds3_conv_kernel<CG, NKS, HAS1, ROLES, STRIDE, TH, TW, ROWS, COLS, 2>;
   }
@@ -712,7 +711,7 @@ static int lds3_launch(const IgemmParams& p, const Lds3Geo& geo, hipStream_t str
   blocks = (blocks + 7) / 8 * 8;
   DN_LAUNCH(kernel, dim3(blocks), dim3(256), lds, stream, p, geo);
   set_last_kernel("dn::lds3_conv_kernel<%d, %d, %s, %d, %d, %d, %d, %d, %d, %s>", CG, NKS, HAS1 ? "true" : "false", ROLES, STRIDE, TH, TW, ROWS, COLS,
-                  nopipe ? "false" : "true");
+                  "true");
   return check_launch("lds3_conv_kernel");
 }
 

@@ -795,8 +795,7 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
 
 // 0 none, 1 without / 2 with the trailing 1-channel piece
 static int lds3k_wgrad_form(const dn_conv_desc* d, const IgemmParams& p) {
-  static const bool off = getenv("DN_NO_LDS3K_WGRAD") != nullptr;
-  if (off || knobs().no_lds3_wgrad || d->compute != DN_COMPUTE_F32X3) return 0;
+  if (knobs().no_lds3_wgrad || d->compute != DN_COMPUTE_F32X3) return 0;
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return 0;
   if (d->IH != d->OH || d->IW != d->OW || p.Ntot > 32 || p.Ntot < 17 || (p.Ntot & 3)) return 0;
   if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) return 0;

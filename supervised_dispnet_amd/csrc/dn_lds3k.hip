@@ -404,8 +404,7 @@ struct LkPick {
 static LkPick lk_pick(const dn_conv_desc* d, const IgemmParams& p) {
   LkPick r;
   r.cfg = 0;
-  static const bool off = getenv("DN_NO_LDS3K") != nullptr;
-  if (off || knobs().no_lds3 || p.compute != DN_COMPUTE_F32X3) return r;
+  if (knobs().no_lds3 || p.compute != DN_COMPUTE_F32X3) return r;
   if (p.reflect || p.bn_partial != nullptr || p.bnb_y != nullptr || d->dilation > 1 || p.n_out < 1) return r;
   if (!(p.nphases == 1 || p.nphases == 4) || p.sy != p.sx || (p.sy != 1 && p.sy != 2)) return r;
   int nmain = p.n_in;

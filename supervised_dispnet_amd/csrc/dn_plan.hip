@@ -84,20 +84,20 @@ static void read_knobs(Knobs* k) {
   k->no_winograd = on("DN_NO_WINOGRAD");
   k->no_winograd_wgrad = on("DN_NO_WINOGRAD_WGRAD");
   k->no_direct = on("DN_NO_DIRECT");
-  k->no_stem = on("DN_NO_STEM");
-  k->no_u32 = on("DN_NO_U32");
-  k->no_bm64 = on("DN_NO_BM64");
+  k->no_stem = false;
+  k->no_u32 = false;
+  k->no_bm64 = false;
   k->no_thin = on("DN_NO_THIN");
   k->no_thin_conv = on("DN_NO_THIN_CONV");
-  k->no_tile_store = on("DN_NO_TILE_STORE");
-  k->tile_store_linear_only = on("DN_TILE_STORE_LINEAR_ONLY");
-  k->no_wgrad_split = on("DN_NO_WGRAD_SPLIT");
-  k->x3_bn32 = on("DN_X3_BN32");
+  k->no_tile_store = false;
+  k->tile_store_linear_only = false;
+  k->no_wgrad_split = false;
+  k->x3_bn32 = false;
   k->no_splitk = on("DN_NO_SPLITK");
-  k->no_head2 = on("DN_NO_HEAD2");
-  k->extra_lds = num("DN_DEBUG_EXTRA_LDS", 0);
+  k->no_head2 = false;
+  k->extra_lds = 0;
   k->wino_dbg = num("DN_WINO_DBG", 0);
-  k->wino_mtw = num("DN_WINO_MTW", 1);
+  k->wino_mtw = 1;
   k->wino_wg_dbg = num("DN_WINO_WG_DBG", 0);
   k->wino_wgw = num("DN_WINO_WGW", 1);
   k->lds3_dbg = num("DN_LDS3_DBG", 0);
@@ -105,40 +105,36 @@ static void read_knobs(Knobs* k) {
   k->wino_min_tiles = num("DN_WINO_MIN_TILES", 192);
   k->no_x3_direct = on("DN_NO_X3_DIRECT");
   k->no_wino_splitk = on("DN_NO_WINO_SPLITK");
-  k->wino_splitk_target = num("DN_WINO_SPLITK_TARGET", 256);
-  k->wino_splitk_minch = num("DN_WINO_SPLITK_MINCH", 8);
-  k->wino_splitk_maxblocks = num("DN_WINO_SPLITK_MAXBLOCKS", 128);
+  k->wino_splitk_target = num("DN_WINO_SPLITK_TARGET", 512);   // (r05: 256 -> 512 and 128 -> 208 blocks: the 208-block layers of a 4-image shard take two co-resident half-K blocks per CU; b4 3.83 -> 3.74 ms, b8 5.50 -> 5.45, profiles/r05_exp2.txt)
+  k->wino_splitk_minch = 8;
+  k->wino_splitk_maxblocks = num("DN_WINO_SPLITK_MAXBLOCKS", 208);
   if (k->wino_splitk_minch < 1) k->wino_splitk_minch = 1;
-  k->reduce_rows_per_thread = num("DN_REDUCE_ROWS_PER_THREAD", 2);
+  k->reduce_rows_per_thread = 2;
   if (k->reduce_rows_per_thread < 1) k->reduce_rows_per_thread = 1;
-  k->reduce_max_blocks = num("DN_REDUCE_MAX_BLOCKS", 1024);
+  k->reduce_max_blocks = 1024;
   if (k->reduce_max_blocks < 1) k->reduce_max_blocks = 1;
   k->no_wino8_tail = on("DN_NO_WINO8_TAIL");
-  k->wino8_tail_max = num("DN_WINO8_TAIL_MAX", 64);
-  k->wino8_tail_minch = num("DN_WINO8_TAIL_MINCH", 8);
+  k->wino8_tail_max = 64;
+  k->wino8_tail_minch = 8;
   if (k->wino8_tail_minch < 1) k->wino8_tail_minch = 1;
-  k->no_bn_hoist = on("DN_NO_BN_HOIST");
+  k->no_bn_hoist = false;
   k->no_x3_splitk = on("DN_NO_X3_SPLITK");
-  k->x3_splitk_target = num("DN_X3_SPLITK_TARGET", 512);
-  k->x3_splitk_minch = num("DN_X3_SPLITK_MINCH", 8);
+  k->x3_splitk_target = 512;
+  k->x3_splitk_minch = 8;
   if (k->x3_splitk_minch < 1) k->x3_splitk_minch = 1;
-  k->x3_splitk_maxblocks = num("DN_X3_SPLITK_MAXBLOCKS", 208);
-  k->no_bn_sums_fusion = on("DN_NO_BN_SUMS_FUSION");
+  k->x3_splitk_maxblocks = 208;
+  k->no_bn_sums_fusion = false;
   k->pack_blocks = num("DN_PACK_BLOCKS", 512);
   if (k->pack_blocks < 1) k->pack_blocks = 1;
-  k->wino_min_n = num("DN_WINO_MIN_N", 64);
-  k->wino_pad_pct = num("DN_WINO_PAD_PCT", 60);
+  k->wino_min_n = 64;
+  k->wino_pad_pct = 60;
   k->no_lds3 = on("DN_NO_LDS3");
-  k->no_lds3_wgrad = on("DN_NO_LDS3") || on("DN_NO_LDS3_WGRAD");
-  k->no_stem3 = on("DN_NO_LDS3") || on("DN_NO_STEM3");
+  k->no_lds3_wgrad = on("DN_NO_LDS3");
+  k->no_stem3 = on("DN_NO_LDS3");
   k->no_x3_wgrad = on("DN_NO_X3_WGRAD");
   k->no_tap_windows = on("DN_NO_TAP_WINDOWS");
   k->wino8 = num("DN_WINO8", -1);
-  k->wino8_min_k = num("DN_WINO8_MIN_K", 128);
-  k->wino8_fullsplit = num("DN_WINO8_FULLSPLIT", 0);
-  k->wino8_fullsplit_minch = num("DN_WINO8_FULLSPLIT_MINCH", 4);
-  if (k->wino8_fullsplit_minch < 1) k->wino8_fullsplit_minch = 1;
-  k->wino8_fullsplit_maxblocks = num("DN_WINO8_FULLSPLIT_MAXBLOCKS", 128);
+  k->wino8_min_k = 128;
 }
 
 const Knobs& knobs() {

@@ -72,6 +72,47 @@ __global__ void __launch_bounds__(64) xcd_probe_kernel(int* __restrict__ out) {
   }
 }
 
+// Cross-XCD last-arrival WITHOUT an agent-scope fence (round 5 probe for reductions finished by the last block of a grid): every block
+// writes a record with agent-scope (sc1) relaxed atomic stores, waits for them (vmcnt(0)), bumps an agent-scope counter; the block that
+// arrives last reads EVERY block's record with agent-scope relaxed atomic loads and counts mismatches.  The same buffers are reused round
+// after round, so another XCD's L2 holds the previous round's lines -- exactly what a plain load would return.  mode 1 = plain stores /
+// plain loads (the control: expected to see stale data across XCDs).  result[0] += mismatches, result[1] = last block, result[2] += 1.
+__global__ void __launch_bounds__(256) last_arrival_probe_kernel(float* __restrict__ data, int* __restrict__ counter, int* __restrict__ result,
+                                                                 int rec, int round, int mode) {
+  __shared__ int last;
+  const int tid = threadIdx.x;
+  float* mine = data + (long long)blockIdx.x * rec;
+  // (blocks arrive in a scrambled order: a block-dependent number of dependent FMAs first)
+  float spin = 1.f + tid;
+  for (int i = 0; i < (int)((blockIdx.x * 37u) % 64u) * 16; ++i) spin = __builtin_fmaf(spin, 1.0000001f, 1e-7f);
+  const float tag = (float)(round % 1000) * 1000.f + (float)blockIdx.x + (spin < 0.f ? 1.f : 0.f);
+  for (int i = tid; i < rec; i += 256) {
+    const float v = tag + (float)i * 0.0009765625f;
+    if (mode == 0) __hip_atomic_store(mine + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else mine[i] = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) last = (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!last) return;
+  int bad = 0;
+  for (int b = 0; b < (int)gridDim.x; ++b) {
+    const float want0 = (float)(round % 1000) * 1000.f + (float)b;
+    const float* rp = data + (long long)b * rec;
+    for (int i = tid; i < rec; i += 256) {
+      const float v = mode == 0 ? __hip_atomic_load(rp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *reinterpret_cast<const volatile float*>(rp + i);
+      bad += (v != want0 + (float)i * 0.0009765625f) ? 1 : 0;
+    }
+  }
+  if (bad) atomicAdd(result, bad);
+  if (tid == 0) {
+    result[1] = (int)blockIdx.x;
+    atomicAdd(result + 2, 1);
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // self-resetting, like the K-split counters
+  }
+}
+
 }  // namespace dn
 
 using namespace dn;
@@ -81,7 +122,7 @@ extern "C" {
 int dn_ubench_copy(const float* src, float* dst, int64_t n, dn_stream_t stream) {
   DN_REQUIRE(src && dst && n > 0 && n % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, DN_ERR_BAD_ARG,
              "dn_ubench_copy: need 16-byte aligned buffers and n %% 4 == 0");
-  static const int blocks = getenv("DN_UBENCH_COPY_BLOCKS") ? atoi(getenv("DN_UBENCH_COPY_BLOCKS")) : 256 * 16;
+  const int blocks = 256 * 16;
   DN_LAUNCH(ubench_copy_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const f32x4*)src, (f32x4*)dst, (long long)(n / 4));
   return check_launch("ubench_copy_kernel");
 }
@@ -101,6 +142,12 @@ int dn_ubench_store(float* dst, int64_t n, int32_t mode, dn_stream_t stream) {
   DN_REQUIRE(dst && n > 0 && n % 1024 == 0 && ((uintptr_t)dst & 15) == 0, DN_ERR_BAD_ARG, "dn_ubench_store: need a 16-byte aligned buffer of a multiple of 1024 floats");
   DN_LAUNCH(ubench_store_kernel, dim3(256 * 8), dim3(256), 0, as_stream(stream), (f32x4*)dst, (long long)(n / 4), mode);
   return check_launch("ubench_store_kernel");
+}
+
+int dn_last_arrival_probe(float* data, int32_t* counter, int32_t* result, int32_t blocks, int32_t rec, int32_t round, int32_t mode, dn_stream_t stream) {
+  DN_REQUIRE(data && counter && result && blocks > 0 && rec > 0, DN_ERR_BAD_ARG, "dn_last_arrival_probe: bad argument");   // data: blocks*rec floats; counter: 1 zeroed int; result: 3 ints
+  DN_LAUNCH(last_arrival_probe_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), data, counter, result, rec, round, mode);
+  return check_launch("last_arrival_probe_kernel");
 }
 
 int dn_xcd_probe(int32_t* out, int32_t gx, int32_t gy, int32_t gz, dn_stream_t stream) {

@@ -228,8 +228,7 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_x3_kernel(const IgemmParam
 // plans the kernel takes: the fast weight-gradient plan (<= 32 taps, zero padding, 32-bit offsets) whose operands are all float4-addressable,
 // and a grid row of at least 8 pixels (an 8-pixel staging group wraps at most once)
 bool wgrad_x3_eligible(const IgemmParams& p) {
-  static const bool no32 = getenv("DN_NO_X3_WGRAD32") != nullptr;
-  if (knobs().no_x3_wgrad || p.compute != DN_COMPUTE_F32X3 || !p.wg_uniform || p.GW < 8 || (p.BN == 32 && no32)) return false;
+  if (knobs().no_x3_wgrad || p.compute != DN_COMPUTE_F32X3 || !p.wg_uniform || p.GW < 8) return false;
   for (int i = 0; i < p.n_in; ++i) {
     const KOperand& o = p.in[i];
     if (!(o.vec && o.small)) return false;

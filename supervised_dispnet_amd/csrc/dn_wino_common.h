@@ -143,7 +143,6 @@ __device__ __forceinline__ void wino_bn_bwd_sums(const IgemmParams& p, const f32
 
 // dn_winograd8.hip: the 8-wave / one-block-per-CU form of the three-piece kernel (64 tiles x 64 output channels, two positions per wave)
 bool wino8_wanted(const IgemmParams& p);
-int wino8_fullsplit_choice(const IgemmParams& p, int* ks_out);
 int launch_wino_conv8(const IgemmParams& p, hipStream_t stream);
 
 }  // namespace dn

@@ -60,7 +60,6 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     kz = r / p.ks_tail;
     if (kz >= p.ksplit) return;
     q = p.ks_reg + r % p.ks_tail;
-    if (q >= MT * NT) return;             // (full split of a small grid: the tail is padded to a multiple of 8 blocks)
     const int cps = (p.ks_chunks + p.ksplit - 1) / p.ksplit;
     g0 = kz * cps;
     g1 = g0 + cps < p.ks_chunks ? g0 + cps : p.ks_chunks;
@@ -627,8 +626,6 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
   }
 }
 
-int wino8_fullsplit_choice(const IgemmParams& p, int* ks_out);
-
 template <bool HA, int DBG>
 static int launch_wino8_variant(const IgemmParams& p, hipStream_t stream) {
   auto kernel = wino_conv8_kernel<HA, DBG>;
@@ -662,22 +659,6 @@ static int launch_wino8_variant(const IgemmParams& p, hipStream_t stream) {
       blocks = reg + tail * ks;
     }
   }
-  // full split (round 5; small grids = the 32/N-image shards of the literal metric): fewer than 192 blocks of 64 tiles leave CUs
-  // idle while every block walks the whole K axis alone -- EVERY tile is split (no regular part: ks_reg = 0, the tail padded to a
-  // multiple of 8 blocks so that the splits of a tile share an XCD; blocks past the grid return at once)
-  if (DBG == 0) {
-    int fks = 0, chunks = 0;
-    for (int i = 0; i < p.n_in; ++i) chunks += (p.in[i].C + WKC - 1) / WKC;
-    const int fpad = wino8_fullsplit_choice(p, &fks);
-    if (fpad > 0 && p.ks_ws_bytes >= 4096 + (size_t)fpad * fks * 32 * 512 * 16) {
-      q.ksplit = fks;
-      q.ks_chunks = chunks;
-      q.ks_cnt_floats = 4096 / 4;
-      q.ks_reg = 0;
-      q.ks_tail = fpad;
-      blocks = fpad * fks;
-    }
-  }
   dim3 grid(blocks);
   DN_LAUNCH(kernel, grid, dim3(512), kLds8, stream, q);
   set_last_kernel("dn::wino_conv8_kernel<%s, %d>", HA ? "true" : "false", DBG);
@@ -688,24 +669,6 @@ static int launch_wino8_variant(const IgemmParams& p, hipStream_t stream) {
 // (profiles/r03_wino8_microbench.txt): 512 -> 512 @16x52 forward 0.466 -> 0.422 ms, @8x26 0.123 -> 0.106; 256 -> 256 -5 %; 128 -> 128
 // -2 %; 64 -> 64 +-0 (four chunks: the exposed prologue / epilogue eat the main loop's gain); 768 -> 256 @8x26 (104 blocks of 64 tiles
 // for 256 CUs) +30 %: the 4-wave kernel's 208 half-size blocks fill the chip better.
-// Full split of a small grid: returns the padded number of 64-tile blocks (0 = no) and the split count.
-int wino8_fullsplit_choice(const IgemmParams& p, int* ks_out) {
-  *ks_out = 0;
-  if (p.compute != DN_COMPUTE_F32X3 || knobs().wino8 == 0 || knobs().wino8_fullsplit == 0 || knobs().no_wino_splitk) return 0;
-  if (p.ks_ws == nullptr) return 0;
-  int chunks = 0;
-  for (int i = 0; i < p.n_in; ++i) chunks += (p.in[i].C + WKC - 1) / WKC;
-  const long long blocks = (long long)((p.M / 4 + BT8 - 1) / BT8) * ((p.Ntot + WBN - 1) / WBN);
-  if (blocks >= 192 || blocks > knobs().wino8_fullsplit_maxblocks || chunks * WKC < knobs().wino8_min_k) return 0;
-  const int pad = (int)((blocks + 7) / 8 * 8);
-  int ks = 256 / pad;
-  if (ks > chunks / knobs().wino8_fullsplit_minch) ks = chunks / knobs().wino8_fullsplit_minch;
-  if (ks > 8) ks = 8;
-  if (ks < 2 || p.ks_ws_bytes < 4096 + (size_t)pad * ks * 32 * 512 * 16) return 0;
-  *ks_out = ks;
-  return pad;
-}
-
 bool wino8_wanted(const IgemmParams& p) {
   if (p.compute != DN_COMPUTE_F32X3) return false;
   const int mode = knobs().wino8;
@@ -714,9 +677,10 @@ bool wino8_wanted(const IgemmParams& p) {
   int k = 0;
   for (int i = 0; i < p.n_in; ++i) k += (p.in[i].C + WKC - 1) / WKC * WKC;
   const long long blocks = (long long)((p.M / 4 + BT8 - 1) / BT8) * ((p.Ntot + WBN - 1) / WBN);
-  if (k >= knobs().wino8_min_k && blocks >= 192) return true;
-  int fks;
-  return wino8_fullsplit_choice(p, &fks) > 0;
+  // (round 5 measured a FULL split for grids below 192 blocks -- every 64-tile block split 2-8 ways along K, ks_reg = 0: 256 KB of partial
+  //  accumulators per split block against the 4-wave kernel's 32 KB of transformed partial tiles; 512 -> 512 @16x52 with 4 images 0.084 ->
+  //  0.082 ms, @8x26 0.044 -> 0.055, the 4-image step 3.78 -> 3.89 ms: dropped, profiles/r05_exp1.txt)
+  return k >= knobs().wino8_min_k && blocks >= 192;
 }
 
 int launch_wino_conv8(const IgemmParams& p, hipStream_t stream) {

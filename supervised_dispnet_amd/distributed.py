@@ -159,10 +159,10 @@ class GradReducer(object):
         b = self.buckets[bi]
         # Which stream: the weight-gradient side stream this event comes from (or the first one).  A stream of the optimizer's own
         # was measured SLOWER (b4 4.01 -> 4.18 ms, b32 +0.07 ms): a fourth concurrent queue costs more than the update's overlap gains,
-        # like a third weight-gradient stream (engine.WGRAD_STREAMS).  DN_ADAM_STREAM=own keeps the dedicated stream for measurements.
+        # like a third weight-gradient stream (engine.WGRAD_STREAMS); the dedicated stream is only the fallback without side streams.
         cur = torch.cuda.current_stream()
         sides = engine.side_stream()["sides"] if engine.wgrad_stream_enabled() else []
-        if os.environ.get("DN_ADAM_STREAM") == "own" or not sides:
+        if not sides:
             if self._opt_stream is None:
                 self._opt_stream = torch.cuda.Stream(device=self.arena.flat_g.device)
             O = self._opt_stream

@@ -36,12 +36,11 @@ PARAM_EPOCH = 0
 # for every implicit-GEMM launch, bracketed with HIP events on the launch stream.  None = off (zero overhead).
 PROFILE = None
 
-# DN_BN_MATERIALIZE=1: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back) for A/B runs and the equivalence test
-SPLITK = os.environ.get("DN_NO_WINO_SPLITK") is None            # small Winograd grids split their input channels over several blocks
-PACK_ON_SIDE_STREAM = os.environ.get("DN_NO_PACK_SIDE") is None     # batched weight re-lay of the large layers under the first layers of the forward
-PACK_LATE_MIN_ELEMS = int(os.environ.get("DN_PACK_LATE_MIN_ELEMS", "400000"))
-BN_SUMS_FUSION = os.environ.get("DN_NO_BN_SUMS_FUSION") is None     # input-gradient kernels take the BatchNorm backward's column sums of the layer below
-BN_MATERIALIZE_DZ = bool(os.environ.get("DN_BN_MATERIALIZE"))
+SPLITK = True                   # small Winograd / direct grids split their K axis over several blocks (tests switch it off to compare)
+PACK_ON_SIDE_STREAM = True      # batched weight re-lay of the large layers under the first layers of the forward
+PACK_LATE_MIN_ELEMS = 400000
+BN_SUMS_FUSION = True           # input-gradient kernels take the BatchNorm backward's column sums of the layer below
+BN_MATERIALIZE_DZ = False       # True: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back); the equivalence test sets it
 
 # Arithmetic of the matrix-core kernels that offer a choice (dn_conv_desc.compute, include/dispnet_hip.h), today the Winograd forward /
 # input-gradient kernels.  Tensors in HBM, statistics, transforms and all other kernels are fp32 in every mode.
@@ -88,10 +87,9 @@ WGRAD_STREAM = _WGRAD_STREAM_MODE != "0"
 # Number of side streams the weight gradients alternate between.  At the metric's b32 the device is full and one is as good as two; at
 # 4 images per GPU (b32 over 8 GPUs) no kernel fills the chip and the ONE side stream's queue (2.4 ms of weight-gradient launches that
 # cannot start before the loss) had become the critical path of the step.
-WGRAD_STREAMS = int(os.environ.get("DN_WGRAD_STREAMS", "2"))
-WGRAD_STREAMS_MAX_PIXELS = int(os.environ.get("DN_WGRAD_STREAMS_MAX_PIXELS", str(16 * 128 * 416)))   # measured: b4 -3.8 %, b8 -0.4 %, b16 -1.3 %, b32 +-0
+WGRAD_STREAMS = 2
+WGRAD_STREAMS_MAX_PIXELS = 16 * 128 * 416   # measured: b4 -3.8 %, b8 -0.4 %, b16 -1.3 %, b32 +-0
 SIDE_STREAMS_ACTIVE = 1
-BIAS_FINALIZE_ON_MAIN = os.environ.get("DN_BIAS_FINALIZE_MAIN") is not None      # (A/B: second stage of the bias-gradient sums on the main stream)
 
 
 def choose_side_streams(input_pixels):
@@ -227,13 +225,10 @@ def xcd_placement_ok(device):
     """One-time probe per device: the K-split kernels publish partial tiles to ONE XCD's L2 and rely on every block with the
     same blockIdx.x (gridDim.x a multiple of 8) running on the same XCD.  HIP promises no placement, so the property is CHECKED on the
     device in hand -- three grid shapes of the kind the split launches use, on the current stream and, concurrently, on a second one --
-    and the split is simply not offered (results identical, small grids slower) when it does not hold.  DN_SPLITK_TRUST=1 skips the probe."""
+    and the split is simply not offered (results identical, small grids slower) when it does not hold."""
     ok = _XCD_OK.get(device.index)
     if ok is not None:
         return ok
-    if os.environ.get("DN_SPLITK_TRUST") == "1":
-        _XCD_OK[device.index] = True
-        return True
     ok = True
     # (a launch tape being recorded must not see the probe: its launches would be replayed into buffers that are long freed -- found by
     #  test_two_ranks_through_the_launch_tape..., whose FIRST step is the recorded one; graph.TapedStep also probes before it records)
@@ -696,15 +691,13 @@ def pack_table(device):
 
 def prepack_all(device):
     """Start of a recorded forward pass: one batched re-lay of every packed weight the previous steps used (no-op when nothing
-    changed since the last call or DN_NO_PACK_TABLE is set)."""
-    if os.environ.get("DN_NO_PACK_TABLE"):
-        return
+    changed since the last call)."""
     t = _PACK_TABLES.get(device)
     if t is not None:
         t.run(PARAM_EPOCH)
 
 
-FUSE_RECIP = os.environ.get("DN_NO_RECIP_FUSION") is None       # a one-channel disparity head also emits depth = 1 / disp (train.py:445)
+FUSE_RECIP = True       # a one-channel disparity head also emits depth = 1 / disp (train.py:445); tests switch it off to compare
 
 
 def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None, out_view=None, recip=None):
@@ -1171,11 +1164,7 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
                 sink.put(layer.m.bias, db)
             return db if (layer.m.bias is None or sink.dest(layer.m.bias) is None) else None      # (a fresh tensor the caller's stream will read)
 
-        if BIAS_FINALIZE_ON_MAIN:
-            bias_grad()
-            conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink)
-        else:
-            conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink, first=(bias_grad, db_partial))
+        conv_wgrad(layer, pieces, g, (OH, OW), out=sink.dest(layer.m.weight), sink=sink, first=(bias_grad, db_partial))
         conv_dgrad(layer, g, a0.N, OH, OW, pieces, in_hw)
         y.grad = None
 
