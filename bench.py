@@ -357,6 +357,18 @@ def main():
                     help="1: the Adam update of a gradient bucket runs as soon as the bucket (and its all-reduce) is complete, on its own "
                          "stream under the rest of the backward pass (FusedAdam.overlap_backward; bit-identical to the single update); "
                          "auto: on for the metric's config")
+    ap.add_argument("--reducer", default="auto", choices=["auto", "rccl1"],
+                    help="one rank only.  rccl1: run the step with the data-parallel machinery live -- gradient buckets, the launch tape cut "
+                         "at every bucket, event fences against both compute streams, ncclAllReduce on this library's own single-rank RCCL "
+                         "communicator and stream, 1/N folded into Adam -- so that the host-side cost of the N > 1 path is a number on the "
+                         "one-GPU pool (only the wire is missing); config.comm says what ran")
+    ap.add_argument("--comm-standin", type=int, default=0, metavar="K",
+                    help="with --reducer rccl1: after each bucket's all-reduce, K round trips of the bucket through a scratch buffer on the "
+                         "communication stream (dn_ubench_copy: read + write of the bucket twice per trip) -- a stand-in for the HBM side of "
+                         "a ring all-reduce competing with the backward pass.  A PROJECTION, labelled as such in config.comm_standin")
+    ap.add_argument("--watchdog-s", type=float, default=0.0,
+                    help="N > 1: if the line has not been printed after this many seconds (default 900 at N > 1, 0 = off at N = 1) rank 0 "
+                         "prints a line with value null and the reason, and every rank exits non-zero")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only plumbing check of the N>1 path: build the net, the arena, the buckets, one fake all-reduce cycle, tear down")
     args = ap.parse_args()
@@ -371,6 +383,7 @@ def main():
         return self_launch(args.gpus)
     if args.dry_run:
         return dry_run(args, world, rank)
+    watchdog = start_watchdog(args, world, rank)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -416,7 +429,20 @@ def main():
     overlap_adam = args.adam_overlap == "1" or (args.adam_overlap == "auto" and args.config == "vggbn128" and batch * H * W > 16 * 128 * 416)
     # one rank: the reducer exchanges nothing (comm "torch" at world 1 = no collective) and only tells the optimizer when a bucket of
     # gradients is complete
-    reducer = GradReducer(opt.arena, comm=(None if world > 1 else "torch")) if (world > 1 or overlap_adam) else None
+    standin = None
+    if args.reducer == "rccl1" and world == 1:
+        reducer = GradReducer(opt.arena, comm="rccl")
+        if reducer.comm is None:
+            raise SystemExit("--reducer rccl1: the single-rank RCCL communicator could not be created")
+        if args.comm_standin > 0:
+            standin = {"round_trips_per_bucket": args.comm_standin, "buckets": len(reducer.buckets),
+                       "bytes_moved_per_step": sum((b["hi"] - b["lo"]) * 4 for b in reducer.buckets) * 4 * args.comm_standin,
+                       "note": "PROJECTION: dn_ubench_copy of every gradient bucket to a scratch buffer and back on the communication stream "
+                               "behind its single-rank ncclAllReduce -- the HBM side of a ring all-reduce under the backward pass; no xGMI "
+                               "link is involved"}
+            reducer.comm.standin_round_trips = args.comm_standin
+    else:
+        reducer = GradReducer(opt.arena, comm=(None if world > 1 else "torch")) if (world > 1 or overlap_adam) else None
     if overlap_adam:
         opt.overlap_backward(reducer)
     state["reducer"] = reducer
@@ -655,7 +681,12 @@ def main():
                        "tape_verified": (None if tape_verified is None else
                                          ("replay == eager step, bit for bit" if tape_verified[0] else "MISMATCH: max |diff| %.3g" % tape_verified[1])),
                        "graph_fallback": graph_note, "adam": "per bucket, under the backward pass" if overlap_adam else "one pass after the backward",
-                       "comm": reducer.path if reducer is not None else "none (one rank)",
+                       "comm": (reducer.path + (" (single-rank communicator: buckets, tape cuts, fences and ncclAllReduce live; no wire)"
+                                                if (world == 1 and reducer.comm is not None) else "")) if reducer is not None else "none (one rank)",
+                       "comm_buckets": len(reducer.buckets) if reducer is not None else 0,
+                       "comm_standin": standin,
+                       "rccl_selfcheck": {"status": "not run: " + ("one rank" if world == 1 else ("--rccl-selfcheck 0" if args.rccl_selfcheck == "0" else
+                                                                                                 "backend %s" % os.environ.get("DN_DIST_BACKEND", "nccl")))},
                        "dist_backend": dist.get_backend() if world > 1 else None},
             "step_tflops_credited_per_gpu": (step_credited_flops / sec_step / 1e12) if step_credited_flops else None,
             "step_credited_frac": (step_credited_flops / sec_step / 1e12 / PEAK_FP32_MFMA_TFLOPS) if step_credited_flops else None,
@@ -667,11 +698,43 @@ def main():
         line = None
     if world > 1 and args.rccl_selfcheck != "0" and os.environ.get("DN_DIST_BACKEND", "nccl") == "nccl":
         rccl_selfcheck(line, dev, rank, world)
+    if watchdog is not None:
+        watchdog.cancel()
+    try:
+        # librccl prints its version banner through C stdio (buffered when stdout is a pipe): push it out BEFORE the line, so that the
+        # JSON line is the last thing this process writes
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                           # noqa: BLE001
+        pass
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def start_watchdog(args, world, rank):
+    """N > 1: a collective that never returns (a rank died, RCCL wedged) would leave the driver without any line.  After --watchdog-s
+    seconds rank 0 prints ONE line that keeps the contract's keys (value null, the reason in `error`) and every rank leaves."""
+    import threading
+    limit = args.watchdog_s if args.watchdog_s > 0 else (900.0 if world > 1 else 0.0)
+    if limit <= 0:
+        return None
+
+    def bail():
+        if rank == 0:
+            print(json.dumps({"metric": CONFIGS[args.config][0], "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                              "dtype": args.compute, "data": "synthetic", "config": {"name": args.config, "parallelism": "dp%d" % world},
+                              "error": "watchdog: no result after %.0f s (a rank or a collective is stuck); nothing was measured" % limit}))
+            sys.stdout.flush()
+        os._exit(3)
+
+    t = threading.Timer(limit, bail)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def self_launch(n):

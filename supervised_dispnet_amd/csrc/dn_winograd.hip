@@ -193,103 +193,75 @@ __device__ __forceinline__ void wino_split3(float x, __bf16* pc) {
   pc[2] = (__bf16)(r1 - (float)pc[1]);      // exact, at most 8 significant bits: the conversion does not round
 }
 
-// Round 5: one thread per 16-byte B fragment (16-k chunk, 32-n group, lane) = EIGHT k of one n, written with one 16-byte store per
-// (position, piece) -- 48 stores of 16 bytes where the round-2 kernel (one thread per (n, k) pair) issued 48 two-byte stores per pair,
-// chose every tap through a 9 x 9 compare chain and converted value by value: that kernel was bound by its vector ALU work (~300
-// instructions per pair, 83 us per launch for the metric's network).  Same values, bit for bit (the same transform expressions and the
-// same round-to-nearest three-piece split).
 template <int NSPL>
 __device__ __forceinline__ void wino_pack16_body(const IgemmParams& p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
-  typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
   __bf16* wp16 = reinterpret_cast<__bf16*>(wp);
-  const long long nfrag = total >> 7;                        // (n, k) pairs / 8
-  // source offset (r * 3 + s of the framework filter) of every slot (a, b) of the 3 x 3 correlation kernel: wave-uniform, once per thread
+  const long long npairs = total >> 4;                       // (n, k) pairs, each written at 16 positions
+  // framework tap (r * 3 + s) behind every slot (a, b) of the 3 x 3 correlation kernel: wave-uniform, once per thread (round 5: the
+  // round-2 body chose each of the nine values through a 9 x 9 compare chain per pair -- 81 selects of the ~300 vector instructions)
   int src_of[9];
 #pragma unroll
-  for (int d = 0; d < 9; ++d) src_of[d] = -1;
+  for (int d = 0; d < 9; ++d) src_of[d] = 0;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int slot = (p.tdy[t] + 1) * 3 + (p.tdx[t] + 1), so = p.tr[t] * 3 + p.ts[t];
 #pragma unroll
     for (int d = 0; d < 9; ++d) src_of[d] = slot == d ? so : src_of[d];
   }
-  bool ident = true;                                          // slot (a, b) <- framework tap (a, b): the forward layout of nn.Conv2d
-#pragma unroll
-  for (int d = 0; d < 9; ++d) ident = ident && src_of[d] == d;
-  const bool w16 = ident && (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (p.D1 & 3) == 0 && p.n_is_dim0;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < nfrag; idx += (long long)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    const long long rest = idx >> 6;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < npairs; idx += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const long long rest = idx >> 9;
     const int nsub = (int)(rest % NS), kc16 = (int)(rest / NS);
-    const int k0 = kc16 * 16 + (lane >> 5) * 8, n = nsub * 32 + (lane & 31);
-    // the eight k share an operand (operands are padded to whole 16-channel chunks on the K axis); `live` of them exist
-    int cc0 = 0, live = 0, kb = 0;
+    const int k = kc16 * 16 + (lane >> 5) * 8 + e, n = nsub * 32 + (lane & 31);
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
+    int cc = -1, kb = 0;
 #pragma unroll
     for (int s = 0; s < DN_MAX_OPERANDS; ++s) {
       if (s < p.n_in) {
-        const int C = p.in[s].C, Cp = (C + WKC - 1) / WKC * WKC;
-        if (k0 >= kb && k0 < kb + Cp) {
-          cc0 = p.in[s].ch_off + (k0 - kb);
-          live = C - (k0 - kb);
-        }
-        kb += Cp;
+        const int C = p.in[s].C;
+        if (k >= kb && k < kb + C) cc = p.in[s].ch_off + (k - kb);
+        kb += (C + WKC - 1) / WKC * WKC;
       }
     }
-    live = n < p.Ntot ? (live > 8 ? 8 : (live < 0 ? 0 : live)) : 0;
-    float t4[8][4][3];
-    float gbuf[72];
-    const bool vec = w16 && live == 8 && (cc0 & 3) == 0;
-    if (vec) {                                               // 72 consecutive floats of one filter row block: 18 aligned 16-byte loads
-      const f32x4* src = reinterpret_cast<const f32x4*>(w + ((long long)n * p.D1 + cc0) * 9);
+    if (n < p.Ntot && cc >= 0) {
+      const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + cc) : ((long long)cc * p.D1 + n)) * 9;
 #pragma unroll
-      for (int q = 0; q < 18; ++q) {
-        const f32x4 v = src[q];
+      for (int aa = 0; aa < 3; ++aa)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) gbuf[4 * q + u] = v[u];
-      }
+        for (int bb = 0; bb < 3; ++bb) g[aa][bb] = w[base + src_of[aa * 3 + bb]];
     }
+    float t4[4][3];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float g[9];
-      if (vec) {
-#pragma unroll
-        for (int d = 0; d < 9; ++d) g[d] = gbuf[9 * e + d];
-      } else {
-        const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + (cc0 + e)) : ((long long)(cc0 + e) * p.D1 + n)) * 9;
-#pragma unroll
-        for (int d = 0; d < 9; ++d) g[d] = (e < live && src_of[d] >= 0) ? w[base + src_of[d]] : 0.f;
-      }
-#pragma unroll
-      for (int bb = 0; bb < 3; ++bb) {
-        const float g0 = g[0 * 3 + bb], g1 = g[1 * 3 + bb], g2 = g[2 * 3 + bb];
-        t4[e][0][bb] = g0;
-        t4[e][1][bb] = 0.5f * (g0 + g1 + g2);
-        t4[e][2][bb] = 0.5f * (g0 - g1 + g2);
-        t4[e][3][bb] = g2;
-      }
+    for (int bb = 0; bb < 3; ++bb) {
+      const float g0 = g[0][bb], g1 = g[1][bb], g2 = g[2][bb];
+      t4[0][bb] = g0;
+      t4[1][bb] = 0.5f * (g0 + g1 + g2);
+      t4[2][bb] = 0.5f * (g0 - g1 + g2);
+      t4[3][bb] = g2;
     }
-    __bf16* dst = wp16 + ((((long long)kc16 * 16 * NS + nsub) * NSPL) * 64 + lane) * 8;
+    __bf16* dst = wp16 + ((((long long)kc16 * 16 * NS + nsub) * NSPL) * 64 + lane) * 8 + e;
     const long long posB = (long long)NS * NSPL * 64 * 8;     // elements between two positions
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      float u[4];
+      u[0] = t4[i][0];
+      u[1] = 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]);
+      u[2] = 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]);
+      u[3] = t4[i][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        bf16x8v out[NSPL];
+        if constexpr (NSPL == 1) {
+          dst[(4 * i + j) * posB] = (__bf16)u[j];
+        } else {
+          __bf16 pc[3];
+          wino_split3(u[j], pc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float a0 = t4[e][i][0], a1 = t4[e][i][1], a2 = t4[e][i][2];
-          const float u = j == 0 ? a0 : (j == 1 ? 0.5f * (a0 + a1 + a2) : (j == 2 ? 0.5f * (a0 - a1 + a2) : a2));
-          if constexpr (NSPL == 1) {
-            out[0][e] = (__bf16)u;
-          } else {
-            __bf16 pc[3];
-            wino_split3(u, pc);
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) out[sp][e] = pc[sp];
-          }
+          for (int sp = 0; sp < 3; ++sp) dst[(4 * i + j) * posB + sp * 512] = pc[sp];
         }
-#pragma unroll
-        for (int sp = 0; sp < NSPL; ++sp) *reinterpret_cast<bf16x8v*>(dst + (4 * i + j) * posB + sp * 512) = out[sp];
       }
     }
   }
@@ -314,7 +286,7 @@ int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, int piec
 
 int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, int pieces, hipStream_t stream) {
   const long long total = wino_packed_elems(p);              // (n, k) pairs x 16 positions, as for the fp32 layout
-  int blocks = (int)(((total >> 7) + 255) / 256);           // one thread per 16-byte fragment (eight k of one n)
+  int blocks = (int)(((total >> 4) + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   if (pieces == 3) DN_LAUNCH(wino_pack16_kernel<3>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
   else DN_LAUNCH(wino_pack16_kernel<1>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);

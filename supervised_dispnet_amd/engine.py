@@ -1024,7 +1024,7 @@ def bn_backward(y, bn, sink, training):
                  y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn, dgamma.data_ptr(),
                  dbeta.data_ptr(), _stream())
     else:
-        hbm_call("dn::bn_bwd_apply_kernel", y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
+        hbm_call(None, y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
                  y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride,
                  y.partial_offset, y.rows, Cn, dgamma.data_ptr(), dbeta.data_ptr(), _stream())
     sink.put(bn.weight, dgamma)

@@ -84,6 +84,10 @@ class Communicator(object):
             _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
             self.stream = torch.cuda.Stream(device=self.device)
         self._events = []
+        # bench.py --comm-standin (a PROJECTION of the HBM side of a ring all-reduce on the one-GPU pool): round trips of every reduced
+        # range through a scratch buffer on the communicator's stream, behind its ncclAllReduce.  0 = off (always, outside that flag).
+        self.standin_round_trips = 0
+        self._standin_scratch = None
 
     def all_reduce_sum_(self, tensor, producers):
         """In-place fp32 sum over the ranks on the communicator's stream, after everything enqueued so far on each stream of
@@ -96,6 +100,13 @@ class Communicator(object):
             self.stream.wait_event(ev)
         _check(load().ncclAllReduce(tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), ncclFloat32, ncclSum, self.comm,
                                     self.stream.cuda_stream), "ncclAllReduce")
+        if self.standin_round_trips > 0 and tensor.numel() % 4 == 0 and tensor.data_ptr() % 16 == 0:
+            from . import _lib as dn
+            if self._standin_scratch is None or self._standin_scratch.numel() < tensor.numel():
+                self._standin_scratch = torch.empty(tensor.numel(), dtype=torch.float32, device=self.device)
+            for _ in range(self.standin_round_trips):
+                dn.call("dn_ubench_copy", tensor.data_ptr(), self._standin_scratch.data_ptr(), tensor.numel(), self.stream.cuda_stream)
+                dn.call("dn_ubench_copy", self._standin_scratch.data_ptr(), tensor.data_ptr(), tensor.numel(), self.stream.cuda_stream)
 
     def join(self, stream=None):
         """Make `stream` (default: the current one) wait for every collective enqueued so far."""

@@ -138,8 +138,11 @@ def test_train_cli_legacy_align_corners_changes_only_the_warp_sampling(tmp_path)
     v0, _, _ = _run_train(tmp_path / "a", common, epochs=1)
     v1, _, _ = _run_train(tmp_path / "b", common + ["--legacy-align-corners"], epochs=1)
     assert v0.shape == v1.shape and np.isfinite(v1).all()
-    assert abs(v0[0, 1] - v1[0, 1]) > 1e-6 * abs(v0[0, 1])                    # the photometric term moved ...
-    assert abs(v0[0, 1] - v1[0, 1]) < 0.2 * abs(v0[0, 1])                     # ... by a resampling, not by garbage
+    # The synthetic frames are the target + 5 % noise and the untrained pose net predicts ~zero motion, so the warp is (almost) the
+    # identity: with align_corners=True the reference's pixel grid 2 X / (w - 1) - 1 (inverse_warp.py:62-68) lands exactly ON the
+    # source pixels and the photometric term is the noise level; with today's default (False) every sample falls between pixels of a
+    # noise image and the term is about twice that.  So the flag must LOWER the first step's photometric loss, by a lot.
+    assert v1[0, 1] < 0.8 * v0[0, 1], (v0[0, 1], v1[0, 1])
     np.testing.assert_allclose(v0[0, 3], v1[0, 3], rtol=1e-6)                 # first step: same net, same smoothness value
     assert engine.compute_mode() == "f32x3"
 
