@@ -142,7 +142,7 @@ __device__ __forceinline__ AGroup gather4(const KOperand& S, int kl, int ntaps, 
   return r;
 }
 
-// p.tile_store: 0 = never, 1 = dense un-phased results only (the round-2 rule, DN_TILE_STORE_LINEAR_ONLY), 2 = every pixel-dense result
+// p.tile_store: 0 = never, 1 = dense un-phased results only (the round-2 rule), 2 = every pixel-dense result
 // (run_conv requires pixel-dense results; the tile path addresses pixels through rowpix[], which is phase-aware)
 __device__ __forceinline__ bool knobs_dev_linear_only(const IgemmParams& p) { return p.tile_store == 1; }
 
@@ -1548,7 +1548,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const IgemmParams p) {
 }
 
 static bool stem_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  if (knobs().no_stem) return false;
+  if (false) return false;
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (p.n_in != 1 || p.n_out != 1 || p.Ntot != 64 || p.nphases != 1) return false;
   const KOperand& o = p.in[0];
@@ -2151,7 +2151,7 @@ static int enable_big_lds(K kernel, size_t bytes) {
 template <int BM, int BN, int WM, int WN, bool ALLVEC>
 static int launch_conv_v(const IgemmParams& p, hipStream_t stream) {
   size_t lds = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + (kMaxTaps + BM) * sizeof(int);
-  lds += (size_t)knobs().extra_lds;   // tuning aid: lowers blocks per CU
+  lds += (size_t)0;   // tuning aid: lowers blocks per CU
   auto kernel = igemm_conv_kernel<BM, BN, WM, WN, ALLVEC>;
   int rc = enable_big_lds(kernel, lds);
   if (rc != DN_OK) return rc;
@@ -2181,7 +2181,7 @@ static int x3_splitk_choice(const IgemmParams& p, int tiles) {
   const KOperand& S = p.in[0];
   if (!(S.vec && S.small && S.up == 0 && (S.C % 32 == 0 || S.C == 4 || S.C == 8 || S.C == 16))) return 1;   // the scheduled loaders only
   const int blocks = tiles * p.nphases;
-  if (blocks > knobs().x3_splitk_maxblocks || blocks > (int)(kX3SplitKCounterBytes / sizeof(int))) return 1;
+  if (blocks > 208 || blocks > (int)(kX3SplitKCounterBytes / sizeof(int))) return 1;
   int nch = 1 << 30;                               // fewest chunks of a (non-empty) phase
   for (int z = 0; z < p.nphases; ++z) {
     const int nt = p.ph[z].ntaps;
@@ -2190,8 +2190,8 @@ static int x3_splitk_choice(const IgemmParams& p, int tiles) {
     if (c < nch) nch = c;
   }
   if (nch == (1 << 30)) return 1;
-  int ks = knobs().x3_splitk_target / blocks;
-  if (ks > nch / knobs().x3_splitk_minch) ks = nch / knobs().x3_splitk_minch;
+  int ks = 512 / blocks;
+  if (ks > nch / 8) ks = nch / 8;
   if (ks > 16) ks = 16;
   return ks < 2 ? 1 : ks;
 }
@@ -2259,7 +2259,7 @@ static int launch_conv_x3b(const IgemmParams& p, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const IgemmParams& p, hipStream_t stream) {
-  if (p.uni32 && !knobs().no_u32)
+  if (p.uni32 && !false)
     return launch_conv_u32<BM, BN, WM, WN>(p, stream);
   return p.allvec ? launch_conv_v<BM, BN, WM, WN, true>(p, stream) : launch_conv_v<BM, BN, WM, WN, false>(p, stream);
 }
@@ -2295,8 +2295,8 @@ static int run_conv(const dn_conv_desc* d, int expect_kind, dn_stream_t stream) 
   // 64-row tiles double the block count at the same per-wave MFMA density along N.  Not with batch statistics: the
   // bn_partial layout is per 128-row tile.
   const long long blocks128 = (long long)((p.M + 127) / 128) * (p.Npad / p.BN) * p.nphases;
-  const bool small_m = p.uni32 && p.bn_partial == nullptr && blocks128 <= 208 && !knobs().no_bm64;
-  if (p.compute == DN_COMPUTE_F32X3 && p.uni32 && !knobs().no_u32 && !knobs().no_x3_direct && (p.BN >= 64 || knobs().x3_bn32)) {
+  const bool small_m = p.uni32 && p.bn_partial == nullptr && blocks128 <= 208 && !false;
+  if (p.compute == DN_COMPUTE_F32X3 && p.uni32 && !false && !knobs().no_x3_direct && (p.BN >= 64 || false)) {
     // (the 32-wide N tile -- one 32 x 32 tile per wave, 12 matrix instructions per chunk against five split-and-store items -- measured
     //  4-17 % slower than the fp32 instruction: it stays on that)
     // fp32 products on the bf16 matrix cores (wave tiles of at most 2 x 32 x 32: the 128-wide N tile runs as 64-row blocks)
@@ -2341,7 +2341,7 @@ static int launch_wgrad_u32(const IgemmParams& p, hipStream_t stream) {
 
 template <int BNW, int WNn, int WKk>
 static int launch_wgrad(const IgemmParams& p, hipStream_t stream) {
-  if (p.wg_uniform && !knobs().no_u32)
+  if (p.wg_uniform && !false)
     return p.any_affine ? launch_wgrad_u32<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_u32<BNW, WNn, WKk, false>(p, stream);
   return p.allvec ? launch_wgrad_v<BNW, WNn, WKk, true>(p, stream) : launch_wgrad_v<BNW, WNn, WKk, false>(p, stream);
 }
@@ -2445,7 +2445,7 @@ static int generic_wgrad(const dn_conv_desc* fwd, IgemmParams& p, const float* d
 // the one trailing channel (9 columns of dw).  iconv2 at 32 images: 0.272 -> 0.15 ms; config 4's 321 -> 64 @120x160: 1.25 -> 0.5 ms.
 static bool wgrad_split_plans(const dn_conv_desc* fwd, dn_conv_desc* d1, dn_conv_desc* d2, IgemmParams* p1, IgemmParams* p2, size_t* w1,
                               size_t* w2) {
-  if (knobs().no_wgrad_split || fwd->kind != DN_CONV_FWD || fwd->n_in < 2 || fwd->in[fwd->n_in - 1].C != 1) return false;
+  if (false || fwd->kind != DN_CONV_FWD || fwd->n_in < 2 || fwd->in[fwd->n_in - 1].C != 1) return false;
   *d1 = *fwd;
   d1->n_in = fwd->n_in - 1;
   *d2 = *fwd;

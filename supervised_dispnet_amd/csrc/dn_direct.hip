@@ -382,7 +382,7 @@ bool head_fwd_eligible(const dn_conv_desc* d, const IgemmParams& p) {
 
 // the r02 kernels: 3x3 taps within +-1, stride 1, 16-aligned channels
 static bool head2_geometry(const IgemmParams& p, int C) {
-  if (knobs().no_head2 || p.ph[0].ntaps != 9 || C % 16 != 0 || C > 16 * kH2MaxCG || p.sy != 1 || p.sx != 1) return false;
+  if (false || p.ph[0].ntaps != 9 || C % 16 != 0 || C > 16 * kH2MaxCG || p.sy != 1 || p.sx != 1) return false;
   for (int j = 0; j < 9; ++j)
     if (p.tdy[j] < -1 || p.tdy[j] > 1 || p.tdx[j] < -1 || p.tdx[j] > 1) return false;
   return true;

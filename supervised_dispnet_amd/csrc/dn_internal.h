@@ -38,31 +38,20 @@ static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_
 // Tuning / test switches (DN_* environment variables), read ONCE and again only on dn_reload_knobs(): the conv entry points
 // consult a dozen of them per launch.
 struct Knobs {
-  bool no_winograd, no_winograd_wgrad, no_direct, no_stem, no_u32, no_bm64, no_thin, no_thin_conv, no_tile_store, no_splitk, no_head2;
-  int extra_lds;            // DN_DEBUG_EXTRA_LDS: bytes added to the tiled kernels' LDS request (lowers blocks per CU)
-  int wino_wgw;                          // DN_WINO_WGW: 0 = keep the 64 x 64 x 16-position weight-gradient block where 128 x 64 x 8 would run
-  int wino_dbg, wino_mtw, wino_wg_dbg;   // DN_WINO_DBG / DN_WINO_MTW / DN_WINO_WG_DBG: ablation variants (tools/wino_timing.py)
-  unsigned long long wino_dbgptr;
-  int lds3_dbg;                          // DN_LDS3_DBG: phase timestamps of the LDS-resident kernels into DN_WINO_DBGPTR (tools/lds3_timing.py)
-  int wino_min_tiles;       // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (default 192)
-  bool no_x3_direct;        // DN_NO_X3_DIRECT: keep the fp32 matrix instruction in the direct (implicit-GEMM) forward family under DN_COMPUTE_F32X3
-  int wino_splitk_target, wino_splitk_minch;   // DN_WINO_SPLITK_TARGET (256 blocks), DN_WINO_SPLITK_MINCH (8 chunks per block)
-  int wino_splitk_maxblocks;                   // DN_WINO_SPLITK_MAXBLOCKS: 32-tile x 64-channel blocks at or below which the split is considered
-  bool no_wino_splitk;      // DN_NO_WINO_SPLITK: no input-channel split of small Winograd grids
-  int reduce_rows_per_thread, reduce_max_blocks;   // DN_REDUCE_ROWS_PER_THREAD (2), DN_REDUCE_MAX_BLOCKS (1024): grid of the two-stage column reductions
-  bool no_wino8_tail;       // DN_NO_WINO8_TAIL: no K split of the last partial round of the 8-wave Winograd kernel
-  int wino8_tail_max, wino8_tail_minch;   // DN_WINO8_TAIL_MAX (64 tiles), DN_WINO8_TAIL_MINCH (8 chunks per split)
-  bool x3_bn32;             // DN_X3_BN32: three-piece direct kernel also for 32-wide N tiles (measured slower; A/B)
-  bool no_wgrad_split;      // DN_NO_WGRAD_SPLIT: no Winograd + tiled split of a weight gradient with a trailing 1-channel piece
-  bool tile_store_linear_only;   // DN_TILE_STORE_LINEAR_ONLY: whole-pixel tile stores for dense un-phased results only (A/B)
-  bool no_bn_hoist;         // DN_NO_BN_HOIST: the plain BatchNorm-backward apply kernel (A/B)
-  bool no_x3_splitk;        // DN_NO_X3_SPLITK: no K split of small grids in the three-piece direct kernel
-  int x3_splitk_target, x3_splitk_minch, x3_splitk_maxblocks;   // DN_X3_SPLITK_TARGET (512 blocks) / _MINCH (8 chunks per block) / _MAXBLOCKS (208)
-  bool no_bn_sums_fusion;   // DN_NO_BN_SUMS_FUSION: dn_conv_dgrad_fuses_bn_sums() answers 0 (the engine then runs the separate sums pass)
-  int pack_blocks;          // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
-  int wino_min_n, wino_pad_pct;   // DN_WINO_MIN_N (64): fewest output channels of a Winograd layer; DN_WINO_PAD_PCT (60): least live share of its padded tile x channel grid
-  bool no_lds3, no_lds3_wgrad, no_stem3, no_x3_wgrad, no_tap_windows;   // DN_NO_LDS3 / DN_NO_LDS3_WGRAD / DN_NO_STEM3 / DN_NO_X3_WGRAD / DN_NO_TAP_WINDOWS (round 4 kernels, A/B)
-  int wino8, wino8_min_k;   // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel; DN_WINO8_MIN_K: its rule's channel floor
+  bool no_winograd, no_winograd_wgrad;   // DN_NO_WINOGRAD / DN_NO_WINOGRAD_WGRAD: the tiled kernels take the 3x3 / stride 1 layers (tests compare the two)
+  bool no_direct;                        // DN_NO_DIRECT: no one-channel head kernels
+  bool no_thin, no_thin_conv;            // DN_NO_THIN / DN_NO_THIN_CONV: the thin full-resolution layers on the tiled kernels (tests compare the three forms)
+  bool no_lds3;                          // DN_NO_LDS3: no LDS-resident family (dn_lds3*.hip, dn_stemk.hip, stem3)
+  bool no_splitk, no_wino_splitk, no_x3_splitk, no_wino8_tail;   // DN_NO_SPLITK / DN_NO_WINO_SPLITK / DN_NO_X3_SPLITK / DN_NO_WINO8_TAIL: K splits of small grids off
+  bool no_x3_direct, no_x3_wgrad;        // DN_NO_X3_DIRECT / DN_NO_X3_WGRAD: the fp32 matrix instruction in the direct forward family / tiled weight gradient
+  bool no_tap_windows;                   // DN_NO_TAP_WINDOWS: > 32-tap weight gradients on the unscheduled kernel
+  int wino_wgw;                          // DN_WINO_WGW: 0 = keep the 64 x 64 x 16-position weight-gradient block where 128 x 64 x 8 would run (bitwise test)
+  int wino_dbg, wino_wg_dbg, lds3_dbg;   // DN_WINO_DBG / DN_WINO_WG_DBG / DN_LDS3_DBG: timing / ablation instantiations (tools/wino_timing.py, tools/lds3_timing.py)
+  unsigned long long wino_dbgptr;        // DN_WINO_DBGPTR: where they write their time stamps
+  int wino_min_tiles;                    // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (192)
+  int wino_splitk_target, wino_splitk_maxblocks;   // DN_WINO_SPLITK_TARGET (512 blocks) / _MAXBLOCKS (208): the 4-wave kernel's K split of small grids
+  int pack_blocks;                       // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
+  int wino8;                             // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel
 };
 const Knobs& knobs();
 
@@ -141,7 +130,7 @@ struct IgemmParams {
   int any_affine;                // some operand carries a pending BN-apply + ReLU
   int reflect;                   // gather with ReflectionPad2d index mapping instead of zero fill
   int compute;                   // DN_COMPUTE_F32 / _BF16 / _F32X3 (descriptor field; honoured by the Winograd forward / input gradient)
-  int tile_store;                // epilogue may stage the result tile in LDS and store whole pixels (off: DN_NO_TILE_STORE)
+  int tile_store;                // epilogue may stage the result tile in LDS and store whole pixels
   // Winograd F(2x2,3x3) launches only (dn_winograd.hip)
   // BatchNorm-backward column sums of the producer, taken in the input gradient's epilogue (dn_conv_desc.bnb_*; Winograd kernels only)
   const float *bnb_y, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;

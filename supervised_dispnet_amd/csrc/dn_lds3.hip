@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256, 2) stem3_conv_kernel(const IgemmParams p,
 }
 
 static bool stem3_eligible(const dn_conv_desc* d, const IgemmParams& p) {
-  if (knobs().no_stem3 || p.compute != DN_COMPUTE_F32X3) return false;
+  if (knobs().no_lds3 || p.compute != DN_COMPUTE_F32X3) return false;
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (p.n_in != 1 || p.n_out != 1 || p.Ntot != 64 || p.nphases != 1) return false;
   const KOperand& o = p.in[0];

@@ -84,20 +84,10 @@ static void read_knobs(Knobs* k) {
   k->no_winograd = on("DN_NO_WINOGRAD");
   k->no_winograd_wgrad = on("DN_NO_WINOGRAD_WGRAD");
   k->no_direct = on("DN_NO_DIRECT");
-  k->no_stem = false;
-  k->no_u32 = false;
-  k->no_bm64 = false;
   k->no_thin = on("DN_NO_THIN");
   k->no_thin_conv = on("DN_NO_THIN_CONV");
-  k->no_tile_store = false;
-  k->tile_store_linear_only = false;
-  k->no_wgrad_split = false;
-  k->x3_bn32 = false;
   k->no_splitk = on("DN_NO_SPLITK");
-  k->no_head2 = false;
-  k->extra_lds = 0;
   k->wino_dbg = num("DN_WINO_DBG", 0);
-  k->wino_mtw = 1;
   k->wino_wg_dbg = num("DN_WINO_WG_DBG", 0);
   k->wino_wgw = num("DN_WINO_WGW", 1);
   k->lds3_dbg = num("DN_LDS3_DBG", 0);
@@ -106,35 +96,15 @@ static void read_knobs(Knobs* k) {
   k->no_x3_direct = on("DN_NO_X3_DIRECT");
   k->no_wino_splitk = on("DN_NO_WINO_SPLITK");
   k->wino_splitk_target = num("DN_WINO_SPLITK_TARGET", 512);   // (r05: 256 -> 512 and 128 -> 208 blocks: the 208-block layers of a 4-image shard take two co-resident half-K blocks per CU; b4 3.83 -> 3.74 ms, b8 5.50 -> 5.45, profiles/r05_exp2.txt)
-  k->wino_splitk_minch = 8;
   k->wino_splitk_maxblocks = num("DN_WINO_SPLITK_MAXBLOCKS", 208);
-  if (k->wino_splitk_minch < 1) k->wino_splitk_minch = 1;
-  k->reduce_rows_per_thread = 2;
-  if (k->reduce_rows_per_thread < 1) k->reduce_rows_per_thread = 1;
-  k->reduce_max_blocks = 1024;
-  if (k->reduce_max_blocks < 1) k->reduce_max_blocks = 1;
   k->no_wino8_tail = on("DN_NO_WINO8_TAIL");
-  k->wino8_tail_max = 64;
-  k->wino8_tail_minch = 8;
-  if (k->wino8_tail_minch < 1) k->wino8_tail_minch = 1;
-  k->no_bn_hoist = false;
   k->no_x3_splitk = on("DN_NO_X3_SPLITK");
-  k->x3_splitk_target = 512;
-  k->x3_splitk_minch = 8;
-  if (k->x3_splitk_minch < 1) k->x3_splitk_minch = 1;
-  k->x3_splitk_maxblocks = 208;
-  k->no_bn_sums_fusion = false;
   k->pack_blocks = num("DN_PACK_BLOCKS", 512);
   if (k->pack_blocks < 1) k->pack_blocks = 1;
-  k->wino_min_n = 64;
-  k->wino_pad_pct = 60;
   k->no_lds3 = on("DN_NO_LDS3");
-  k->no_lds3_wgrad = on("DN_NO_LDS3");
-  k->no_stem3 = on("DN_NO_LDS3");
   k->no_x3_wgrad = on("DN_NO_X3_WGRAD");
   k->no_tap_windows = on("DN_NO_TAP_WINDOWS");
   k->wino8 = num("DN_WINO8", -1);
-  k->wino8_min_k = 128;
 }
 
 const Knobs& knobs() {
@@ -367,7 +337,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
     if (!o.small || (!o.vec && o.scale != nullptr) || o.C >= 32768) p->wg_uniform = 0;
   }
   (void)n_uniform;
-  p->tile_store = knobs().no_tile_store ? 0 : (knobs().tile_store_linear_only ? 1 : 2);
+  p->tile_store = false ? 0 : (false ? 1 : 2);
   p->compute = (d->compute == DN_COMPUTE_BF16 || d->compute == DN_COMPUTE_F32X3) ? d->compute : DN_COMPUTE_F32;
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
@@ -441,7 +411,7 @@ int32_t dn_conv_fwd_fuses_reciprocal(const dn_conv_desc* d) {
 int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d) {
   dn::IgemmParams p;
   if (d == nullptr || dn::build_plan(d, false, &p) != DN_OK) return -1;
-  if (d->kind != DN_CONV_DGRAD || dn::knobs().no_bn_sums_fusion) return 0;
+  if (d->kind != DN_CONV_DGRAD || false) return 0;
   if (dn::wino_layout(d, p) == 0) return 0;
   const dn_result& r = d->out[0];
   const bool dense = d->n_out == 1 && !r.accumulate && (r.C & 3) == 0 && r.stride_w == r.C && r.stride_h == (int64_t)d->OW * r.C &&

@@ -24,9 +24,9 @@ static inline int reduce_blocks(long long rows, int C) {
   int tpr = 1;
   while (tpr < groups && tpr < kThreads) tpr <<= 1;
   int rpi = kThreads / tpr;
-  const int rpt = knobs().reduce_rows_per_thread;        // rows each thread walks (DN_REDUCE_ROWS_PER_THREAD, default 2: 8 left a 4-image shard 416 blocks of 8 dependent row visits each)
+  const int rpt = 2;        // rows each thread walks (2: 8 left a 4-image shard 416 blocks of 8 dependent row visits each)
   long long b = (rows + (long long)rpi * rpt - 1) / ((long long)rpi * rpt);
-  const int cap = knobs().reduce_max_blocks < kMaxReduceBlocks ? knobs().reduce_max_blocks : kMaxReduceBlocks;
+  const int cap = 1024 < kMaxReduceBlocks ? 1024 : kMaxReduceBlocks;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
@@ -1062,7 +1062,7 @@ int dn_bn_bwd_apply_relu(float* da_dy, const float* y, const float* scale, const
   hipStream_t s = as_stream(stream);
   int rc = bn_bwd_sums_to_params(partial, partial_rows, partial_stride, partial_offset, C, dgamma, dbeta, s, "dn_bn_bwd_apply_relu");
   if (rc != DN_OK) return rc;
-  const bool hoisted = C % 4 == 0 && kThreads % (C / 4) == 0 && !knobs().no_bn_hoist;
+  const bool hoisted = C % 4 == 0 && kThreads % (C / 4) == 0 && !false;
   set_last_kernel(hoisted ? "dn::bn_bwd_apply_relu_hoisted_kernel" : "dn::bn_bwd_apply_relu_kernel");
   if (hoisted)
     DN_LAUNCH(bn_bwd_apply_relu_hoisted_kernel, dim3(ew_blocks((rows * (C / 4) + 3) / 4)), dim3(kThreads), 0, s, da_dy, y, scale, shift, mean,

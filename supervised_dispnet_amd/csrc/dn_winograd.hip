@@ -15,7 +15,7 @@
 // = 16 independent GEMMs  M_p[tile][cout] = sum_c V_p[tile][c] * U_p[c][cout],  p = 4i + j the position in the 4x4 transform
 // domain.  One block: 32 tiles (= 128 output pixels) x 64 output channels x all 16 positions, 4 waves, TWO blocks per CU:
 // wave w owns the four positions of transform row i = w, i.e. 4 x (32x64) accumulators = 128 registers next to at most 128
-// others (the 64-tile / 256-accumulator / one-block-per-CU variant is kept for comparison, DN_WINO_MTW=2).
+// others (the 64-tile / 256-accumulator / one-block-per-CU variant is kept for comparison; not dispatched since round 5).
 //   A side : each thread gathers one 4x4 patch of 2 (4) channels straight from the NHWC operands (virtual concat, pending
 //            BatchNorm-apply + ReLU of the producer, zero halo by the buffer bounds check), transforms it in registers and
 //            writes the 16 transformed values into LDS planes [position][k half][tile][4], padded so that both the stores and
@@ -46,13 +46,13 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p) {
   if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return false;
   if (d->IH != d->OH || d->IW != d->OW || (d->OH & 1) || (d->OW & 1)) return false;
   if (p.nphases != 1 || p.ph[0].ntaps != 9) return false;
-  if (p.Ntot < knobs().wino_min_n) return false;
+  if (p.Ntot < 64) return false;
   if ((long long)p.M * 4 >= (1ll << 31)) return false;
   {
     // a block always computes 64 tiles x 64 output channels: not worth it (and not better than the direct kernel's 64-row tiles)
     // when padding eats the 2.25x, e.g. the 12-tile deep layers of a 64x96 test image
     const long long T = p.M / 4, Tpad = (T + 31) / 32 * 32, Npad = (p.Ntot + WBN - 1) / WBN * WBN;
-    if (T * p.Ntot * 100 < Tpad * Npad * knobs().wino_pad_pct) return false;
+    if (T * p.Ntot * 100 < Tpad * Npad * 60) return false;
     // Few tiles: F(2x2,3x3) rounds 2-3x coarser than the direct FMA chain (tests/test_gpu_kernels.py::test_winograd_error_vs_fp64),
     // which the BatchNorm of a tiny map (batch statistics over a few dozen values) amplifies: such maps keep the direct kernel.
     // The floor is 192 tiles so that the 8x26 levels of a 4-image shard (208 tiles: BASELINE's b32 split over 8 GPUs) stay on
@@ -90,7 +90,7 @@ int wino_splitk_choice(const IgemmParams& p) {
   const int blocks = ((T + 31) / 32) * (wino_npad(p) / WBN), chunks = wino_ktot(p) / WKC;
   if (blocks > knobs().wino_splitk_maxblocks || blocks > (int)(kSplitKCounterBytes / sizeof(int))) return 1;
   int ks = knobs().wino_splitk_target / blocks;  // aim at two blocks per CU ...
-  if (ks > chunks / knobs().wino_splitk_minch) ks = chunks / knobs().wino_splitk_minch;   // ... of at least eight chunks each
+  if (ks > chunks / 8) ks = chunks / 8;   // ... of at least eight chunks each
   if (ks > 8) ks = 8;
   return ks < 2 ? 1 : ks;
 }
@@ -299,7 +299,7 @@ int wino_layout(const dn_conv_desc* d, const IgemmParams& p) {
   if (!wino_eligible(d, p)) return 0;
   if (knobs().wino_dbg != 0 && knobs().wino_dbg != 4 && knobs().wino_dbg < 16) return 1;
   if (p.compute == DN_COMPUTE_F32X3) return 3;          // (either tile height)
-  if (knobs().wino_mtw != 1) return 1;
+  if (1 != 1) return 1;
   return p.compute == DN_COMPUTE_BF16 ? 2 : 1;
 }
 
@@ -1096,13 +1096,13 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.TW = p.OW / 2;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
-  const int dbg = knobs().wino_dbg, mtw = knobs().wino_mtw;
+  const int dbg = knobs().wino_dbg;
   if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variants may be used)
     return p.any_affine ? launch_wino_variant<1, true, 0, 1>(p, stream) : launch_wino_variant<1, false, 0, 1>(p, stream);
   p.ksplit = 1;
   if (p.compute == DN_COMPUTE_F32X3) {
-    if ((knobs().wino_dbg == 0 || (knobs().wino_dbg & 4)) && mtw == 1 && wino8_wanted(p)) return launch_wino_conv8(p, stream);
-    if (knobs().wino_dbg == 0 && mtw == 1) {
+    if ((knobs().wino_dbg == 0 || (knobs().wino_dbg & 4)) && wino8_wanted(p)) return launch_wino_conv8(p, stream);
+    if (knobs().wino_dbg == 0) {
       // few blocks, long K: split the input channels.  Needs the caller's workspace (dn_conv_desc.splitk_ws)
       const int ks = wino_splitk_choice(p);
       if (ks > 1 && p.ks_ws != nullptr && p.ks_ws_bytes >= wino_splitk_workspace_bytes(p)) {
@@ -1113,9 +1113,7 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
     }
     // (the 64-tile / one-block-per-CU form of this variant -- the loop below is written for either tile height -- moves 37 % fewer bytes
     //  through the texture addresser, the weight pieces being fetched once per 64 tiles, and was measured 5-10 % SLOWER on every layer
-    //  but one: a single wave per SIMD stalls on every wait; DN_WINO_MTW=3 selects it for such measurements)
-    if (knobs().wino_dbg == 0 && mtw == 3)
-      return p.any_affine ? launch_wino_variant<2, true, 0, 3>(p, stream) : launch_wino_variant<2, false, 0, 3>(p, stream);
+    //  but one: a single wave per SIMD stalls on every wait)
     if (knobs().wino_dbg == 4) {           // in-kernel timestamps (tools/wino_timing.py)
       p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
       return p.any_affine ? launch_wino_variant<1, true, 4, 3>(p, stream) : launch_wino_variant<1, false, 4, 3>(p, stream);
@@ -1135,11 +1133,9 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   }
   if (dbg == 4) {
     p.ws = reinterpret_cast<float*>(knobs().wino_dbgptr);
-    if (mtw == 1) return p.any_affine ? launch_wino_variant<1, true, 4>(p, stream) : launch_wino_variant<1, false, 4>(p, stream);
-    return p.any_affine ? launch_wino_variant<2, true, 4>(p, stream) : launch_wino_variant<2, false, 4>(p, stream);
+    return p.any_affine ? launch_wino_variant<1, true, 4>(p, stream) : launch_wino_variant<1, false, 4>(p, stream);
   }
-  if (mtw == 1) return p.any_affine ? launch_wino_variant<1, true, 0>(p, stream) : launch_wino_variant<1, false, 0>(p, stream);
-  return p.any_affine ? launch_wino_variant<2, true, 0>(p, stream) : launch_wino_variant<2, false, 0>(p, stream);
+  return p.any_affine ? launch_wino_variant<1, true, 0>(p, stream) : launch_wino_variant<1, false, 0>(p, stream);
 }
 
 }  // namespace dn

@@ -644,13 +644,13 @@ static int launch_wino8_variant(const IgemmParams& p, hipStream_t stream) {
     int chunks = 0;
     for (int i = 0; i < p.n_in; ++i) chunks += (p.in[i].C + WKC - 1) / WKC;
     int ks = tail > 0 ? cus / tail : 1;
-    if (ks > chunks / knobs().wino8_tail_minch) ks = chunks / knobs().wino8_tail_minch;
+    if (ks > chunks / 8) ks = chunks / 8;
     if (ks > 8) ks = 8;
     const size_t need = 4096 + (size_t)tail * ks * 32 * 512 * 16;
     // (measured at 32 images, tools/conv_microbench.py: 512 -> 512 @16x52 = 832 blocks = 3 rounds + 64: forward 0.428 -> 0.413 ms, input
     //  gradient 0.395 -> 0.371; 256 -> 256 @32x104 = 6 rounds + 128: +3..5 % SLOWER -- the rounds are not in lock step, so the partial
     //  round costs less than a round, and 128 tiles x 2 x 256 KB of partial accumulators cost more than it: few rounds, small tails only)
-    if (reg > 0 && reg <= 3 * cus && tail > 0 && tail % 8 == 0 && tail <= knobs().wino8_tail_max && ks >= 2 && p.ks_ws_bytes >= need) {
+    if (reg > 0 && reg <= 3 * cus && tail > 0 && tail % 8 == 0 && tail <= 64 && ks >= 2 && p.ks_ws_bytes >= need) {
       q.ksplit = ks;
       q.ks_chunks = chunks;
       q.ks_cnt_floats = 4096 / 4;
@@ -680,7 +680,7 @@ bool wino8_wanted(const IgemmParams& p) {
   // (round 5 measured a FULL split for grids below 192 blocks -- every 64-tile block split 2-8 ways along K, ks_reg = 0: 256 KB of partial
   //  accumulators per split block against the 4-wave kernel's 32 KB of transformed partial tiles; 512 -> 512 @16x52 with 4 images 0.084 ->
   //  0.082 ms, @8x26 0.044 -> 0.055, the 4-image step 3.78 -> 3.89 ms: dropped, profiles/r05_exp1.txt)
-  return k >= knobs().wino8_min_k && blocks >= 192;
+  return k >= 128 && blocks >= 192;
 }
 
 int launch_wino_conv8(const IgemmParams& p, hipStream_t stream) {
