@@ -151,6 +151,28 @@ typedef struct dn_conv_desc {
    * returns 1 the head kernel that writes disp = alpha * sigmoid(conv) + beta also writes 1 / disp here (dense [N][OH][OW] floats, the
    * same IEEE division dn_reciprocal_fwd performs), so the caller's reciprocal needs no launch.  Otherwise ignored; NULL: not wanted. */
   float* recip_out;
+  /* Optional (round 5), DN_CONV_FWD with bn_partial: finish the BatchNorm batch statistics INSIDE this launch.  The block that arrives
+   * last for a 64-channel slice of the result merges the slice's bn_partial rows and writes what dn_bn_finalize would have written
+   * (mean, invstd, the folded (scale, shift), the running statistics, the step counter) -- same arithmetic, same order, same bits
+   * (dn_bn_finalize takes the same sliced order for up to 128 partial rows); the conv bias is this descriptor's `bias`.  Honoured only
+   * where dn_conv_fwd_folds_bn_finalize(desc) returns 1 (three-piece Winograd kernels, <= 128 partial rows, a splitk_ws whose last 256
+   * bytes serve as self-resetting counters); otherwise ignored and the caller runs dn_bn_finalize.  bnf_scale == NULL: not wanted. */
+  const float* bnf_gamma;
+  const float* bnf_beta;
+  float* bnf_running_mean;         /* may be NULL together with bnf_running_var (untracked statistics) */
+  float* bnf_running_var;
+  int64_t* bnf_num_batches_tracked;   /* may be NULL */
+  float bnf_momentum, bnf_eps;
+  float* bnf_mean;
+  float* bnf_invstd;
+  float* bnf_scale;
+  float* bnf_shift;
+  /* Optional (round 5), DN_CONV_DGRAD with bnb_*: also FINISH the two BatchNorm-backward sums of the layer below inside this launch:
+   * bnb_dbeta[c] = sum dz, bnb_dgamma[c] = sum dz * xhat -- the parameter gradients dn_bn_bwd_apply_relu derives from bnb_partial with a
+   * launch of its own (pass partial = NULL there: the sums are final).  Same sliced order as that launch for <= 128 rows.  Honoured
+   * only where dn_conv_dgrad_folds_bn_sums(desc) returns 1. */
+  float* bnb_dgamma;
+  float* bnb_dbeta;
 } dn_conv_desc;
 
 enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2 };
@@ -182,6 +204,10 @@ int32_t dn_conv_bn_partial_rows(const dn_conv_desc* d);
  * split: the three-piece Winograd forward / input gradient (input channels) and the three-piece direct kernel with one scheduled operand
  * (chunks of the K axis: the 4x13 / 8x26 transposed convolutions of the decoder). */
 int64_t dn_conv_splitk_workspace_bytes(const dn_conv_desc* d);
+/* 1 when dn_conv2d_fwd(desc) will finish the BatchNorm statistics itself (dn_conv_desc.bnf_*), 0 when the caller has to run
+ * dn_bn_finalize; likewise for the input gradient and the BatchNorm-backward sums (dn_conv_desc.bnb_dgamma / bnb_dbeta). */
+int32_t dn_conv_fwd_folds_bn_finalize(const dn_conv_desc* d);
+int32_t dn_conv_dgrad_folds_bn_sums(const dn_conv_desc* d);
 /* 1 if dn_conv2d_dgrad(d) will write bnb_partial (see dn_conv_desc), 0 if it ignores the bnb_* fields, < 0 on a bad descriptor. */
 int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d);
 /* 1 if dn_conv2d_fwd(d) writes 1 / out[0] to d->recip_out (a one-channel head on the second-generation head kernel), else 0. */

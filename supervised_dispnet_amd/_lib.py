@@ -13,7 +13,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 # ABI version this binding was written against (include/dispnet_hip.h: dn_version(), bumped on any signature / struct change).
 # load() refuses a library that reports anything else: a stale .so (DISPNET_HIP_LIB, a build that did not re-run) would otherwise
 # read struct fields past the end of what this binding fills in and mis-marshal arguments -- silent memory corruption, not an error.
-EXPECTED_ABI = 13
+EXPECTED_ABI = 14
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
@@ -44,7 +44,11 @@ class ConvDesc(C.Structure):
                 ("w_packed", _f32p), ("bias", _f32p), ("act", C.c_int32), ("act_p0", C.c_float), ("act_p1", C.c_float),
                 ("bn_partial", _f32p), ("pad_mode", C.c_int32), ("compute", C.c_int32), ("dilation", C.c_int32),
                 ("bnb_y", _f32p), ("bnb_scale", _f32p), ("bnb_shift", _f32p), ("bnb_mean", _f32p), ("bnb_invstd", _f32p), ("bnb_partial", _f32p),
-                ("splitk_ws", _f32p), ("splitk_ws_bytes", C.c_int64), ("recip_out", _f32p)]
+                ("splitk_ws", _f32p), ("splitk_ws_bytes", C.c_int64), ("recip_out", _f32p),
+                ("bnf_gamma", _f32p), ("bnf_beta", _f32p), ("bnf_running_mean", _f32p), ("bnf_running_var", _f32p),
+                ("bnf_num_batches_tracked", C.c_void_p), ("bnf_momentum", C.c_float), ("bnf_eps", C.c_float),
+                ("bnf_mean", _f32p), ("bnf_invstd", _f32p), ("bnf_scale", _f32p), ("bnf_shift", _f32p),
+                ("bnb_dgamma", _f32p), ("bnb_dbeta", _f32p)]
 
 
 _P = C.POINTER
@@ -67,6 +71,8 @@ SIGNATURES = {
     "dn_conv_dgrad_fuses_bn_sums": (_i32, [_P(ConvDesc)]),
     "dn_conv_fwd_fuses_reciprocal": (_i32, [_P(ConvDesc)]),
     "dn_conv_splitk_workspace_bytes": (_i64, [_P(ConvDesc)]),
+    "dn_conv_fwd_folds_bn_finalize": (_i32, [_P(ConvDesc)]),
+    "dn_conv_dgrad_folds_bn_sums": (_i32, [_P(ConvDesc)]),
     "dn_conv2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),
     "dn_conv2d_dgrad": (C.c_int, [_P(ConvDesc), _vp]),
     "dn_convT2d_fwd": (C.c_int, [_P(ConvDesc), _vp]),

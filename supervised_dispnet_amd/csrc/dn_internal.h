@@ -98,6 +98,21 @@ struct KPhase {
   long long w_off;               // element offset of this phase's [Npad][nchunks*32] block in w_packed
 };
 
+// what dn_bn_finalize takes per layer; also carried by a conv launch that finishes the statistics itself (dn_conv_desc.bnf_*, dn_fold.h)
+struct BnFinalizeArgs {
+  const float* conv_bias;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  long long* num_batches_tracked;
+  float momentum, eps;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+};
+
 struct IgemmParams {
   KOperand in[DN_MAX_OPERANDS];
   KResult out[DN_MAX_OPERANDS];
@@ -143,6 +158,12 @@ struct IgemmParams {
   size_t ks_ws_bytes;
   int T, TH, TW;                 // 2x2 output tiles: total, per image column / row
   unsigned mTW, mTH;             // fastdiv magics
+  // last-arrival epilogues (round 5, dn_fold.h; Winograd kernels): requested through dn_conv_desc.bnf_* / bnb_dgamma, bnb_dbeta; the
+  // launcher sets fold_bn / fold_bnb when the launch qualifies (few partial rows, counters available)
+  BnFinalizeArgs bnf;
+  float *bnb_dgamma, *bnb_dbeta;
+  int* fold_cnt;                 // kFoldCounters zeroed, self-resetting ints: the last 256 bytes of dn_conv_desc.splitk_ws
+  int fold_bn, fold_bnb;
 };
 
 // floor(n / d) for 0 <= n < 2^31 with a precomputed magic (see fastdiv_magic); branch-free
@@ -191,6 +212,8 @@ bool wino_eligible(const dn_conv_desc* d, const IgemmParams& p);
 long long wino_packed_elems(const IgemmParams& p);
 int launch_wino_pack(const IgemmParams& p, const float* w, float* wp, hipStream_t stream);
 int launch_wino_conv(IgemmParams& p, hipStream_t stream);
+bool wino_folds_bn_finalize(const IgemmParams& p);   // the launch will finish the BatchNorm statistics / the BatchNorm-backward sums itself
+bool wino_folds_bn_sums(const IgemmParams& p);
 int wino_splitk_choice(const IgemmParams& p);
 size_t conv_x3_splitk_workspace_upper_bytes(const IgemmParams& p);   // dn_conv.hip: K split of the three-piece direct kernel
 size_t wino_splitk_workspace_bytes(const IgemmParams& p);

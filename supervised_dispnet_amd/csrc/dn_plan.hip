@@ -153,6 +153,32 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   if (!for_wgrad && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0) {
     p->ks_ws = reinterpret_cast<float*>(d->splitk_ws);
     p->ks_ws_bytes = (size_t)d->splitk_ws_bytes;
+    if (d->splitk_ws_bytes >= 8192 && (d->splitk_ws_bytes & 3) == 0) {
+      // the last 256 bytes: counters of the last-arrival epilogues (dn_fold.h), out of reach of the K splits' partial tiles
+      p->ks_ws_bytes -= 256;
+      p->fold_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(d->splitk_ws) + d->splitk_ws_bytes - 256);
+    }
+  }
+  if (!for_wgrad && d->kind == DN_CONV_FWD && d->bn_partial != nullptr && d->bnf_scale != nullptr) {
+    DN_REQUIRE(d->bnf_gamma && d->bnf_beta && d->bnf_mean && d->bnf_invstd && d->bnf_shift, DN_ERR_BAD_ARG,
+               "bnf_scale needs gamma / beta / mean / invstd / shift");
+    DN_REQUIRE((d->bnf_running_mean == nullptr) == (d->bnf_running_var == nullptr), DN_ERR_BAD_ARG, "bnf_running_mean and bnf_running_var go together");
+    p->bnf.conv_bias = d->bias;
+    p->bnf.gamma = d->bnf_gamma;
+    p->bnf.beta = d->bnf_beta;
+    p->bnf.running_mean = d->bnf_running_mean;
+    p->bnf.running_var = d->bnf_running_var;
+    p->bnf.num_batches_tracked = reinterpret_cast<long long*>(d->bnf_num_batches_tracked);
+    p->bnf.momentum = d->bnf_momentum;
+    p->bnf.eps = d->bnf_eps;
+    p->bnf.mean = d->bnf_mean;
+    p->bnf.invstd = d->bnf_invstd;
+    p->bnf.scale = d->bnf_scale;
+    p->bnf.shift = d->bnf_shift;
+  }
+  if (!for_wgrad && d->kind == DN_CONV_DGRAD && p->bnb_y != nullptr && d->bnb_dgamma != nullptr && d->bnb_dbeta != nullptr) {
+    p->bnb_dgamma = d->bnb_dgamma;
+    p->bnb_dbeta = d->bnb_dbeta;
   }
   const int st = d->stride, pad = d->pad;
   const int dil = d->dilation > 1 ? d->dilation : 1;
@@ -356,7 +382,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 13; }
+int dn_version(void) { return 14; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);
@@ -417,6 +443,22 @@ int32_t dn_conv_dgrad_fuses_bn_sums(const dn_conv_desc* d) {
   const bool dense = d->n_out == 1 && !r.accumulate && (r.C & 3) == 0 && r.stride_w == r.C && r.stride_h == (int64_t)d->OW * r.C &&
                      r.stride_n == (int64_t)d->OH * d->OW * r.C;
   return (dense && d->bias == nullptr && d->act == DN_ACT_NONE) ? 1 : 0;
+}
+
+int32_t dn_conv_fwd_folds_bn_finalize(const dn_conv_desc* d) {
+  dn::IgemmParams p;
+  if (d == nullptr || dn::build_plan(d, false, &p) != DN_OK) return -1;
+  if (d->kind != DN_CONV_FWD || dn::wino_layout(d, p) == 0) return 0;
+  p.T = p.M / 4;
+  return dn::wino_folds_bn_finalize(p) ? 1 : 0;
+}
+
+int32_t dn_conv_dgrad_folds_bn_sums(const dn_conv_desc* d) {
+  if (dn_conv_dgrad_fuses_bn_sums(d) != 1) return 0;
+  dn::IgemmParams p;
+  if (dn::build_plan(d, false, &p) != DN_OK) return -1;
+  p.T = p.M / 4;
+  return dn::wino_folds_bn_sums(p) ? 1 : 0;
 }
 
 int64_t dn_conv_splitk_workspace_bytes(const dn_conv_desc* d) {

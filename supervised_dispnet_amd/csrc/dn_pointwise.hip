@@ -3,6 +3,7 @@
 // All column reductions are two-stage (per-block partial rows in a caller workspace, then a finalize) so results are
 // deterministic and no float atomics are used.
 #include "dn_internal.h"
+#include "dn_fold.h"
 
 namespace dn {
 
@@ -177,6 +178,21 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(const float* __re
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   }
+}
+
+// The sliced order of dn_fold.h as kernels of their own (<= kFoldMaxRows partial rows): one block per 64 channels.  The Winograd kernels
+// run the same device functions in their last-arriving block when the caller asked for it -- same bits either way.
+__global__ void __launch_bounds__(256) bn_finalize_sliced_kernel(const float* __restrict__ partial, int rows, int C, double count, BnFinalizeArgs a) {
+  __shared__ double red[3 * kFoldSlices * 64];
+  const int c0 = blockIdx.x * 64;
+  bn_finalize_sliced<false>(partial, rows, C, c0, C - c0 < 64 ? C - c0 : 64, count, a, red, threadIdx.x);
+}
+
+__global__ void __launch_bounds__(256) colsum2_sliced_kernel(const float* __restrict__ partial, int rows, int C, int stride, int offset,
+                                                             float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ double red[2 * kFoldSlices * 64];
+  const int c0 = blockIdx.x * 64;
+  colsum2_sliced<false>(partial, rows, C, stride, offset, c0, C - c0 < 64 ? C - c0 : 64, out0, out1, red, threadIdx.x);
 }
 
 __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -981,6 +997,12 @@ int dn_bn_finalize(const float* partial, int32_t rows, int32_t C, int64_t count,
                    float* scale, float* shift, int64_t* num_batches_tracked, dn_stream_t stream) {
   DN_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift && rows > 0 && C > 0 && count > 0, DN_ERR_BAD_ARG,
              "dn_bn_finalize: bad argument");
+  if (rows <= kFoldMaxRows) {          // the order a folded finalize uses (dn_conv_desc.bnf_*): bit-identical results either way
+    const BnFinalizeArgs a{conv_bias, gamma, beta, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps,
+                           mean, invstd, scale, shift};
+    DN_LAUNCH(bn_finalize_sliced_kernel, dim3((C + 63) / 64), dim3(256), 0, as_stream(stream), partial, rows, C, (double)count, a);
+    return check_launch("bn_finalize_sliced_kernel");
+  }
   DN_LAUNCH(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, as_stream(stream), partial, rows, C, (double)count, conv_bias, gamma,
                      beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                      reinterpret_cast<long long*>(num_batches_tracked));
@@ -1045,13 +1067,25 @@ int dn_bn_relu_bwd_sums(const float* da, const float* y, const float* scale, con
   return launch_colreduce(op, rows, C, partial, as_stream(stream), "bn_relu_bwd_sums");
 }
 
+static void launch_colsum2(const float* partial, int32_t partial_rows, int32_t C, int32_t partial_stride, int32_t partial_offset, float* out0,
+                           float* out1, hipStream_t s) {
+  // few rows: the sliced order a folded sum uses (dn_conv_desc.bnb_dgamma / bnb_dbeta) -- bit-identical either way
+  if (partial_rows <= kFoldMaxRows && (partial_stride & 1) == 0 && (partial_offset & 1) == 0 && (reinterpret_cast<uintptr_t>(partial) & 7) == 0)
+    DN_LAUNCH(colsum2_sliced_kernel, dim3((C + 63) / 64), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, out0, out1);
+  else
+    DN_LAUNCH(colsum2_finalize_kernel, dim3(C), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, out0, out1);
+}
+
+// partial == nullptr: dgamma / dbeta already hold the two sums (the input-gradient launch that produced the partial rows finished them
+// itself: dn_conv_desc.bnb_dgamma / bnb_dbeta, dn_conv_dgrad_folds_bn_sums)
 static int bn_bwd_sums_to_params(const float* partial, int32_t partial_rows, int32_t partial_stride, int32_t partial_offset, int32_t C,
                                  float* dgamma, float* dbeta, hipStream_t s, const char* who) {
-  DN_REQUIRE(partial && dgamma && dbeta && partial_rows > 0, DN_ERR_BAD_ARG, "%s: bad argument", who);
+  DN_REQUIRE(dgamma && dbeta, DN_ERR_BAD_ARG, "%s: bad argument", who);
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "%s: need C%%4==0", who);
+  if (partial == nullptr) return DN_OK;
+  DN_REQUIRE(partial_rows > 0, DN_ERR_BAD_ARG, "%s: bad argument", who);
   DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "%s: partial layout", who);
-  DN_LAUNCH(colsum2_finalize_kernel, dim3(C), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
-                     dgamma);
+  launch_colsum2(partial, partial_rows, C, partial_stride, partial_offset, dbeta, dgamma, s);
   return DN_OK;
 }
 
@@ -1094,8 +1128,7 @@ int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float
   DN_REQUIRE(C % 4 == 0, DN_ERR_UNSUPPORTED, "dn_bn_bwd_apply: need C%%4==0");
   DN_REQUIRE(partial_stride >= 2 && partial_offset >= 0 && partial_offset + 1 < partial_stride, DN_ERR_BAD_ARG, "dn_bn_bwd_apply: partial layout");
   hipStream_t s = as_stream(stream);
-  DN_LAUNCH(colsum2_finalize_kernel, dim3(C), dim3(256), 0, s, partial, partial_rows, C, partial_stride, partial_offset, dbeta,
-                     dgamma);
+  launch_colsum2(partial, partial_rows, C, partial_stride, partial_offset, dbeta, dgamma, s);
   // hoisted form: a grid whose stride (blocks x 256 threads) is a multiple of the channel groups G = C / 4
   const int G = C / 4;
   int blocks = ew_blocks((rows * (long long)G + 3) / 4);

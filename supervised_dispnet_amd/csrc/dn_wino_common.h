@@ -4,6 +4,7 @@
 #include <utility>
 
 #include "dn_internal.h"
+#include "dn_fold.h"
 
 namespace dn {
 
@@ -135,10 +136,25 @@ __device__ __forceinline__ void wino_bn_bwd_sums(const IgemmParams& p, const f32
     const int n = (n_first - 4 * c4) + col;           // nb * WBN + col
     if (n < p.Ntot && mb * BT + 32 * g < p.T) {
       float* dst = p.bnb_partial + ((long long)(GROUPS * mb + g) * p.Ntot + n) * 2;
-      dst[0] = a1;
-      dst[1] = a2;
+      fold_store(dst, a1);             // (agent scope: the block that arrives last may read them, dn_fold.h)
+      fold_store(dst + 1, a2);
     }
   }
+}
+
+// Last-arrival epilogues of the Winograd forward / input-gradient kernels (dn_fold.h), called by every thread at the very END of a block
+// that ran the epilogue (its statistics / sums rows are stored): the block that arrives last for its 64-channel slice `nb` finishes the
+// BatchNorm statistics of the slice (p.fold_bn: what dn_bn_finalize would do next) or the two BatchNorm-backward sums (p.fold_bnb: what
+// the BatchNorm backward's own sums launch would do).  `mblocks` = blocks per slice that get here, `lds` >= 6 KB of free LDS.
+__device__ __forceinline__ void wino_fold_tail(const IgemmParams& p, int nb, int mblocks, float* lds, int tid) {
+  if (!(p.fold_bn | p.fold_bnb)) return;
+  __shared__ int fold_flag;
+  if (!fold_last_arrival(p.fold_cnt + nb, mblocks, &fold_flag)) return;
+  const int rows = (p.T + 31) / 32, c0 = nb * WBN;
+  const int nlive = p.Ntot - c0 < WBN ? p.Ntot - c0 : WBN;
+  double* red = reinterpret_cast<double*>(lds);
+  if (p.fold_bn) bn_finalize_sliced<true>(p.bn_partial, rows, p.Ntot, c0, nlive, (double)p.M, p.bnf, red, tid);
+  if (p.fold_bnb) colsum2_sliced<true>(p.bnb_partial, rows, p.Ntot, 2, 0, c0, nlive, p.bnb_dbeta, p.bnb_dgamma, red, tid);
 }
 
 // dn_winograd8.hip: the 8-wave / one-block-per-CU form of the three-piece kernel (64 tiles x 64 output channels, two positions per wave)

@@ -951,8 +951,8 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       const int gc = m == 0 ? gcount[0] : gcount[MTW - 1];
       if (n < p.Ntot && gc > 0) {
         float* dst = p.bn_partial + ((long long)(MTW * mb + m) * p.Ntot + n) * 2;
-        dst[0] = tot;
-        dst[1] = m2;
+        fold_store(dst, tot);          // (agent scope: the block that arrives last may read them, dn_fold.h)
+        fold_store(dst + 1, m2);
       }
     }
   }
@@ -1067,6 +1067,30 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = te1; o[5] = te2;
     }
   }
+  if constexpr (DBG == 0) {
+    if (p.fold_bn | p.fold_bnb) {
+      // (tile coordinates recomputed from a laundered block index: keeping nb / MT alive across the whole kernel for this tail cost the
+      //  variant with a pending BatchNorm five spilled registers)
+      __syncthreads();                   // (the LDS of the epilogue is free from here)
+      unsigned bx = blockIdx.x;
+      asm volatile("" : "+s"(bx));
+      const int MT2 = (p.T + BT - 1) / BT, NT2 = p.Npad / WBN;
+      const int per2 = (MT2 * NT2 + 7) >> 3;
+      const int q2 = (int)(bx & 7u) * per2 + (int)(bx >> 3);
+      wino_fold_tail(p, q2 % NT2, MT2, smem, (int)threadIdx.x);
+    }
+  }
+}
+
+// Whether a launch finishes the BatchNorm statistics (forward) / the BatchNorm-backward sums (input gradient) in its last-arriving
+// blocks: asked for by the caller, few enough partial rows for one block per 64 channels, counters available.
+bool wino_folds_bn_finalize(const IgemmParams& p) {
+  return p.bnf.scale != nullptr && p.bn_partial != nullptr && p.fold_cnt != nullptr && (p.T + 31) / 32 <= kFoldMaxRows &&
+         wino_npad(p) / WBN <= kFoldCounters && knobs().wino_dbg == 0;
+}
+bool wino_folds_bn_sums(const IgemmParams& p) {
+  return p.bnb_dgamma != nullptr && p.bnb_dbeta != nullptr && p.bnb_partial != nullptr && p.fold_cnt != nullptr && (p.T + 31) / 32 <= kFoldMaxRows &&
+         wino_npad(p) / WBN <= kFoldCounters && knobs().wino_dbg == 0;
 }
 
 template <int MTW, bool HA, int DBG, int PREC = 0>
@@ -1096,6 +1120,8 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.TW = p.OW / 2;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
+  p.fold_bn = wino_folds_bn_finalize(p) ? 1 : 0;
+  p.fold_bnb = wino_folds_bn_sums(p) ? 1 : 0;
   const int dbg = knobs().wino_dbg;
   if (p.compute == DN_COMPUTE_BF16)      // (wino_layout() has checked that the bf16 variants may be used)
     return p.any_affine ? launch_wino_variant<1, true, 0, 1>(p, stream) : launch_wino_variant<1, false, 0, 1>(p, stream);

@@ -516,8 +516,8 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
       const int gc = m == 0 ? gcount[0] : gcount[1];
       if (n < p.Ntot && gc > 0) {
         float* dst = p.bn_partial + ((long long)(2 * mb + m) * p.Ntot + n) * 2;
-        dst[0] = tot;
-        dst[1] = m2;
+        fold_store(dst, tot);          // (agent scope: the block that arrives last may read them, dn_fold.h)
+        fold_store(dst + 1, m2);
       }
     }
   }
@@ -623,6 +623,10 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
       long long* o = reinterpret_cast<long long*>(p.ws) + (size_t)blockIdx.x * 8;
       o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = te1; o[5] = te2;
     }
+  }
+  if constexpr (DBG == 0) {
+    __syncthreads();                     // (the LDS of the epilogue is free from here)
+    wino_fold_tail(p, nb, MT, smem, tid);
   }
 }
 

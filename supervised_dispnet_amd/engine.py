@@ -40,6 +40,8 @@ SPLITK = True                   # small Winograd / direct grids split their K ax
 PACK_ON_SIDE_STREAM = True      # batched weight re-lay of the large layers under the first layers of the forward
 PACK_LATE_MIN_ELEMS = 400000
 BN_SUMS_FUSION = True           # input-gradient kernels take the BatchNorm backward's column sums of the layer below
+FOLD_FINALIZE = True            # ... and finish them / the forward's BatchNorm statistics in their last-arriving block when the partial rows are few
+                                # (dn_conv_desc.bnf_* / bnb_dgamma, bnb_dbeta; csrc/dn_fold.h).  Tests switch it off to compare: same bits
 BN_MATERIALIZE_DZ = False       # True: the r01 BatchNorm backward (reduce pass writes dz, apply pass reads it back); the equivalence test sets it
 
 # Arithmetic of the matrix-core kernels that offer a choice (dn_conv_desc.compute, include/dispnet_hip.h), today the Winograd forward /
@@ -401,7 +403,7 @@ class Act:
     """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
     __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
                  "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar", "pool_src", "sums_ready",
-                 "recip_t")
+                 "recip_t", "bn_owner", "sums_final")
 
     def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
         self.t = t
@@ -420,6 +422,9 @@ class Act:
                                         # backward itself (dn_bn_bwd_apply_pool); .grad is then only the destination buffer
         self.planar = False             # .t is [N,C,H,W] (a network OUTPUT the caller's API wants planar: ord_c1, decode_c)
         self.recip_t = None             # a one-channel disparity head's 1 / disp, written by the head kernel (dn_conv_desc.recip_out)
+        self.bn_owner = None            # (BatchNorm2d, GradSink) of a pre-BatchNorm activation: where the input-gradient kernel of the layer
+                                        # above may put d(gamma), d(beta) when it finishes the sums itself (dn_conv_desc.bnb_dgamma / bnb_dbeta)
+        self.sums_final = None          # (dgamma, dbeta) tensors that already hold the two BatchNorm-backward sums
         self.needs_grad = needs_grad
         self.strides = strides or (H * W * C, W * C, C, 1)   # (n, h, w, c) element strides
 
@@ -700,7 +705,7 @@ def prepack_all(device):
 FUSE_RECIP = True       # a one-channel disparity head also emits depth = 1 / disp (train.py:445); tests switch it off to compare
 
 
-def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None, out_view=None, recip=None):
+def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, out_hw=None, out_view=None, recip=None, bn_fold=None):
     """Forward of conv / conv-transpose over virtually concatenated `pieces`.  Returns (y tensor NHWC, partial, rows).
     `out_view` = (tensor, element offset, (stride_n, stride_h, stride_w), accumulate): write the result into a strided view of an
     existing tensor instead of a fresh one (FCRN's interleaved up-projection maps; the ASPP classifier's sum of four convolutions)."""
@@ -739,6 +744,22 @@ def conv_forward(layer, pieces, act=ACT_NONE, p0=0.0, p1=0.0, bn_stats=False, ou
         rows = _lib.load().dn_conv_bn_partial_rows(C.byref(d))
         partial = torch.empty((rows, layer.Cout, 2), dtype=torch.float32, device=y.device)
         d.bn_partial = partial.data_ptr()
+        if bn_fold is not None and FOLD_FINALIZE and d.splitk_ws:
+            # `bn_fold` = [BatchNorm2d, mean, invstd, scale, shift, num_batches_tracked pointer]: let the launch finish the statistics in its last-arriving blocks (what
+            # dn_bn_finalize would do next); the answer goes back in bn_fold[0] (True: done, the caller skips dn_bn_finalize)
+            bn = bn_fold[0]
+            d.bnf_gamma, d.bnf_beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+            d.bnf_running_mean, d.bnf_running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
+            d.bnf_num_batches_tracked = bn_fold[5]
+            d.bnf_momentum = bn.momentum if bn.momentum is not None else BN_MOMENTUM
+            d.bnf_eps = bn.eps
+            d.bnf_mean, d.bnf_invstd, d.bnf_scale, d.bnf_shift = (t.data_ptr() for t in bn_fold[1:5])
+            if _lib.load().dn_conv_fwd_folds_bn_finalize(C.byref(d)) == 1:
+                bn_fold[0] = True
+            else:
+                d.bnf_scale = None
+    if bn_fold is not None and bn_fold[0] is not True:
+        bn_fold[0] = False
     with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cout), 2 * layer.macs(N, IH, IW, OH, OW),
                 "%s %dx%d k%d s%d cin%d cout%d in %dx%dx%d" % ("convT_fwd" if layer.transposed else "conv_fwd", layer.R, layer.S,
                                                                layer.R, layer.stride, layer.Cin, layer.Cout, N, IH, IW),
@@ -849,6 +870,7 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
                 a.grad = a.new_like()
             else:
                 a.sums_ready = False    # a second consumer adds to this gradient: sums taken by the first writer no longer describe it
+                a.sums_final = None
             _fill_result(d.out[i], a.grad, a.C, IH, IW, not first)
     d.w_packed = layer.packed(kind, d).data_ptr()
     d.bias = None
@@ -868,7 +890,21 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
             scratch = torch.empty((max(rows, 1), a.C, 2), dtype=torch.float32, device=dy.device)
             d.bnb_partial = scratch.data_ptr()
             if _lib.load().dn_conv_dgrad_fuses_bn_sums(C.byref(d)) == 1:
-                fuse = (a, scratch, rows)
+                fuse = (a, scratch, rows, None)
+                if FOLD_FINALIZE and a.bn_owner is not None and d.splitk_ws:
+                    # ... and FINISH the two sums in the launch's last-arriving blocks: d(gamma), d(beta) of the BatchNorm below land where
+                    # bn_backward() would have its own sums launch put them
+                    obn, osink = a.bn_owner
+                    dg, db = osink.dest(obn.weight), osink.dest(obn.bias)
+                    if dg is None:
+                        dg = torch.empty(a.C, dtype=torch.float32, device=dy.device)
+                    if db is None:
+                        db = torch.empty(a.C, dtype=torch.float32, device=dy.device)
+                    d.bnb_dgamma, d.bnb_dbeta = dg.data_ptr(), db.data_ptr()
+                    if _lib.load().dn_conv_dgrad_folds_bn_sums(C.byref(d)) == 1:
+                        fuse = (a, scratch, rows, (dg, db))
+                    else:
+                        d.bnb_dgamma = d.bnb_dbeta = None
             else:
                 d.bnb_y = d.bnb_partial = None
     with _Timed("igemm_conv_kernel<128,%d>" % _pick_bn(layer.Cin), 2 * layer.macs(N, IH, IW, OH, OW),
@@ -877,9 +913,10 @@ def conv_dgrad(layer, dy, N, OH, OW, pieces, in_hw):
                 4 * (dy.numel() + sum(p.act.rows * p.act.C for p in targets))):
         _lib.call("dn_convT2d_dgrad" if layer.transposed else "dn_conv2d_dgrad", C.byref(d), _stream())
     if fuse is not None:
-        a, scratch, rows = fuse
+        a, scratch, rows, final = fuse
         a.partial, a.partial_rows, a.partial_stride, a.partial_offset = scratch, rows, 2, 0
         a.sums_ready = True
+        a.sums_final = final
     for p, tmp in post:
         a = p.act
         cur = tmp
@@ -987,8 +1024,10 @@ def bn_backward(y, bn, sink, training):
     if not training:
         raise NotImplementedError("backward through eval-mode BatchNorm (frozen statistics) is not implemented")
     relu_pending = not y.grad_is_dz           # g is dL/d(relu output): the mask is applied by the kernels below
+    final = None
     if relu_pending and y.sums_ready and not BN_MATERIALIZE_DZ:
         y.sums_ready = False                  # the column sums came out of the epilogue of the kernel that wrote g (conv_dgrad)
+        final, y.sums_final = y.sums_final, None      # ... already summed over the blocks too (dgamma, dbeta): no sums launch at all
     elif relu_pending:
         y.sums_ready = False
         if y.no_relu:
@@ -1005,12 +1044,15 @@ def bn_backward(y, bn, sink, training):
                      y_t.data_ptr(), y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), y.rows, Cn,
                      y.partial.data_ptr(), _stream())
     # written straight into the optimizer arena's gradient slices when there is one (no copy launches)
-    dgamma = sink.dest(bn.weight)
-    dbeta = sink.dest(bn.bias)
-    if dgamma is None:
-        dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
-    if dbeta is None:
-        dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
+    if final is not None:
+        dgamma, dbeta = final
+    else:
+        dgamma = sink.dest(bn.weight)
+        dbeta = sink.dest(bn.bias)
+        if dgamma is None:
+            dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
+        if dbeta is None:
+            dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
     if y.pool_src is not None:                # gradient through the 2x2 max-pool: expanded here, never materialised as dz
         dpooled, pidx = y.pool_src
         hbm_call("dn::bn_bwd_apply_pool_kernel", y.rows * Cn * 8 + y.rows * Cn * 5 // 4, "dn_bn_bwd_apply_pool", dpooled.data_ptr(),
@@ -1021,8 +1063,8 @@ def bn_backward(y, bn, sink, training):
     elif relu_pending and not BN_MATERIALIZE_DZ:
         hbm_call(None, y.rows * Cn * 12, "dn_bn_bwd_apply_relu", g.data_ptr(), y_t.data_ptr(),
                  y.scale.data_ptr(), y.shift.data_ptr(), y.mean.data_ptr(), y.invstd.data_ptr(), bn.weight.data_ptr(),
-                 y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn, dgamma.data_ptr(),
-                 dbeta.data_ptr(), _stream())
+                 None if final is not None else y.partial.data_ptr(), y.partial_rows, y.partial_stride, y.partial_offset, y.rows, Cn,
+                 dgamma.data_ptr(), dbeta.data_ptr(), _stream())
     else:
         hbm_call(None, y.rows * Cn * 12, "dn_bn_bwd_apply", g.data_ptr(), y_t.data_ptr(), y.mean.data_ptr(),
                  y.invstd.data_ptr(), bn.weight.data_ptr(), y.partial.data_ptr(), y.partial_rows, y.partial_stride,
@@ -1056,21 +1098,28 @@ def block_conv_bn(tape, sink, x_piece, layer, bn, training, relu=True):
     (the consumer's loader applies it).  Reference: torchvision vgg16_bn features triplets used at
     models/Disp_vgg_BN.py:137-141."""
     xa = x_piece.act
-    y_t, partial, prow = conv_forward(layer, [x_piece], ACT_NONE, bn_stats=training)
-    OH, OW = y_t.shape[1], y_t.shape[2]
+    dev = xa.t.device
     Cn = layer.Cout
+    scale = torch.empty(Cn, dtype=torch.float32, device=dev)
+    shift = torch.empty(Cn, dtype=torch.float32, device=dev)
+    mean = invstd = fold = nbt = None
+    if training:
+        mean = torch.empty(Cn, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Cn, dtype=torch.float32, device=dev)
+        nbt = _nbt_ptr(bn)
+        fold = [bn, mean, invstd, scale, shift, nbt]
+    y_t, partial, prow = conv_forward(layer, [x_piece], ACT_NONE, bn_stats=training, bn_fold=fold)
+    OH, OW = y_t.shape[1], y_t.shape[2]
     y = Act(y_t, xa.N, OH, OW, Cn)
     y.no_relu = not relu
-    dev = y_t.device
-    y.scale = torch.empty(Cn, dtype=torch.float32, device=dev)
-    y.shift = torch.empty(Cn, dtype=torch.float32, device=dev)
+    y.scale, y.shift, y.mean, y.invstd = scale, shift, mean, invstd
+    y.bn_owner = (bn, sink)
     if training:
-        y.mean = torch.empty(Cn, dtype=torch.float32, device=dev)
-        y.invstd = torch.empty(Cn, dtype=torch.float32, device=dev)
-        _lib.call("dn_bn_finalize", partial.data_ptr(), prow, Cn, y.rows, _ptr(layer.m.bias.detach()) if layer.m.bias is not None else None,
-                  bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                  bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps, y.mean.data_ptr(), y.invstd.data_ptr(),
-                  y.scale.data_ptr(), y.shift.data_ptr(), _nbt_ptr(bn), _stream())
+        if fold[0] is not True:              # (True: the convolution's last-arriving blocks finished the statistics themselves)
+            _lib.call("dn_bn_finalize", partial.data_ptr(), prow, Cn, y.rows, _ptr(layer.m.bias.detach()) if layer.m.bias is not None else None,
+                      bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                      bn.momentum if bn.momentum is not None else BN_MOMENTUM, bn.eps, y.mean.data_ptr(), y.invstd.data_ptr(),
+                      y.scale.data_ptr(), y.shift.data_ptr(), nbt, _stream())
     else:
         _lib.call("dn_bn_eval_affine", Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                   bn.running_var.data_ptr(), bn.eps, y.scale.data_ptr(), y.shift.data_ptr(), _stream())

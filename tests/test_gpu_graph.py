@@ -312,3 +312,57 @@ def test_launch_tape_outlives_other_models_in_the_weight_relay_table():
     assert torch.equal(opt_t.arena.flat_p, opt_e.arena.flat_p)
     ts.close()
     ts.close()                                                # idempotent
+
+
+def test_folded_reductions_are_bitwise_the_separate_kernels(monkeypatch):
+    """engine.FOLD_FINALIZE (round 5, csrc/dn_fold.h): with few partial rows the Winograd forward finishes the BatchNorm statistics and the
+    Winograd input gradient finishes the BatchNorm-backward sums in the block that arrives last, instead of dn_bn_finalize / the sums
+    launch of dn_bn_bwd_apply_relu.  The stand-alone kernels use the same sliced order for up to 128 partial rows, so loss, outputs,
+    EVERY gradient, the BatchNorm buffers and the parameters after two Adam steps are bit-identical with the folds on and off -- at 4
+    images (the 8-GPU shard of the metric: nine forward + six backward folds) and at 2 x 64 x 96; and the folds really happen
+    (fewer dn_bn_finalize calls, sums launches skipped)."""
+    from oracle import detgen
+    from supervised_dispnet_amd import _lib, engine
+    for (b, h, w, fwd_folds, bwd_folds) in ((4, 128, 416, 9, 6), (2, 64, 96, 1, 1)):
+        x = detgen.image_batch(b, h, w, "fold:x").to(DEV)
+        gt = detgen.sparse_depth(b, h, w, "fold:gt", density=0.3).to(DEV)
+        res, calls = {}, {}
+        real_call = _lib.call
+        for fold in (True, False):
+            counts = {"dn_bn_finalize": 0, "sums_skipped": 0}
+
+            def counting(name, *args, _c=counts):
+                if name == "dn_bn_finalize":
+                    _c["dn_bn_finalize"] += 1
+                if name == "dn_bn_bwd_apply_relu" and args[7] is None:
+                    _c["sums_skipped"] += 1
+                return real_call(name, *args)
+
+            monkeypatch.setattr(engine, "FOLD_FINALIZE", fold)
+            monkeypatch.setattr(_lib, "call", counting)
+            net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+            detgen.fill_state_dict(net.state_dict(), "vggbn")
+            net.to(DEV).train()
+            opt = FusedAdam(net._hot_parameters(), lr=1e-4, betas=(0.9, 0.999), production_order=net._grad_production_order())
+            losses = []
+            for _ in range(2):
+                disps = net(x)
+                loss = LF.l1_loss(gt, [reciprocal(d) for d in disps], "kitti")
+                opt.zero_grad()
+                loss.backward()
+                grads = opt.arena.flat_g.clone()
+                opt.step()
+                losses.append(loss.item())
+            torch.cuda.synchronize()
+            monkeypatch.setattr(_lib, "call", real_call)
+            res[fold] = (losses, [d.detach().clone() for d in disps], grads, opt.arena.flat_p.clone(),
+                         {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k})
+            calls[fold] = counts
+        assert calls[False]["dn_bn_finalize"] == 2 * 13 and calls[False]["sums_skipped"] == 0
+        assert calls[True]["dn_bn_finalize"] <= 2 * (13 - fwd_folds), calls
+        assert calls[True]["sums_skipped"] >= 2 * bwd_folds, calls
+        assert res[True][0] == res[False][0]
+        assert all(torch.equal(a, c) for a, c in zip(res[True][1], res[False][1]))
+        assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+        assert res[True][4].keys() == res[False][4].keys() and all(torch.equal(res[True][4][k], res[False][4][k]) for k in res[True][4])
+        assert int(res[True][4]["features.features.1.num_batches_tracked"]) == 2
