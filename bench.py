@@ -366,6 +366,11 @@ def main():
                     help="with --reducer rccl1: after each bucket's all-reduce, K round trips of the bucket through a scratch buffer on the "
                          "communication stream (dn_ubench_copy: read + write of the bucket twice per trip) -- a stand-in for the HBM side of "
                          "a ring all-reduce competing with the backward pass.  A PROJECTION, labelled as such in config.comm_standin")
+    ap.add_argument("--wgrad-streams", type=int, default=0, help="A/B: side streams the weight gradients alternate between (0: the engine's rule)")
+    ap.add_argument("--no-defer-pack", action="store_true", help="A/B: re-lay the large input-gradient weight layouts with the forward ones at the start of the step")
+    ap.add_argument("--no-fold", action="store_true",
+                    help="A/B: run dn_bn_finalize / the BatchNorm-backward sums as launches of their own instead of in the last-arriving block "
+                         "of the Winograd kernels (engine.FOLD_FINALIZE; same bits either way)")
     ap.add_argument("--watchdog-s", type=float, default=0.0,
                     help="N > 1: if the line has not been printed after this many seconds (default 900 at N > 1, 0 = off at N = 1) rank 0 "
                          "prints a line with value null and the reason, and every rank exits non-zero")
@@ -409,6 +414,12 @@ def main():
     from supervised_dispnet_amd.optim import FusedAdam
 
     engine.set_compute(args.compute)
+    if args.no_fold:
+        engine.FOLD_FINALIZE = False
+    if args.wgrad_streams > 0:
+        engine.WGRAD_STREAMS = args.wgrad_streams
+    if args.no_defer_pack:
+        engine.PACK_DEFER_BWD = False
     global PMC_CONFIG
     PMC_CONFIG = args.config
     metric, netname, H, W, cfg_batch, ds, gflop_img = CONFIGS[args.config]

@@ -89,11 +89,17 @@ static void wg_choose_splits(const IgemmParams& p, int* splits, int* tiles_per_s
   int best = 1;
   double best_util = 0.0;
   const int r0 = (p.compute == DN_COMPUTE_F32X3 && T >= (1 << 18)) ? 3 : 1;
+  // Blocks of one round the split aims at: every CU -- unless the layer is small (less than 64 chunks per CU when spread over all 256:
+  // the 4- and 8-image shards of the metric's batch).  A weight gradient block owns a CU (8 waves, 96-128 KB of LDS), so 256 of them
+  // lock the input gradients on the main stream out -- the step's critical path, which the weight gradients on their side streams are
+  // not; aiming at 128 leaves half the chip to it (round 5, one box: 4 images 3.713 -> 3.671 ms, 8 images 5.419 -> 5.337; 64: +-0,
+  // 32: +10 %; profiles/r05_exp7_wgrad_footprint.txt).  DN_WINO_WG_TARGET overrides.
+  const int cus = knobs().wino_wg_target > 0 ? knobs().wino_wg_target : ((long long)chunks * tb < 64 * 256 ? 128 : 256);
   for (int R = r0; R <= 4; ++R) {
-    int sp = (R * 256) / tb;
+    int sp = (R * cus) / tb;
     if (sp < 1) continue;
     if (sp > max_by_work) sp = max_by_work;
-    const double util = (double)tb * sp / ((double)((tb * sp + 255) / 256) * 256);
+    const double util = (double)tb * sp / ((double)((tb * sp + cus - 1) / cus) * cus);
     if (util > best_util + 1e-9) {
       best_util = util;
       best = sp;
