@@ -367,7 +367,6 @@ def main():
                          "communication stream (dn_ubench_copy: read + write of the bucket twice per trip) -- a stand-in for the HBM side of "
                          "a ring all-reduce competing with the backward pass.  A PROJECTION, labelled as such in config.comm_standin")
     ap.add_argument("--wgrad-streams", type=int, default=0, help="A/B: side streams the weight gradients alternate between (0: the engine's rule)")
-    ap.add_argument("--no-defer-pack", action="store_true", help="A/B: re-lay the large input-gradient weight layouts with the forward ones at the start of the step")
     ap.add_argument("--no-fold", action="store_true",
                     help="A/B: run dn_bn_finalize / the BatchNorm-backward sums as launches of their own instead of in the last-arriving block "
                          "of the Winograd kernels (engine.FOLD_FINALIZE; same bits either way)")
@@ -418,8 +417,6 @@ def main():
         engine.FOLD_FINALIZE = False
     if args.wgrad_streams > 0:
         engine.WGRAD_STREAMS = args.wgrad_streams
-    if args.no_defer_pack:
-        engine.PACK_DEFER_BWD = False
     global PMC_CONFIG
     PMC_CONFIG = args.config
     metric, netname, H, W, cfg_batch, ds, gflop_img = CONFIGS[args.config]

@@ -39,7 +39,6 @@ PROFILE = None
 SPLITK = True                   # small Winograd / direct grids split their K axis over several blocks (tests switch it off to compare)
 PACK_ON_SIDE_STREAM = True      # batched weight re-lay of the large layers under the first layers of the forward
 PACK_LATE_MIN_ELEMS = 400000
-PACK_DEFER_BWD = True           # ... and of their INPUT-GRADIENT layouts under the deep layers of the forward pass (PackTable, round 5)
 BN_SUMS_FUSION = True           # input-gradient kernels take the BatchNorm backward's column sums of the layer below
 FOLD_FINALIZE = True            # ... and finish them / the forward's BatchNorm statistics in their last-arriving block when the partial rows are few
                                 # (dn_conv_desc.bnf_* / bnb_dgamma, bnb_dbeta; csrc/dn_fold.h).  Tests switch it off to compare: same bits
@@ -557,7 +556,7 @@ class ConvLayer:
         table = pack_table(w.device) if w.is_cuda else None
         if table is not None and hit is not None and hit[0][:2] + hit[0][3:] == key[:2] + key[3:] and table.fresh(hit[1], PARAM_EPOCH):
             self._packed[(kind, layout)] = (key, hit[1])      # re-laid by the batched launch of this epoch
-            if table.pending is not None or table.deferred is not None or table.bwd_pending is not None:
+            if table.pending is not None:
                 table.consumer_wait(hit[1])
             return hit[1]
         n = lib.dn_conv_packed_weight_elems(C.byref(desc))
@@ -603,15 +602,6 @@ class PackTable(object):
         self.late = set()
         self.pending = None
         self.split_mode = None
-        # Round 5: the large INPUT-GRADIENT layouts (half of the late bytes) are not needed before the backward pass: their re-lay is
-        # launched on the side stream only when the forward's first consumer of a large layer has waited for the forward layouts, so
-        # it runs under the deep layers of the forward pass instead of under conv1_1 / conv1_2 (which the one big re-lay slowed from
-        # ~80 to ~190 us at 4 images); the forward's stream waits for it once, at the end of the forward pass (finish_forward).
-        self.bwd_table = None
-        self.bwd_counts = (0, 0, 0, 0)
-        self.late_bwd = set()
-        self.deferred = None            # (side, main): the backward-layout re-lay still has to be launched
-        self.bwd_pending = None         # (side, main): launched, not yet waited for
 
     def register(self, key, desc, w, buf, owner):
         if len(self.rows) >= self.MAX_ROWS:
@@ -657,15 +647,11 @@ class PackTable(object):
                 with outside_tape_pool():
                     return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device), tuple(len(k) for k in kinds)
             rows = list(self.rows.values())
-            big = [(k, r) for k, r in self.rows.items() if split and (r[2]() is not None and r[2]().numel() > PACK_LATE_MIN_ELEMS)]
-            late = [r for k, r in big if not (PACK_DEFER_BWD and k[1] in (CONV_DGRAD, CONVT_DGRAD))]
-            late_bwd = [r for k, r in big if PACK_DEFER_BWD and k[1] in (CONV_DGRAD, CONVT_DGRAD)]
-            early = [r for r in rows if not any(r is q for _k, q in big)]
+            late = [r for r in rows if split and (r[2]() is not None and r[2]().numel() > PACK_LATE_MIN_ELEMS)]
+            early = [r for r in rows if not any(r is q for q in late)]
             self.dev_table, self.counts = upload(early)
             self.late_table, self.late_counts = upload(late)
-            self.bwd_table, self.bwd_counts = upload(late_bwd)
             self.late = {r[5] for r in late}
-            self.late_bwd = {r[5] for r in late_bwd}
             self.covered = {r[5] for r in rows}
             self.dirty = False
             self.split_mode = split
@@ -673,49 +659,22 @@ class PackTable(object):
             # the launches below go on a launch tape: everything they point at must live as long as the tape does -- the device tables
             # (replaced whenever a row changes), and the weights / packed buffers of EVERY row, also those of another model that
             # happens to be alive now and is deleted later (its rows are re-laid needlessly at replay, never into freed memory)
-            TAPE["keep"] += [t for t in (self.dev_table, self.late_table, self.bwd_table) if t is not None]
+            TAPE["keep"] += [t for t in (self.dev_table, self.late_table) if t is not None]
             for r in self.rows.values():
                 TAPE["keep"] += [x for x in (r[2](), r[3]()) if x is not None]
         if self.dev_table is not None:
             _lib.call("dn_pack_many", self.dev_table.data_ptr(), *self.counts, _stream())
-        if self.late_table is not None or self.bwd_table is not None:
+        if self.late_table is not None:
             st = side_stream()
             main, side = torch.cuda.current_stream(), st["side"]
             stream_wait(side, main)                  # the optimizer step that produced these weights
-            if self.late_table is not None:
-                _lib.call("dn_pack_many", self.late_table.data_ptr(), *self.late_counts, side.cuda_stream)
-                self.pending = (side, main)
-            if self.bwd_table is not None:
-                self.deferred = (side, main)
-                if self.late_table is None:
-                    self._launch_deferred()
+            _lib.call("dn_pack_many", self.late_table.data_ptr(), *self.late_counts, side.cuda_stream)
+            self.pending = (side, main)
         self.epoch = epoch
-
-    def _launch_deferred(self):
-        side, main = self.deferred
-        _lib.call("dn_pack_many", self.bwd_table.data_ptr(), *self.bwd_counts, side.cuda_stream)
-        self.deferred = None
-        self.bwd_pending = (side, main)
-
-    def finish_forward(self):
-        """End of a forward pass: the input-gradient layouts are on their way (or launched now), and the forward's stream waits for
-        them here -- the side stream carries nothing else at this point, so the backward pass inherits no other dependency."""
-        if self.deferred is not None:
-            self._launch_deferred()
-        if self.bwd_pending is not None:
-            side, main = self.bwd_pending
-            cur = torch.cuda.current_stream()
-            if cur.cuda_stream != side.cuda_stream:
-                stream_wait(cur, side)
-            self.bwd_pending = None
 
     def consumer_wait(self, buf):
         """First use of a buffer the side stream is re-laying: the consumer's stream waits for it (once per step)."""
-        ptr = buf.data_ptr()
-        if ptr in self.late_bwd:                     # an input-gradient layout asked for before the forward pass has ended (a bare
-            self.finish_forward()                    # conv_dgrad call, a second network): launch / wait now
-            return
-        if self.pending is None or ptr not in self.late:
+        if self.pending is None or buf.data_ptr() not in self.late:
             return
         side, main = self.pending
         h = _stream()
@@ -723,18 +682,9 @@ class PackTable(object):
             return                                   # (stream order; the main stream's first consumer still has to wait)
         stream_wait(main if h == main.cuda_stream else torch.cuda.current_stream(), side)
         self.pending = None
-        if self.deferred is not None:                # the forward layouts are done: the side stream takes the backward ones now
-            self._launch_deferred()
 
 
 _PACK_TABLES = {}
-
-
-def finish_forward_packs(device):
-    """Called at the end of a network's forward pass (models/_common.HipNetFunction.forward)."""
-    t = _PACK_TABLES.get(device)
-    if t is not None and (t.deferred is not None or t.bwd_pending is not None):
-        t.finish_forward()
 
 
 def pack_table(device):
