@@ -2014,11 +2014,11 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_u32_kernel(const IgemmPara
       if (m == 0) { decode_pixel(mnext); }
       if (m >= 1 && m < 1 + GR) load_g(m - 1);
       if (m >= 1 + GR && m < 5 + GR) load_x(m - 1 - GR);
-      if (s2 < 15) {     // fragments of the next pixel pair, spread over this pair's slots
-        if (PS >= NI + KI) {
-          if (ij < NI) fa[nxt][ij] = *reinterpret_cast<const float*>(Gb + (s2 + 1) * 2 * BNW * 4 + ij * 128);
-          else if (ij < NI + KI) fb[nxt][ij - NI] = *reinterpret_cast<const float*>(Xb + (s2 + 1) * 2 * BKW * 4 + (ij - NI) * 128);
-        } else if (ij == 0) {
+      if constexpr (s2 < 15) {     // fragments of the next pixel pair, spread over this pair's slots
+        if constexpr (PS >= NI + KI) {
+          if constexpr (ij < NI) fa[nxt][ij] = *reinterpret_cast<const float*>(Gb + (s2 + 1) * 2 * BNW * 4 + ij * 128);
+          else if constexpr (ij < NI + KI) fb[nxt][ij - NI] = *reinterpret_cast<const float*>(Xb + (s2 + 1) * 2 * BKW * 4 + (ij - NI) * 128);
+        } else if constexpr (ij == 0) {
 #pragma unroll
           for (int a = 0; a < NI; ++a) fa[nxt][a] = *reinterpret_cast<const float*>(Gb + (s2 + 1) * 2 * BNW * 4 + a * 128);
 #pragma unroll

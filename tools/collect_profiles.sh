@@ -17,4 +17,10 @@ for c in res50_480 vggbn480 dorn128_bf16; do
   [ -f gpurun_out/bench_${tag}_$c.json ] && cp gpurun_out/bench_${tag}_$c.json profiles/${tag}_bench_$c.json
 done
 [ -f gpurun_out/strong_${tag}.txt ] && cp gpurun_out/strong_${tag}.txt profiles/${tag}_strong_1gpu.txt
+[ -f gpurun_out/bench_default_${tag}.json ] && cp gpurun_out/bench_default_${tag}.json profiles/${tag}_bench_default.json
+[ -f gpurun_out/bench_${tag}_res50_480_per_layer.txt ] && grep -v amdgpu.ids gpurun_out/bench_${tag}_res50_480_per_layer.txt > profiles/${tag}_res50_480_per_layer.txt
+[ -f gpurun_out/tests_${tag}.log ] && tail -5 gpurun_out/tests_${tag}.log > profiles/${tag}_gpu_tests.txt
+for f in b4_timeline b4_trace_summary; do [ -f gpurun_out/timeline_${tag}/$f.txt ] && cp gpurun_out/timeline_${tag}/$f.txt profiles/${tag}_$f.txt; done
+[ -f gpurun_out/sq_${tag}_wino8.txt ] && cp gpurun_out/sq_${tag}_wino8.txt profiles/${tag}_sq_counters_wino8_raw.txt
+[ -f gpurun_out/sq_${tag}_wino64.txt ] && cp gpurun_out/sq_${tag}_wino64.txt profiles/${tag}_sq_counters_wino64_raw.txt
 ls -la profiles | grep $tag
