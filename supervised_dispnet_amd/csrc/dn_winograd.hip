@@ -196,7 +196,6 @@ __device__ __forceinline__ void wino_split3(float x, __bf16* pc) {
 template <int NSPL>
 __device__ __forceinline__ void wino_pack16_body(const IgemmParams& p, const float* __restrict__ w, float* __restrict__ wp, int NS, long long total) {
   __bf16* wp16 = reinterpret_cast<__bf16*>(wp);
-  const long long npairs = total >> 4;                       // (n, k) pairs, each written at 16 positions
   // framework tap (r * 3 + s) behind every slot (a, b) of the 3 x 3 correlation kernel: wave-uniform, once per thread (round 5: the
   // round-2 body chose each of the nine values through a 9 x 9 compare chain per pair -- 81 selects of the ~300 vector instructions)
   int src_of[9];
@@ -208,59 +207,73 @@ __device__ __forceinline__ void wino_pack16_body(const IgemmParams& p, const flo
 #pragma unroll
     for (int d = 0; d < 9; ++d) src_of[d] = slot == d ? so : src_of[d];
   }
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < npairs; idx += (long long)gridDim.x * blockDim.x) {
-    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
-    const long long rest = idx >> 9;
+  // one thread per (n, k PAIR): two adjacent k share every store (one dword = two bf16) and every conversion (v_cvt_pk_bf16_f32 takes
+  // two values) -- half the stores, conversions and address arithmetic per weight of the one-thread-per-(n, k) form (round 5)
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  const long long nduos = total >> 5;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < nduos; idx += (long long)gridDim.x * blockDim.x) {
+    const int e2 = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const long long rest = idx >> 8;
     const int nsub = (int)(rest % NS), kc16 = (int)(rest / NS);
-    const int k = kc16 * 16 + (lane >> 5) * 8 + e, n = nsub * 32 + (lane & 31);
-    float g[3][3];
+    const int k0 = kc16 * 16 + (lane >> 5) * 8 + 2 * e2, n = nsub * 32 + (lane & 31);
+    f32x2v g[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
-    int cc = -1, kb = 0;
+      for (int b = 0; b < 3; ++b) g[a][b] = f32x2v{0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < DN_MAX_OPERANDS; ++s) {
-      if (s < p.n_in) {
-        const int C = p.in[s].C;
-        if (k >= kb && k < kb + C) cc = p.in[s].ch_off + (k - kb);
-        kb += (C + WKC - 1) / WKC * WKC;
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + h;
+      int cc = -1, kb = 0;
+#pragma unroll
+      for (int s = 0; s < DN_MAX_OPERANDS; ++s) {
+        if (s < p.n_in) {
+          const int C = p.in[s].C;
+          if (k >= kb && k < kb + C) cc = p.in[s].ch_off + (k - kb);
+          kb += (C + WKC - 1) / WKC * WKC;
+        }
+      }
+      if (n < p.Ntot && cc >= 0) {
+        const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + cc) : ((long long)cc * p.D1 + n)) * 9;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) g[aa][bb][h] = w[base + src_of[aa * 3 + bb]];
       }
     }
-    if (n < p.Ntot && cc >= 0) {
-      const long long base = (p.n_is_dim0 ? ((long long)n * p.D1 + cc) : ((long long)cc * p.D1 + n)) * 9;
-#pragma unroll
-      for (int aa = 0; aa < 3; ++aa)
-#pragma unroll
-        for (int bb = 0; bb < 3; ++bb) g[aa][bb] = w[base + src_of[aa * 3 + bb]];
-    }
-    float t4[4][3];
+    f32x2v t4[4][3];
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) {
-      const float g0 = g[0][bb], g1 = g[1][bb], g2 = g[2][bb];
+      const f32x2v g0 = g[0][bb], g1 = g[1][bb], g2 = g[2][bb];
       t4[0][bb] = g0;
       t4[1][bb] = 0.5f * (g0 + g1 + g2);
       t4[2][bb] = 0.5f * (g0 - g1 + g2);
       t4[3][bb] = g2;
     }
-    __bf16* dst = wp16 + ((((long long)kc16 * 16 * NS + nsub) * NSPL) * 64 + lane) * 8 + e;
+    __bf16* dst = wp16 + ((((long long)kc16 * 16 * NS + nsub) * NSPL) * 64 + lane) * 8 + 2 * e2;
     const long long posB = (long long)NS * NSPL * 64 * 8;     // elements between two positions
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float u[4];
+      f32x2v u[4];
       u[0] = t4[i][0];
       u[1] = 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]);
       u[2] = 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]);
       u[3] = t4[i][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        // the same three-piece split as wino_split3, two values at a time: piece = bf16(what the previous pieces left), exactly
+        const bf16x2v p0 = __builtin_convertvector(u[j], bf16x2v);
         if constexpr (NSPL == 1) {
-          dst[(4 * i + j) * posB] = (__bf16)u[j];
+          *reinterpret_cast<bf16x2v*>(dst + (4 * i + j) * posB) = p0;
         } else {
-          __bf16 pc[3];
-          wino_split3(u[j], pc);
-#pragma unroll
-          for (int sp = 0; sp < 3; ++sp) dst[(4 * i + j) * posB + sp * 512] = pc[sp];
+          const f32x2v r1 = u[j] - __builtin_convertvector(p0, f32x2v);
+          const bf16x2v p1 = __builtin_convertvector(r1, bf16x2v);
+          const f32x2v r2 = r1 - __builtin_convertvector(p1, f32x2v);
+          const bf16x2v p2 = __builtin_convertvector(r2, bf16x2v);
+          *reinterpret_cast<bf16x2v*>(dst + (4 * i + j) * posB) = p0;
+          *reinterpret_cast<bf16x2v*>(dst + (4 * i + j) * posB + 512) = p1;
+          *reinterpret_cast<bf16x2v*>(dst + (4 * i + j) * posB + 1024) = p2;
         }
       }
     }
@@ -286,7 +299,7 @@ int launch_wino_pack16_many(const PackEntry* tab_dev, int first, int n, int piec
 
 int launch_wino_pack16(const IgemmParams& p, const float* w, float* wp, int pieces, hipStream_t stream) {
   const long long total = wino_packed_elems(p);              // (n, k) pairs x 16 positions, as for the fp32 layout
-  int blocks = (int)(((total >> 4) + 255) / 256);
+  int blocks = (int)(((total >> 5) + 255) / 256);            // one thread per (n, k pair)
   if (blocks > 8192) blocks = 8192;
   if (pieces == 3) DN_LAUNCH(wino_pack16_kernel<3>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
   else DN_LAUNCH(wino_pack16_kernel<1>, dim3(blocks), dim3(256), 0, stream, p, w, wp, wino_npad(p) / 32, total);
