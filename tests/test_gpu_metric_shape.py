@@ -183,3 +183,85 @@ def test_dataparallel_wrapper_on_one_device_equals_the_bare_module():
         dp = torch.nn.DataParallel(net.to(DEV))
         dp.train()
         assert all(torch.equal(a, b) for a, b in zip(dp(x), res[False][1]))
+
+
+def test_config3_at_32x128x416_vs_oracle():
+    """configs[2] at the literal batch: Disp_vgg_BN + PoseExpNet + photometric warp loss + smoothness, 32 x 128 x 416, against the oracle on
+    the host CPU: both loss terms rtol 2e-4, the pose vectors rtol 1e-3, disparity samples, and gradients of both nets through grad_close
+    (the b2 test pins every tensor; here tensors spanning the warp -> pose path and the encoder / decoder at the benchmarked dispatch)."""
+    from cases import config3_inputs
+    from oracle import nets_res
+    tgt, refs, k, kinv = config3_inputs(B)
+    disp_net = models.Disp_vgg_BN(datasets="kitti", with_classifier=False)
+    detgen.fill_state_dict(disp_net.state_dict(), "vggbn")
+    dsd0 = {kk: v.clone() for kk, v in disp_net.state_dict().items()}
+    pose_net = models.PoseExpNet(nb_ref_imgs=2, output_exp=False)
+    detgen.fill_state_dict(pose_net.state_dict(), "posenet")
+    psd0 = {kk: v.clone() for kk, v in pose_net.state_dict().items()}
+    disp_net.to(DEV).train()
+    pose_net.to(DEV).train()
+    tg, rf = tgt.to(DEV), [r.to(DEV) for r in refs]
+    mask, pose = pose_net(tg, rf)
+    disps = disp_net(tg)
+    depth = [reciprocal(d) for d in disps]
+    l1 = LF.photometric_reconstruction_loss(tg, rf, k.to(DEV), kinv.to(DEV), depth, mask, pose, "euler", "zeros")
+    l3 = LF.smooth_loss(depth)
+    (l1 + 0.1 * l3).backward()
+    torch.cuda.synchronize()
+    dsd, psd = _oracle_params(dsd0), _oracle_params(psd0)
+    with _host_threads():
+        omask, opose = nets_res.pose_exp_net(psd, tgt, refs, False, training=True)
+        odisps = ON.disp_vgg_bn(dsd, tgt, training=True)
+        odepth = [1 / d for d in odisps]
+        ol1 = OL.photometric_reconstruction_loss(tgt, refs, k, kinv, odepth, omask, opose, "euler", "zeros")
+        ol3 = OL.smooth_loss(odepth)
+        (ol1 + 0.1 * ol3).backward()
+    np.testing.assert_allclose(l1.item(), ol1.item(), rtol=2e-4)
+    np.testing.assert_allclose(l3.item(), ol3.item(), rtol=2e-4)
+    close("pose", pose, opose, rtol=1e-3, atol_rel=1e-4)
+    for i, (d, od) in enumerate(zip(disps, odisps)):
+        close("disp%d[::97]" % i, d.detach().reshape(-1)[::97].cpu(), od.detach().reshape(-1)[::97], rtol=1e-3, atol_rel=1e-4)
+    dn = dict(disp_net.named_parameters())
+    for key in ("features.features.0.weight", "features.features.3.weight", "features.features.40.weight", "upconv4.0.weight", "iconv2.0.weight",
+                "iconv0.0.weight", "disp0.0.weight", "disp3.0.weight"):
+        grad_close("disp grad:" + key, dn[key].grad, dsd[key].grad)
+    pn = dict(pose_net.named_parameters())
+    for key in ("conv1.0.weight", "conv4.0.weight", "conv7.0.weight", "pose_pred.weight", "pose_pred.bias"):
+        grad_close("pose grad:" + key, pn[key].grad, psd[key].grad)
+
+
+def test_config4_at_16x480x640_vs_oracle():
+    """configs[3] at the literal batch: Disp_res_50 (7x7/2 stem, bottlenecks, residual tails, 3x3/2 transposed-convolution decoder) at
+    16 x 480 x 640 with the NYU loss against the oracle on the host CPU: loss rtol 2e-4, four disparity maps (every 997th element) rtol
+    2e-3, gradient tensors from the stem to the heads through grad_close, BatchNorm running statistics."""
+    from oracle import nets_res
+    b, h, w = 16, 480, 640
+    net = models.Disp_res_50(datasets="nyu")
+    detgen.fill_state_dict(net.state_dict(), "res50")
+    sd0 = {kk: v.clone() for kk, v in net.state_dict().items()}
+    net.to(DEV).train()
+    x = detgen.image_batch(b, h, w, "res50big:x")
+    gt = detgen.sparse_depth(b, h, w, "res50big:gt", density=0.6, lo=0.3, hi=11.0)
+    disps = net(x.to(DEV))
+    depth = [reciprocal(d) for d in disps]
+    loss = LF.l1_loss(gt.to(DEV), depth, "nyu") + 0.1 * LF.smooth_loss(depth)
+    loss.backward()
+    torch.cuda.synchronize()
+    osd = _oracle_params(sd0)
+    with _host_threads():
+        odisps = nets_res.disp_res_50(osd, x, training=True, datasets="nyu")
+        odepth = [1 / d for d in odisps]
+        oloss = OL.l1_loss(gt, odepth, "nyu") + 0.1 * OL.smooth_loss(odepth)
+        oloss.backward()
+    np.testing.assert_allclose(loss.item(), oloss.item(), rtol=2e-4)
+    for i, (d, od) in enumerate(zip(disps, odisps)):
+        assert tuple(d.shape) == tuple(od.shape)
+        close("disp%d[::997]" % i, d.detach().reshape(-1)[::997].cpu(), od.detach().reshape(-1)[::997], rtol=2e-3, atol_rel=2e-4)
+    named = dict(net.named_parameters())
+    for key in ("conv1.weight", "layer1.0.conv1.weight", "layer1.0.downsample.0.weight", "layer2.0.conv2.weight", "layer3.5.conv3.weight",
+                "layer4.2.conv2.weight", "layer4.2.bn3.weight", "upconv5.0.weight", "iconv5.0.weight", "iconv2.0.weight", "iconv1.0.weight",
+                "predict_disp1.0.weight", "predict_disp4.0.weight"):
+        grad_close("grad:" + key, named[key].grad, osd[key].grad)
+    sd1 = net.state_dict()
+    for key in ("bn1.running_mean", "bn1.running_var", "layer4.2.bn3.running_mean", "layer1.0.downsample.1.running_var"):
+        close(key, sd1[key], osd[key], rtol=1e-3, atol_rel=1e-4)
