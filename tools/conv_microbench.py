@@ -32,10 +32,11 @@ def main():
     for name in args.layers.split(","):
         if name in LAYERS:
             cin, cout, H, W, tr = LAYERS[name]
-        else:                                   # free form: c<cin>_<cout>_<H>x<W> / t<cin>_<cout>_<H>x<W>
+        else:                                   # free form: c<cin>_<cout>_<H>x<W> / t<cin>_<cout>_<H>x<W> / p<cin>_<cout>_<H>x<W> (1x1)
             a, b, hw = name[1:].split("_")
             cin, cout, (H, W), tr = int(a), int(b), map(int, hw.split("x")), name[0] == "t"
-        mod = (nn.ConvTranspose2d(cin, cout, 4, 2, 1) if tr else nn.Conv2d(cin, cout, 3, 1, 1)).to(dev)
+        k1 = name[0] == "p"                     # p<cin>_<cout>_<H>x<W>: a 1x1 convolution (ResNet bottleneck layers)
+        mod = (nn.ConvTranspose2d(cin, cout, 4, 2, 1) if tr else (nn.Conv2d(cin, cout, 1, 1, 0) if (name not in LAYERS and k1) else nn.Conv2d(cin, cout, 3, 1, 1))).to(dev)
         layer = engine.ConvLayer(mod, transposed=tr)
         x = engine.Act(torch.randn(args.batch, H, W, cin, device=dev), args.batch, H, W, cin)
         if args.affine:

@@ -12,14 +12,14 @@ for grp in "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum" "TA_BUFFER_TOTAL_CYCLES_sum 
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TD_TD_BUSY_sum TD_TC_STALL_sum" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 180 rocprofv3 --kernel-trace --pmc $grp -d $out/pass$i -o p --output-format csv -- python $R/tools/conv_microbench.py --reps 5 --layers $layers --what $what > $out/pass$i.log 2>&1 || echo "pass $i failed"
+  timeout 180 rocprofv3 --kernel-trace --pmc $grp -d $out/pass$i -o p --output-format csv -- python $R/tools/conv_microbench.py --reps 5 --batch ${BATCH:-32} --layers $layers --what $what > $out/pass$i.log 2>&1 || echo "pass $i failed"
 done
 else
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 180 rocprofv3 --kernel-trace --pmc $grp -d $out/pass$i -o p --output-format csv -- python $R/tools/conv_microbench.py --reps 5 --layers $layers --what $what > $out/pass$i.log 2>&1 || echo "pass $i failed"
+  timeout 180 rocprofv3 --kernel-trace --pmc $grp -d $out/pass$i -o p --output-format csv -- python $R/tools/conv_microbench.py --reps 5 --batch ${BATCH:-32} --layers $layers --what $what > $out/pass$i.log 2>&1 || echo "pass $i failed"
 done
 fi
 cd $R
