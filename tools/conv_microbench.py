@@ -63,6 +63,7 @@ def main():
             e0.record()
             for _ in range(args.reps):
                 run(kind)
+            engine.join_side_stream()          # (weight gradients run on the side streams: the timing stream has to wait for them)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
