@@ -51,6 +51,7 @@ struct Knobs {
   int wino_min_tiles;                    // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (192)
   int wino_splitk_target, wino_splitk_maxblocks;   // DN_WINO_SPLITK_TARGET (512 blocks) / _MAXBLOCKS (208): the 4-wave kernel's K split of small grids
   int pack_blocks;                       // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
+  int wino_nmajor;                       // DN_WINO_NMAJOR (1): Winograd forward/dgrad tile order within an XCD: 1 tile row fastest (one 64-cout weight slice per XCD), 0 cout slice fastest, 2/3 by slice count
   int wino_wg_target;                    // DN_WINO_WG_TARGET (0 = by rule: 128 for small layers, else 256): blocks per round the Winograd weight gradient's tile split aims at
   int wino8;                             // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel
 };
@@ -165,6 +166,7 @@ struct IgemmParams {
   float *bnb_dgamma, *bnb_dbeta;
   int* fold_cnt;                 // kFoldCounters zeroed, self-resetting ints: the last 256 bytes of dn_conv_desc.splitk_ws
   int fold_bn, fold_bnb;
+  int nmajor;                // Winograd tile order: q -> (mb, nb) = (q % MT, q / MT) instead of (q / NT, q % NT)
 };
 
 // floor(n / d) for 0 <= n < 2^31 with a precomputed magic (see fastdiv_magic); branch-free

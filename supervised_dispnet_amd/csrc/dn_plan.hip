@@ -105,6 +105,7 @@ static void read_knobs(Knobs* k) {
   k->no_x3_wgrad = on("DN_NO_X3_WGRAD");
   k->no_tap_windows = on("DN_NO_TAP_WINDOWS");
   k->wino_wg_target = num("DN_WINO_WG_TARGET", 0);
+  k->wino_nmajor = num("DN_WINO_NMAJOR", 1);
   k->wino8 = num("DN_WINO8", -1);
 }
 

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
   const int per = (MT * NT + 7) >> 3;
   const int q = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per || q >= MT * NT) return;
-  const int mb = q / NT, nb = q % NT;
+  const int mb = p.nmajor ? q % MT : q / NT, nb = p.nmajor ? q / MT : q % NT;
   // Input-channel split for small grids (p.ksplit > 1, three-piece variant; launch_wino_conv): blockIdx.y = kz takes the global 16-channel
   // chunks [g0, g1) of the K axis (the operands one after the other); the partial output tiles meet in a workspace and the block that
   // arrives last sums them in index order (deterministic) and runs the epilogue.  A 4-image shard of the metric's batch leaves the deep
@@ -1090,7 +1090,7 @@ __global__ void __launch_bounds__(256, MTW == 2 ? 1 : 2) wino_conv_kernel(const 
       const int MT2 = (p.T + BT - 1) / BT, NT2 = p.Npad / WBN;
       const int per2 = (MT2 * NT2 + 7) >> 3;
       const int q2 = (int)(bx & 7u) * per2 + (int)(bx >> 3);
-      wino_fold_tail(p, q2 % NT2, MT2, smem, (int)threadIdx.x);
+      wino_fold_tail(p, p.nmajor ? q2 / MT2 : q2 % NT2, MT2, smem, (int)threadIdx.x);
     }
   }
 }
@@ -1133,6 +1133,10 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.TW = p.OW / 2;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
+  {   // tile order within an XCD (DN_WINO_NMAJOR: 0 cout slice fastest, 1 tile row fastest, 2/3: tile row fastest from 4 / 8 cout slices)
+    const int nm = knobs().wino_nmajor, nt = p.Npad / WBN;
+    p.nmajor = nm == 1 || (nm == 2 && nt >= 4) || (nm == 3 && nt >= 8);
+  }
   p.fold_bn = wino_folds_bn_finalize(p) ? 1 : 0;
   p.fold_bnb = wino_folds_bn_sums(p) ? 1 : 0;
   const int dbg = knobs().wino_dbg;

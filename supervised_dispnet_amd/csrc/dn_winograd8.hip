@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     if ((int)(blockIdx.x >> 3) >= per || q >= nreg) return;
   }
   const bool split_tile = g1 != 0x7fffffff;
-  const int mb = q / NT, nb = q % NT;
+  const int mb = p.nmajor ? q % MT : q / NT, nb = p.nmajor ? q / MT : q % NT;
   long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, te1 = 0, te2 = 0;
   if (DBG & 4) t0 = clock64();
 

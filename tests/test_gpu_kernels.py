@@ -760,7 +760,7 @@ def test_winograd8_tail_split_of_the_last_partial_round(case):
         engine.SPLITK = prev
     assert "wino_conv8_kernel" in res[True][3] and res[True][3] == res[False][3], res[True][3]
     ys, yn = res[True][0], res[False][0]
-    differs = (ys != yn).reshape(N * H * W, cout).any(dim=1)
+    differs = (ys != yn).reshape(N * H * W, cout // 64, 64).any(dim=2)      # per (pixel, 64-channel slice): the unit a block owns
     frac = float(differs.float().mean())
     assert 0.05 < frac <= 0.21, frac                 # only the tail (64 of 320 blocks = 20 % of the output) sees other summation cuts
     assert float((ys - yn).abs().max()) <= 2e-5 * float(yn.abs().max())

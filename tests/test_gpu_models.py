@@ -780,7 +780,7 @@ def test_heads_emit_the_reciprocal_with_the_disparity():
 _SWITCH_CASES = [("DN_NO_WINOGRAD", "1"), ("DN_NO_WINOGRAD_WGRAD", "1"), ("DN_NO_DIRECT", "1"), ("DN_NO_THIN", "1"), ("DN_NO_THIN_CONV", "1"),
                  ("DN_NO_LDS3", "1"), ("DN_NO_SPLITK", "1"), ("DN_NO_WINO_SPLITK", "1"), ("DN_NO_X3_SPLITK", "1"), ("DN_NO_WINO8_TAIL", "1"),
                  ("DN_NO_X3_DIRECT", "1"), ("DN_NO_X3_WGRAD", "1"), ("DN_NO_TAP_WINDOWS", "1"), ("DN_WINO_WGW", "0"), ("DN_WINO8", "0"),
-                 ("DN_WINO8", "1"), ("DN_WINO_MIN_TILES", "100000"), ("DN_WINO_SPLITK_TARGET", "256"), ("DN_WINO_WG_TARGET", "64"),
+                 ("DN_WINO8", "1"), ("DN_WINO_MIN_TILES", "100000"), ("DN_WINO_SPLITK_TARGET", "256"), ("DN_WINO_WG_TARGET", "64"), ("DN_WINO_NMAJOR", "0"),
                  ("engine.FOLD_FINALIZE", False), ("engine.BN_SUMS_FUSION", False), ("engine.WGRAD_STREAM", False)]
 
 
