@@ -315,6 +315,35 @@ def build_workload(cfg, batch, dev, seed, models, LF, U, reciprocal, FusedAdam):
     return step, opt, state, desc
 
 
+def tape_host_profile(taped, dev):
+    """Where the host spends a replay (stderr): per-op host time of three replays, each started on an idle device."""
+    import ctypes as C
+    from supervised_dispnet_amd import _lib
+    lib = _lib.load()
+    cap = int(taped.launches + taped.fences + 16)
+    ns, names = (C.c_int64 * cap)(), (C.c_char_p * cap)()
+    for rep in range(3):
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(taped._stream):
+            n = lib.dn_tape_replay_timed(taped.tape, ns, names, cap)
+        torch.cuda.synchronize(dev)
+        if n < 0:
+            print("[tape-host-profile] replay failed: %s" % _lib.last_error(), file=sys.stderr)
+            return
+        rows = [(ns[i] / 1e3, i, (names[i] or b"?").decode()[:70]) for i in range(min(n, cap))]
+        tot = sum(r[0] for r in rows)
+        fences = [r for r in rows if r[2] == "fence"]
+        cum, marks = 0.0, []
+        for r in rows:
+            cum += r[0]
+            if r[1] % 20 == 0:
+                marks.append("#%d@%.0f" % (r[1], cum))
+        print("[tape-host-profile] replay %d: %d ops, host %.1f us (launches %.1f us, %d fences %.1f us); cumulative us at op: %s"
+              % (rep, n, tot, tot - sum(r[0] for r in fences), len(fences), sum(r[0] for r in fences), " ".join(marks)), file=sys.stderr)
+        for us, i, nm in sorted(rows, reverse=True)[:12]:
+            print("[tape-host-profile]    op %3d %8.1f us  %s" % (i, us, nm), file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,6 +399,14 @@ def main():
     ap.add_argument("--no-fold", action="store_true",
                     help="A/B: run dn_bn_finalize / the BatchNorm-backward sums as launches of their own instead of in the last-arriving block "
                          "of the Winograd kernels (engine.FOLD_FINALIZE; same bits either way)")
+    ap.add_argument("--system-fences", action="store_true",
+                    help="A/B: the launch tape's fences between the main and the weight-gradient streams with the system-scope release HIP events "
+                         "carry by default (engine.DEVICE_SCOPE_FENCES = False)")
+    ap.add_argument("--tape-join-every-step", action="store_true",
+                    help="A/B: every replay makes the caller's stream wait for the tape's (graph.TapedStep's default; bench.py reads nothing "
+                         "between steps and joins once after the timed loop)")
+    ap.add_argument("--tape-host-profile", action="store_true",
+                    help="after the timed region: host time of every launch / fence of three replays (dn_tape_replay_timed), the slowest to stderr")
     ap.add_argument("--watchdog-s", type=float, default=0.0,
                     help="N > 1: if the line has not been printed after this many seconds (default 900 at N > 1, 0 = off at N = 1) rank 0 "
                          "prints a line with value null and the reason, and every rank exits non-zero")
@@ -413,6 +450,8 @@ def main():
     from supervised_dispnet_amd.optim import FusedAdam
 
     engine.set_compute(args.compute)
+    if args.system_fences:
+        engine.DEVICE_SCOPE_FENCES = False
     if args.no_fold:
         engine.FOLD_FINALIZE = False
     if args.wgrad_streams > 0:
@@ -471,7 +510,7 @@ def main():
         for _ in range(2):
             eager_step()
         try:
-            taped = TapedStep(eager_step, optimizer=opt, warmup=2).capture()
+            taped = TapedStep(eager_step, optimizer=opt, warmup=2, lazy_join=not args.tape_join_every_step).capture()
             step = taped
             if args.tape_verify == "1":
                 # one replay against one eager step from the same parameters / moments / counters / BatchNorm buffers, bit for bit
@@ -504,10 +543,15 @@ def main():
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    marks[0].record()
+    mark_stream = taped._stream if (taped is not None and taped.lazy_join) else torch.cuda.current_stream()     # where the step's work is
+    if mark_stream != torch.cuda.current_stream():
+        mark_stream.wait_stream(torch.cuda.current_stream())
+    marks[0].record(mark_stream)
     for i in range(args.steps):
         loss = step()
-        marks[i + 1].record()
+        marks[i + 1].record(mark_stream)
+    if taped is not None:
+        taped.join()
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -572,6 +616,9 @@ def main():
         engine.GradSink.reducer = reducer
         del wstep, wopt, wstate, wred
         torch.cuda.synchronize()
+
+    if args.tape_host_profile and taped is not None and rank == 0:
+        tape_host_profile(taped, dev)
 
     # ---- instrumented steps (not part of `value`): HIP events around every conv-family launch and every HBM-bound family
     roofline = roofline_hbm = None
@@ -686,6 +733,7 @@ def main():
                        "launch": ("one hipGraph replay per step" if graphed else
                                   ("launch tape: %d launches + %d stream fences of one recorded step re-issued by dn_tape_replay, %d segment(s)"
                                    % (taped.launches, taped.fences, taped.segments)) if taped is not None else "eager launches"),
+                       "tape_replay_host_ms": (round(taped.host_s / max(taped.replays, 1) * 1e3, 4) if taped is not None else None),
                        "tape_verified": (None if tape_verified is None else
                                          ("replay == eager step, bit for bit" if tape_verified[0] else "MISMATCH: max |diff| %.3g" % tape_verified[1])),
                        "graph_fallback": graph_note, "adam": "per bucket, under the backward pass" if overlap_adam else "one pass after the backward",

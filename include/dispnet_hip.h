@@ -521,6 +521,10 @@ int dn_copy(const float* src, float* dst, int64_t n, dn_stream_t stream);
  * same buffers), that the recorded streams exist, and that NO work the step needs was done outside this library while recording.
  *   dn_tape_fence(tape, waiter, waitee)  record "waiter waits for everything enqueued on waitee so far" (event record + stream wait at
  *                                        replay; does nothing now -- the caller fences the live run itself)
+ *   dn_tape_fence_device(...)            the same between two streams whose work stays on THIS device (the engine's main and weight-gradient
+ *                                        streams): the event is created without the system-scope fence (hipEventDisableSystemFence), which
+ *                                        costs the recording stream's queue 2.3-5.9 us instead of 4.5-8.5 (tools/ubench/fence_cost.hip).  NOT for
+ *                                        a stream whose results another GPU or the host reads (the communication stream)
  *   dn_tape_mark(tape)                   cut: returns the number of the segment that starts here; the caller replays segment by
  *                                        segment and does its own host work in between (a gradient bucket's all-reduce)
  *   dn_tape_pause(tape, 1 / 0)           launches in between are executed but not recorded (such host work, when it is live at replay)
@@ -530,11 +534,13 @@ void* dn_tape_begin(void);
 int dn_tape_end(void* tape);
 int dn_tape_pause(void* tape, int32_t paused);
 int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee);
+int dn_tape_fence_device(void* tape, dn_stream_t waiter, dn_stream_t waitee);
 int32_t dn_tape_mark(void* tape);
 int32_t dn_tape_segments(void* tape);
 int64_t dn_tape_launches(void* tape);
 int64_t dn_tape_fences(void* tape);
 int dn_tape_replay(void* tape, int32_t segment);
+int32_t dn_tape_replay_timed(void* tape, int64_t* host_ns, const char** name, int32_t cap);   /* diagnostics: host time of every op of one replay */
 void dn_tape_free(void* tape);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -25,13 +25,13 @@ static inline hipStream_t as_stream(dn_stream_t s) { return reinterpret_cast<hip
 // memory pool and replays into the same buffers).
 struct LaunchTape;
 extern std::atomic<LaunchTape*> g_tape_rec;          // the tape being recorded, or nullptr
-void tape_push(LaunchTape* t, std::function<void()>&& op);
+void tape_push(LaunchTape* t, std::function<void()>&& op, const void* kernel);
 
 template <typename... KArgs, typename... Args>
 static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
   kernel<<<grid, block, lds, stream>>>(args...);
   if (LaunchTape* t = g_tape_rec.load(std::memory_order_relaxed))
-    tape_push(t, [=]() { kernel<<<grid, block, lds, stream>>>(args...); });
+    tape_push(t, [=]() { kernel<<<grid, block, lds, stream>>>(args...); }, reinterpret_cast<const void*>(kernel));
 }
 #define DN_LAUNCH(...) ::dn::launch(__VA_ARGS__)
 

@@ -9,6 +9,7 @@
 // A tape holds, in issue order: kernel launches (closure over kernel, grid, block, LDS bytes, stream, by-value arguments), stream
 // fences (record an event on one stream, make another wait for it) and marks.  Marks cut the tape into segments: the caller replays
 // segment by segment and does its own host work in between (a gradient bucket's all-reduce on another library's communicator).
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -18,6 +19,7 @@ namespace dn {
 
 struct LaunchTape {
   std::vector<std::function<void()>> ops;
+  std::vector<const void*> what;       // per op: the kernel's host function (dn_tape_replay_timed names it), nullptr for a fence
   std::vector<size_t> marks;           // ops.size() at each dn_tape_mark
   std::vector<hipEvent_t> events;
   std::mutex mu;                       // forward is recorded on the caller's thread, backward on autograd's
@@ -26,9 +28,10 @@ struct LaunchTape {
 
 std::atomic<LaunchTape*> g_tape_rec{nullptr};
 
-void tape_push(LaunchTape* t, std::function<void()>&& op) {
+void tape_push(LaunchTape* t, std::function<void()>&& op, const void* kernel) {
   std::lock_guard<std::mutex> lock(t->mu);
   t->ops.emplace_back(std::move(op));
+  t->what.push_back(kernel);
   ++t->launches;
 }
 
@@ -71,14 +74,14 @@ int dn_tape_pause(void* tape, int32_t paused) {
   return DN_OK;
 }
 
-int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee) {
+static int tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee, unsigned flags) {
   dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
   if (t == nullptr || dn::g_tape_rec.load() != t) {
     dn::set_error("dn_tape_fence: this tape is not being recorded");
     return DN_ERR_BAD_ARG;
   }
   hipEvent_t ev;
-  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  hipError_t e = hipEventCreateWithFlags(&ev, flags);
   if (e != hipSuccess) {
     dn::set_error("dn_tape_fence: hipEventCreate: %s", hipGetErrorString(e));
     return DN_ERR_LAUNCH;
@@ -90,8 +93,17 @@ int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee) {
     (void)hipEventRecord(ev, s);
     (void)hipStreamWaitEvent(w, ev, 0);
   });
+  t->what.push_back(nullptr);
   ++t->fences;
   return DN_OK;
+}
+
+int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee) { return tape_fence(tape, waiter, waitee, hipEventDisableTiming); }
+
+// Both streams' work stays on this device: no system-scope release at the event (tools/ubench/fence_cost.hip: the recording stream's queue
+// loses 2.3-5.9 us per fence instead of 4.5-8.5; a 4-image step records ~60 of them on its critical stream).
+int dn_tape_fence_device(void* tape, dn_stream_t waiter, dn_stream_t waitee) {
+  return tape_fence(tape, waiter, waitee, hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
 int32_t dn_tape_mark(void* tape) {
@@ -135,6 +147,29 @@ int dn_tape_replay(void* tape, int32_t segment) {
   const size_t hi = (segment == -1 || segment == nseg - 1) ? t->ops.size() : t->marks[segment];
   for (size_t i = lo; i < hi; ++i) t->ops[i]();
   return dn::check_launch("dn_tape_replay");
+}
+
+// Diagnostics: replay the whole tape and report the HOST time of every op (ns[i]) and what it is (name[i]: the kernel's name, "fence" for
+// a fence; pointers valid while the library is loaded).  Returns the number of ops (<= cap are reported).  A launch that takes the host
+// tens of microseconds is one the runtime blocked in (tools/tape_host_profile.py).
+int32_t dn_tape_replay_timed(void* tape, int64_t* ns, const char** name, int32_t cap) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  if (t == nullptr || dn::g_tape_rec.load() == t) {
+    dn::set_error("dn_tape_replay_timed: null tape, or the tape is still being recorded");
+    return -1;
+  }
+  const size_t n = t->ops.size();
+  for (size_t i = 0; i < n; ++i) {
+    const auto t0 = std::chrono::steady_clock::now();
+    t->ops[i]();
+    const auto t1 = std::chrono::steady_clock::now();
+    if ((int32_t)i < cap) {
+      ns[i] = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+      name[i] = t->what[i] != nullptr ? hipKernelNameRefByPtr(t->what[i], nullptr) : "fence";
+    }
+  }
+  if (dn::check_launch("dn_tape_replay_timed") != DN_OK) return -1;
+  return (int32_t)n;
 }
 
 void dn_tape_free(void* tape) {

@@ -122,13 +122,17 @@ def side_stream():
 # While it is set, every fence between two streams is also put on the tape (stream_wait), and tensors a second stream reads are kept
 # alive instead of relying on the caching allocator's event-guarded reuse (whose timing the replay cannot reproduce).
 TAPE = None
+DEVICE_SCOPE_FENCES = True      # A/B: bench.py --system-fences
 
 
-def stream_wait(waiter, waitee):
-    """waiter.wait_stream(waitee), also recorded on the launch tape when one is being recorded."""
+def stream_wait(waiter, waitee, device_scope=False):
+    """waiter.wait_stream(waitee), also recorded on the launch tape when one is being recorded.  device_scope: both are compute streams
+    of this device (main / weight-gradient side streams) -- the tape's event then carries no system-scope fence (dn_tape_fence_device:
+    2-3 us less of the recording stream's queue per fence, ~60 fences in a step); never for work another GPU or the host reads."""
     waiter.wait_stream(waitee)
     if TAPE is not None and not TAPE.get("paused"):
-        _lib.call("dn_tape_fence", TAPE["handle"], waiter.cuda_stream, waitee.cuda_stream)
+        _lib.call("dn_tape_fence_device" if (device_scope and DEVICE_SCOPE_FENCES) else "dn_tape_fence", TAPE["handle"], waiter.cuda_stream,
+                  waitee.cuda_stream)
 
 
 def tape_host_call(fn):
@@ -182,7 +186,7 @@ def join_side_stream():
         if st is not None:
             cur = torch.cuda.current_stream()
             for x in st["sides"]:
-                stream_wait(cur, x)
+                stream_wait(cur, x, device_scope=True)
 
 
 def compute_streams():
@@ -667,7 +671,7 @@ class PackTable(object):
         if self.late_table is not None:
             st = side_stream()
             main, side = torch.cuda.current_stream(), st["side"]
-            stream_wait(side, main)                  # the optimizer step that produced these weights
+            stream_wait(side, main, device_scope=True)   # the optimizer step that produced these weights
             _lib.call("dn_pack_many", self.late_table.data_ptr(), *self.late_counts, side.cuda_stream)
             self.pending = (side, main)
         self.epoch = epoch
@@ -680,7 +684,7 @@ class PackTable(object):
         h = _stream()
         if h == side.cuda_stream:
             return                                   # (stream order; the main stream's first consumer still has to wait)
-        stream_wait(main if h == main.cuda_stream else torch.cuda.current_stream(), side)
+        stream_wait(main if h == main.cuda_stream else torch.cuda.current_stream(), side, device_scope=True)
         self.pending = None
 
 
@@ -812,7 +816,7 @@ def conv_wgrad(layer, pieces, dy, out_hw, out=None, sink=None, first=None):
     side = st["sides"][st["rr"] % min(len(st["sides"]), max(1, SIDE_STREAMS_ACTIVE))]   # weight gradients of successive layers alternate between the side streams
     st["rr"] += 1
     st["main"] = main
-    stream_wait(side, main)                      # dy, the operands and the bias / BatchNorm gradients of this layer are ready
+    stream_wait(side, main, device_scope=True)   # dy, the operands and the bias / BatchNorm gradients of this layer are ready
     with stream_scope(side):
         if first is not None:
             fresh = first[0]()

@@ -18,6 +18,7 @@ Multi-rank: the gradient all-reduce (RCCL via torch.distributed) is capturable b
 exercised on this one-GPU pool, so callers decide (bench.py: --graph auto = single-rank only).
 """
 import os
+import time
 
 import torch
 
@@ -91,12 +92,18 @@ class TapedStep(object):
     Host work between launches that must ALSO happen at replay (a gradient bucket's all-reduce on torch.distributed) is registered
     with engine.tape_host_call(fn): the tape is cut there and `fn` runs live between the segments, on the tape's stream."""
 
-    def __init__(self, step, optimizer=None, warmup=3, static_inputs=()):
+    def __init__(self, step, optimizer=None, warmup=3, static_inputs=(), lazy_join=False):
         self.step = step
+        # lazy_join: a replay does NOT make the caller's stream wait for the tape's stream; the caller calls join() before it reads the
+        # outputs (or anything else the step wrote) on its own stream.  Back-to-back replays then follow each other on the tape's stream
+        # without the round trip through the caller's stream (record on the tape's stream -> wait on the caller's -> record there -> wait
+        # on the tape's: ~25 us of idle device between two steps, tools/step_gaps.py).
+        self.lazy_join = lazy_join
         self.inputs = tuple(static_inputs)
         self.out = None
         self.tape = None
         self.host_calls = []
+        self.host_s, self.replays = 0.0, 0          # host time spent re-issuing, replays so far
         if optimizer is not None and hasattr(optimizer, "capturable"):
             optimizer.capturable(True)
         self._stream = torch.cuda.Stream()
@@ -164,6 +171,7 @@ class TapedStep(object):
         s = self._stream
         cur = torch.cuda.current_stream()
         s.wait_stream(cur)                # the caller's writes into the static inputs
+        t_host = time.perf_counter()
         if not self.host_calls:
             rc = self._lib.dn_tape_replay(self.tape, -1)
         else:
@@ -179,9 +187,17 @@ class TapedStep(object):
         if rc != 0:
             from . import _lib
             raise _lib.DispnetHipError("dn_tape_replay failed (%d): %s" % (rc, _lib.last_error()))
-        cur.wait_stream(s)
+        self.host_s += time.perf_counter() - t_host     # host time of the re-issue (bench.py reports it per step)
+        self.replays += 1
+        if not self.lazy_join:
+            cur.wait_stream(s)
         engine.bump_param_epoch()         # the replayed optimizer changed the weights: eager code that follows re-lays its packed copies
         return self.out
+
+    def join(self):
+        """The caller's current stream waits for everything replayed so far (needed with lazy_join before the outputs are read there)."""
+        if self.tape is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
 
     def verify(self, state):
         """Replay once and run the SAME step eagerly once from the same state (`state`: the tensors the step reads and updates --
@@ -195,6 +211,7 @@ class TapedStep(object):
         torch.cuda.synchronize()
         before = [t.clone() for t in state]
         out = self()
+        self.join()
         outs_r = [o.clone() for o in (out if isinstance(out, (tuple, list)) else (out,))]
         torch.cuda.synchronize()
         after_r = [t.clone() for t in state]

@@ -226,6 +226,60 @@ def test_adam_per_bucket_under_the_backward_pass_is_bitwise_the_single_update(ta
     assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)
 
 
+def test_launch_tape_lazy_join_runs_replays_back_to_back_and_joins_on_demand():
+    """TapedStep(lazy_join=True): a replay does not make the caller's stream wait for the tape's (bench.py: ~25 us of idle device between
+    two steps saved); join() does.  Four steps on changing batches written into the static inputs on the CALLER's stream: losses (read
+    after join()), parameters and Adam moments equal the eager steps' bit for bit -- the input fence in front of every replay still orders
+    the caller's copies before the step, and the fences between the compute streams are device-scope events (dn_tape_fence_device)."""
+    from supervised_dispnet_amd.graph import TapedStep, backward
+    batches = [bench.synthetic_batch(4, 64, 96, DEV, seed) for seed in range(4)]
+    net_a, opt_a = _make()
+    sd0 = copy.deepcopy({k: v.detach().cpu().clone() for k, v in net_a.state_dict().items()})
+    net_b, opt_b = _make(sd0)
+    opt_a.capturable(True)
+    img, gt = batches[0][0].clone(), batches[0][1].clone()
+
+    def step_a(x, y):
+        depth = [reciprocal(d) for d in net_a(x)]
+        loss = LF.l1_loss(y, depth, "kitti")
+        opt_a.zero_grad()
+        backward(loss)
+        opt_a.step()
+        return loss
+
+    def step_b():
+        depth = [reciprocal(d) for d in net_b(img)]
+        loss = LF.l1_loss(gt, depth, "kitti")
+        opt_b.zero_grad()
+        backward(loss)
+        opt_b.step()
+        return loss
+
+    f = TapedStep(step_b, optimizer=opt_b, warmup=0, static_inputs=(img, gt), lazy_join=True).capture()     # the recorded step: batch 0
+    assert f.lazy_join and f.fences > 0
+    la = [step_a(*batches[0]).clone()]
+    lb = []
+    for x, y in batches[1:]:
+        img.copy_(x)                    # on the caller's stream; the replay's input fence orders it
+        gt.copy_(y)
+        out = f()
+        f.join()
+        lb.append(out.clone())
+        la.append(step_a(x, y).clone())
+    # back to back, one join at the end
+    for x, y in batches[:2]:
+        img.copy_(x)
+        gt.copy_(y)
+        out = f()
+        step_a(x, y)
+    f.join()
+    torch.cuda.synchronize()
+    for u, v in zip(la[1:], lb):
+        assert torch.equal(u, v)
+    assert torch.equal(opt_a.arena.flat_p, opt_b.arena.flat_p)
+    assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)
+
+
 def test_launch_tape_refuses_framework_side_device_work_and_recovers():
     """A step that does device work outside libdispnet_hip while a tape is recorded (here: a gradient seeded into an activation that
     already holds one -- an ATen add) fails the recording loudly instead of producing a tape that would silently skip it; the recording

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--layers", default=",".join(LAYERS))
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--affine", action="store_true", help="give the input a pending BatchNorm-apply + ReLU (forward / wgrad loaders)")
+    ap.add_argument("--stats", action="store_true", help="forward: also write the BatchNorm partial statistics (the encoder's convolutions)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in args.layers.split(","):
@@ -49,7 +50,7 @@ def main():
         flops = 2 * layer.macs(args.batch, H, W, OH, OW)
         def run(kind):
             if kind == "fwd":
-                engine.conv_forward(layer, pieces)
+                engine.conv_forward(layer, pieces, bn_stats=args.stats)
             elif kind == "dgrad":
                 x.grad = None
                 engine.conv_dgrad(layer, dy, args.batch, OH, OW, pieces, (H, W))

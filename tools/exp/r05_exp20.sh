@@ -1,0 +1,15 @@
+#!/bin/bash
+mkdir -p gpurun_out
+exec < /dev/null
+R=$(pwd)
+{
+for B in 4 8; do
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_g; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_g -- python $R/bench.py --batch $B --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0 --alt-steps 0 > /tmp/g.json 2>/tmp/g.err
+cd $R
+f=$(find /tmp/prof_g -name '*kernel_trace.csv' | head -1)
+echo "== batch $B"; grep '^{' /tmp/g.json | python -c "import sys,json; j=json.loads(sys.stdin.readline()); print(j['ms_per_step'])"
+python tools/step_gaps.py $f 3 | tail -32
+done
+} > gpurun_out/r05_exp20.txt 2>&1
+tail -70 gpurun_out/r05_exp20.txt

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One training step out of a rocprofv3 --kernel-trace CSV as a timeline: start offset, duration, queue, grid, kernel -- plus per-queue busy
 time and the idle time of the union.  The step is the span between two consecutive adam_kernel launches near the end of the trace.
-usage: python tools/step_timeline.py <kernel_trace.csv> [steps-from-end]"""
+usage: python tools/step_timeline.py <kernel_trace.csv> [steps-from-end | 0 = the median step of the last 20]"""
 import csv
 import sys
 
@@ -9,7 +9,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-a, b = idx[-back], idx[-back + 1]
+if back > 0:
+    a, b = idx[-back], idx[-back + 1]
+else:                                   # 0: the step of median length among the last 20 (a one-off stall does not end up as "the" timeline)
+    spans = sorted((int(rows[y]["End_Timestamp"]) - int(rows[x]["End_Timestamp"]), x, y) for x, y in zip(idx[-21:-1], idx[-20:]))
+    _, a, b = spans[len(spans) // 2]
 step = rows[a + 1:b + 1]
 t0 = int(rows[a]["End_Timestamp"])
 queues = {}
