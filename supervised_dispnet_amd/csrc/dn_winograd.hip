@@ -1133,9 +1133,10 @@ int launch_wino_conv(IgemmParams& p, hipStream_t stream) {
   p.TW = p.OW / 2;
   p.mTW = fastdiv_magic((unsigned)p.TW);
   p.mTH = fastdiv_magic((unsigned)p.TH);
-  {   // tile order within an XCD (DN_WINO_NMAJOR: 0 cout slice fastest, 1 tile row fastest, 2/3: tile row fastest from 4 / 8 cout slices)
+  {   // tile order within an XCD (DN_WINO_NMAJOR: 0 cout slice fastest, 1 tile row fastest, 2/3: tile row fastest from 4 / 8 cout slices).
+      // Three-piece kernels only: the bf16-rounded and fp32-instruction variants came out 0.2-0.6 % slower with it (profiles/r05_exp28)
     const int nm = knobs().wino_nmajor, nt = p.Npad / WBN;
-    p.nmajor = nm == 1 || (nm == 2 && nt >= 4) || (nm == 3 && nt >= 8);
+    p.nmajor = p.compute == DN_COMPUTE_F32X3 && (nm == 1 || (nm == 2 && nt >= 4) || (nm == 3 && nt >= 8));
   }
   p.fold_bn = wino_folds_bn_finalize(p) ? 1 : 0;
   p.fold_bnb = wino_folds_bn_sums(p) ? 1 : 0;

@@ -20,7 +20,7 @@ done
 [ -f gpurun_out/bench_default_${tag}.json ] && cp gpurun_out/bench_default_${tag}.json profiles/${tag}_bench_default.json
 [ -f gpurun_out/bench_${tag}_res50_480_per_layer.txt ] && grep -v amdgpu.ids gpurun_out/bench_${tag}_res50_480_per_layer.txt > profiles/${tag}_res50_480_per_layer.txt
 [ -f gpurun_out/tests_${tag}.log ] && tail -5 gpurun_out/tests_${tag}.log > profiles/${tag}_gpu_tests.txt
-for f in b4_timeline b4_trace_summary; do [ -f gpurun_out/timeline_${tag}/$f.txt ] && cp gpurun_out/timeline_${tag}/$f.txt profiles/${tag}_$f.txt; done
+for f in b4_timeline b4_trace_summary b4_step_gaps; do [ -f gpurun_out/timeline_${tag}/$f.txt ] && cp gpurun_out/timeline_${tag}/$f.txt profiles/${tag}_$f.txt; done
 [ -f gpurun_out/sq_${tag}_wino8.txt ] && cp gpurun_out/sq_${tag}_wino8.txt profiles/${tag}_sq_counters_wino8_raw.txt
 [ -f gpurun_out/sq_${tag}_wino64.txt ] && cp gpurun_out/sq_${tag}_wino64.txt profiles/${tag}_sq_counters_wino64_raw.txt
 ls -la profiles | grep $tag

@@ -8,5 +8,6 @@ rm -rf /tmp/prof_b4; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_b
 cd $GRAFT_REPO_ROOT
 f=$(find /tmp/prof_b4 -name '*kernel_trace.csv' | head -1)
 python tools/trace_gaps.py $f 0.5 > $out/b${B}_trace_summary.txt
-python tools/step_timeline.py $f 3 > $out/b${B}_timeline.txt
+python tools/step_timeline.py $f 0 > $out/b${B}_timeline.txt
+python tools/step_gaps.py $f 3 | tail -20 > $out/b${B}_step_gaps.txt
 tail -4 $out/b${B}_timeline.txt
