@@ -731,8 +731,8 @@ def main():
             "config": {"workload": "%s, batch %d per GPU" % (desc, batch), "name": args.config, "global_batch": batch * world,
                        "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "launch": ("one hipGraph replay per step" if graphed else
-                                  ("launch tape: %d launches + %d stream fences of one recorded step re-issued by dn_tape_replay, %d segment(s)"
-                                   % (taped.launches, taped.fences, taped.segments)) if taped is not None else "eager launches"),
+                                  ("launch tape: %d launches + %d stream fences (%d as the stop event of the launch in front) of one recorded step re-issued by dn_tape_replay, %d segment(s)"
+                                   % (taped.launches, taped.fences, taped.riding_fences, taped.segments)) if taped is not None else "eager launches"),
                        "tape_replay_host_ms": (round(taped.host_s / max(taped.replays, 1) * 1e3, 4) if taped is not None else None),
                        "tape_verified": (None if tape_verified is None else
                                          ("replay == eager step, bit for bit" if tape_verified[0] else "MISMATCH: max |diff| %.3g" % tape_verified[1])),

@@ -524,7 +524,9 @@ int dn_copy(const float* src, float* dst, int64_t n, dn_stream_t stream);
  *   dn_tape_fence_device(...)            the same between two streams whose work stays on THIS device (the engine's main and weight-gradient
  *                                        streams): the event is created without the system-scope fence (hipEventDisableSystemFence), which
  *                                        costs the recording stream's queue 2.3-5.9 us instead of 4.5-8.5 (tools/ubench/fence_cost.hip).  NOT for
- *                                        a stream whose results another GPU or the host reads (the communication stream)
+ *                                        a stream whose results another GPU or the host reads (the communication stream).  When the last thing
+ *                                        recorded on `waitee` is a kernel launch, the event is re-issued as that launch's STOP event
+ *                                        (hipExtLaunchKernel) -- the dispatch's own completion signal, no marker packet behind the kernel
  *   dn_tape_mark(tape)                   cut: returns the number of the segment that starts here; the caller replays segment by
  *                                        segment and does its own host work in between (a gradient bucket's all-reduce)
  *   dn_tape_pause(tape, 1 / 0)           launches in between are executed but not recorded (such host work, when it is live at replay)
@@ -539,6 +541,7 @@ int32_t dn_tape_mark(void* tape);
 int32_t dn_tape_segments(void* tape);
 int64_t dn_tape_launches(void* tape);
 int64_t dn_tape_fences(void* tape);
+int64_t dn_tape_riding_fences(void* tape);   /* of those: device-scope fences that became the stop event of the launch in front of them */
 int dn_tape_replay(void* tape, int32_t segment);
 int32_t dn_tape_replay_timed(void* tape, int64_t* host_ns, const char** name, int32_t cap);   /* diagnostics: host time of every op of one replay */
 void dn_tape_free(void* tape);

@@ -13,7 +13,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 # ABI version this binding was written against (include/dispnet_hip.h: dn_version(), bumped on any signature / struct change).
 # load() refuses a library that reports anything else: a stale .so (DISPNET_HIP_LIB, a build that did not re-run) would otherwise
 # read struct fields past the end of what this binding fills in and mis-marshal arguments -- silent memory corruption, not an error.
-EXPECTED_ABI = 15
+EXPECTED_ABI = 16
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
@@ -173,6 +173,7 @@ SIGNATURES = {
     "dn_tape_segments": (_i32, [_vp]),
     "dn_tape_launches": (_i64, [_vp]),
     "dn_tape_fences": (_i64, [_vp]),
+    "dn_tape_riding_fences": (_i64, [_vp]),
     "dn_tape_replay_timed": (_i32, [_vp, _vp, _vp, _i32]),
     "dn_tape_replay": (C.c_int, [_vp, _i32]),
     "dn_tape_free": (None, [_vp]),

@@ -1,11 +1,14 @@
 // Internal declarations shared by the HIP translation units of libdispnet_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
 #include <atomic>
 #include <functional>
+#include <tuple>
+#include <type_traits>
 
 #include "dispnet_hip.h"
 
@@ -25,13 +28,27 @@ static inline hipStream_t as_stream(dn_stream_t s) { return reinterpret_cast<hip
 // memory pool and replays into the same buffers).
 struct LaunchTape;
 extern std::atomic<LaunchTape*> g_tape_rec;          // the tape being recorded, or nullptr
-void tape_push(LaunchTape* t, std::function<void()>&& op, const void* kernel);
+// A recorded launch is re-issued as op(stop): stop == nullptr is the plain launch; with an event, the launch carries it as its STOP event
+// (hipExtLaunchKernel: the event is the dispatch packet's own completion signal, no marker packet behind the kernel -- what a fence that
+// follows the launch on its stream is turned into, dn_tape.hip).
+void tape_push(LaunchTape* t, std::function<void(hipEvent_t)>&& op, const void* kernel, hipStream_t stream);
 
 template <typename... KArgs, typename... Args>
 static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
   kernel<<<grid, block, lds, stream>>>(args...);
-  if (LaunchTape* t = g_tape_rec.load(std::memory_order_relaxed))
-    tape_push(t, [=]() { kernel<<<grid, block, lds, stream>>>(args...); }, reinterpret_cast<const void*>(kernel));
+  if (LaunchTape* t = g_tape_rec.load(std::memory_order_relaxed)) {
+    std::tuple<std::decay_t<KArgs>...> held(args...);            // the kernel's own parameter types: hipExtLaunchKernel takes their addresses
+    tape_push(t, [=](hipEvent_t stop) mutable {
+      if (stop == nullptr) {
+        std::apply([&](auto&... a) { kernel<<<grid, block, lds, stream>>>(a...); }, held);
+      } else {
+        std::apply([&](auto&... a) {
+          void* argv[] = {static_cast<void*>(&a)...};
+          (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, stream, nullptr, stop, 0);
+        }, held);
+      }
+    }, reinterpret_cast<const void*>(kernel), stream);
+  }
 }
 #define DN_LAUNCH(...) ::dn::launch(__VA_ARGS__)
 
@@ -51,6 +68,7 @@ struct Knobs {
   int wino_min_tiles;                    // DN_WINO_MIN_TILES: fewest 2x2 output tiles the Winograd kernels take (192)
   int wino_splitk_target, wino_splitk_maxblocks;   // DN_WINO_SPLITK_TARGET (512 blocks) / _MAXBLOCKS (208): the 4-wave kernel's K split of small grids
   int pack_blocks;                       // DN_PACK_BLOCKS: blocks per table entry of the batched weight re-lay (x2 for the Winograd entries)
+  bool no_riding_fences;                 // DN_NO_RIDING_FENCES: the launch tape's device-scope fences as event records of their own, not as the stop event of the launch in front
   int wino_nmajor;                       // DN_WINO_NMAJOR (1): Winograd forward/dgrad tile order within an XCD: 1 tile row fastest (one 64-cout weight slice per XCD), 0 cout slice fastest, 2/3 by slice count
   int wino_wg_target;                    // DN_WINO_WG_TARGET (0 = by rule: 128 for small layers, else 256): blocks per round the Winograd weight gradient's tile split aims at
   int wino8;                             // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel

@@ -106,6 +106,7 @@ static void read_knobs(Knobs* k) {
   k->no_tap_windows = on("DN_NO_TAP_WINDOWS");
   k->wino_wg_target = num("DN_WINO_WG_TARGET", 0);
   k->wino_nmajor = num("DN_WINO_NMAJOR", 1);
+  k->no_riding_fences = on("DN_NO_RIDING_FENCES");
   k->wino8 = num("DN_WINO8", -1);
 }
 
@@ -384,7 +385,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 15; }
+int dn_version(void) { return 16; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);

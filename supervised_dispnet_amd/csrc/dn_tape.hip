@@ -17,21 +17,41 @@
 
 namespace dn {
 
+struct TapeOp {
+  std::function<void(hipEvent_t)> launch;   // a kernel launch (called with `stop`), or empty for a fence
+  const void* what = nullptr;               // the kernel's host function (dn_tape_replay_timed names it), nullptr for a fence
+  hipStream_t stream = nullptr;             // launch: its stream
+  hipEvent_t stop = nullptr;                // launch: the event a fence behind it rides on (its stop event), or nullptr
+  hipStream_t waiter = nullptr, waitee = nullptr;   // fence
+  hipEvent_t ev = nullptr;                  // fence: its event
+  bool record = true;                       // fence: record `ev` on `waitee` at replay (false: `ev` is the stop event of an earlier launch)
+  void run() const {
+    if (launch) {
+      launch(stop);
+    } else {
+      if (record) (void)hipEventRecord(ev, waitee);
+      (void)hipStreamWaitEvent(waiter, ev, 0);
+    }
+  }
+};
+
 struct LaunchTape {
-  std::vector<std::function<void()>> ops;
-  std::vector<const void*> what;       // per op: the kernel's host function (dn_tape_replay_timed names it), nullptr for a fence
+  std::vector<TapeOp> ops;
   std::vector<size_t> marks;           // ops.size() at each dn_tape_mark
   std::vector<hipEvent_t> events;
   std::mutex mu;                       // forward is recorded on the caller's thread, backward on autograd's
-  size_t launches = 0, fences = 0;
+  size_t launches = 0, fences = 0, riding = 0;
 };
 
 std::atomic<LaunchTape*> g_tape_rec{nullptr};
 
-void tape_push(LaunchTape* t, std::function<void()>&& op, const void* kernel) {
+void tape_push(LaunchTape* t, std::function<void(hipEvent_t)>&& op, const void* kernel, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(t->mu);
-  t->ops.emplace_back(std::move(op));
-  t->what.push_back(kernel);
+  TapeOp o;
+  o.launch = std::move(op);
+  o.what = kernel;
+  o.stream = stream;
+  t->ops.emplace_back(std::move(o));
   ++t->launches;
 }
 
@@ -74,7 +94,7 @@ int dn_tape_pause(void* tape, int32_t paused) {
   return DN_OK;
 }
 
-static int tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee, unsigned flags) {
+static int tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee, unsigned flags, bool ride) {
   dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
   if (t == nullptr || dn::g_tape_rec.load() != t) {
     dn::set_error("dn_tape_fence: this tape is not being recorded");
@@ -89,21 +109,41 @@ static int tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee, unsign
   hipStream_t w = dn::as_stream(waiter), s = dn::as_stream(waitee);
   std::lock_guard<std::mutex> lock(t->mu);
   t->events.push_back(ev);
-  t->ops.emplace_back([=]() {
-    (void)hipEventRecord(ev, s);
-    (void)hipStreamWaitEvent(w, ev, 0);
-  });
-  t->what.push_back(nullptr);
+  dn::TapeOp f;
+  f.waiter = w;
+  f.waitee = s;
+  f.ev = ev;
+  // A device-scope fence whose waitee's LAST recorded item is a kernel launch rides on that launch: the event becomes the launch's stop
+  // event (the dispatch packet's own completion signal) instead of a marker packet behind it -- tools/ubench/fence_cost.hip: 1.5-4.5 us of
+  // the waitee's queue per fence instead of 2.3-6.6.  "Last item": no later launch on that stream and no later fence that made it wait
+  // (an in-order stream: the launch's completion then covers everything enqueued on it so far).
+  if (ride && !dn::knobs().no_riding_fences) {
+    for (size_t i = t->ops.size(); i-- > 0;) {
+      dn::TapeOp& o = t->ops[i];
+      if (o.launch) {
+        if (o.stream != s) continue;
+        if (t->marks.empty() || i >= t->marks.back()) {      // (within the current segment)
+          if (o.stop == nullptr) o.stop = ev;
+          f.ev = o.stop;                                     // (a second fence behind the same launch shares its stop event)
+          f.record = false;
+          ++t->riding;
+        }
+        break;
+      }
+      if (o.waiter == s || o.waitee == s) break;      // the stream's last item is a wait / a marker, not a launch
+    }
+  }
+  t->ops.emplace_back(std::move(f));
   ++t->fences;
   return DN_OK;
 }
 
-int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee) { return tape_fence(tape, waiter, waitee, hipEventDisableTiming); }
+int dn_tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee) { return tape_fence(tape, waiter, waitee, hipEventDisableTiming, false); }
 
 // Both streams' work stays on this device: no system-scope release at the event (tools/ubench/fence_cost.hip: the recording stream's queue
 // loses 2.3-5.9 us per fence instead of 4.5-8.5; a 4-image step records ~60 of them on its critical stream).
 int dn_tape_fence_device(void* tape, dn_stream_t waiter, dn_stream_t waitee) {
-  return tape_fence(tape, waiter, waitee, hipEventDisableTiming | hipEventDisableSystemFence);
+  return tape_fence(tape, waiter, waitee, hipEventDisableTiming | hipEventDisableSystemFence, true);
 }
 
 int32_t dn_tape_mark(void* tape) {
@@ -127,6 +167,11 @@ int64_t dn_tape_launches(void* tape) {
   return t == nullptr ? -1 : (int64_t)t->launches;
 }
 
+int64_t dn_tape_riding_fences(void* tape) {
+  dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
+  return t == nullptr ? -1 : (int64_t)t->riding;
+}
+
 int64_t dn_tape_fences(void* tape) {
   dn::LaunchTape* t = reinterpret_cast<dn::LaunchTape*>(tape);
   return t == nullptr ? -1 : (int64_t)t->fences;
@@ -145,7 +190,7 @@ int dn_tape_replay(void* tape, int32_t segment) {
   }
   const size_t lo = segment <= 0 ? 0 : t->marks[segment - 1];
   const size_t hi = (segment == -1 || segment == nseg - 1) ? t->ops.size() : t->marks[segment];
-  for (size_t i = lo; i < hi; ++i) t->ops[i]();
+  for (size_t i = lo; i < hi; ++i) t->ops[i].run();
   return dn::check_launch("dn_tape_replay");
 }
 
@@ -161,11 +206,11 @@ int32_t dn_tape_replay_timed(void* tape, int64_t* ns, const char** name, int32_t
   const size_t n = t->ops.size();
   for (size_t i = 0; i < n; ++i) {
     const auto t0 = std::chrono::steady_clock::now();
-    t->ops[i]();
+    t->ops[i].run();
     const auto t1 = std::chrono::steady_clock::now();
     if ((int32_t)i < cap) {
       ns[i] = std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-      name[i] = t->what[i] != nullptr ? hipKernelNameRefByPtr(t->what[i], nullptr) : "fence";
+      name[i] = t->ops[i].what != nullptr ? hipKernelNameRefByPtr(t->ops[i].what, nullptr) : (t->ops[i].record ? "fence" : "fence (riding)");
     }
   }
   if (dn::check_launch("dn_tape_replay_timed") != DN_OK) return -1;

@@ -160,6 +160,7 @@ class TapedStep(object):
         self._lib = lib
         self.segments = lib.dn_tape_segments(handle)
         self.launches, self.fences = lib.dn_tape_launches(handle), lib.dn_tape_fences(handle)
+        self.riding_fences = lib.dn_tape_riding_fences(handle)      # fences re-issued as the stop event of the launch in front of them
         if self.segments != len(self.host_calls) + 1:
             raise RuntimeError("launch tape: %d segments for %d host calls" % (self.segments, len(self.host_calls)))
         return self

@@ -226,12 +226,19 @@ def test_adam_per_bucket_under_the_backward_pass_is_bitwise_the_single_update(ta
     assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)
 
 
-def test_launch_tape_lazy_join_runs_replays_back_to_back_and_joins_on_demand():
+@pytest.mark.parametrize("riding", [True, False], ids=["riding-fences", "own-event-records"])
+def test_launch_tape_lazy_join_runs_replays_back_to_back_and_joins_on_demand(monkeypatch, riding):
     """TapedStep(lazy_join=True): a replay does not make the caller's stream wait for the tape's (bench.py: ~25 us of idle device between
     two steps saved); join() does.  Four steps on changing batches written into the static inputs on the CALLER's stream: losses (read
     after join()), parameters and Adam moments equal the eager steps' bit for bit -- the input fence in front of every replay still orders
-    the caller's copies before the step, and the fences between the compute streams are device-scope events (dn_tape_fence_device)."""
+    the caller's copies before the step, and the fences between the compute streams are device-scope events (dn_tape_fence_device) --
+    re-issued as the stop event of the launch in front of them (hipExtLaunchKernel; `riding`), or, with DN_NO_RIDING_FENCES=1, as event
+    records of their own."""
+    from supervised_dispnet_amd import _lib
     from supervised_dispnet_amd.graph import TapedStep, backward
+    if not riding:
+        monkeypatch.setenv("DN_NO_RIDING_FENCES", "1")
+        _lib.load().dn_reload_knobs()
     batches = [bench.synthetic_batch(4, 64, 96, DEV, seed) for seed in range(4)]
     net_a, opt_a = _make()
     sd0 = copy.deepcopy({k: v.detach().cpu().clone() for k, v in net_a.state_dict().items()})
@@ -257,6 +264,7 @@ def test_launch_tape_lazy_join_runs_replays_back_to_back_and_joins_on_demand():
 
     f = TapedStep(step_b, optimizer=opt_b, warmup=0, static_inputs=(img, gt), lazy_join=True).capture()     # the recorded step: batch 0
     assert f.lazy_join and f.fences > 0
+    assert (f.riding_fences > 0) == riding and f.riding_fences <= f.fences
     la = [step_a(*batches[0]).clone()]
     lb = []
     for x, y in batches[1:]:

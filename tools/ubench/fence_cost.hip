@@ -13,6 +13,9 @@ __global__ void spin_kernel(float* p, int iters) {
   p[blockIdx.x * blockDim.x + threadIdx.x] = x;
 }
 
+#include <hip/hip_ext.h>
+static bool g_ext = false;     // the event as the STOP event of the kernel's own launch (hipExtLaunchKernel): no marker packet behind the kernel
+
 static double run(hipStream_t a, hipStream_t b, float* buf, float* buf2, int n, int iters, int every, unsigned flags, bool side_work, double* host_ms) {
   std::vector<hipEvent_t> evs(n);
   for (auto& e : evs) hipEventCreateWithFlags(&e, flags);
@@ -25,9 +28,15 @@ static double run(hipStream_t a, hipStream_t b, float* buf, float* buf2, int n, 
     auto h0 = std::chrono::steady_clock::now();
     hipEventRecord(t0, a);
     for (int i = 0; i < n; ++i) {
-      spin_kernel<<<64, 256, 0, a>>>(buf, iters);
-      if (every > 0 && i % every == every - 1) {
-        hipEventRecord(evs[i], a);
+      const bool fence = every > 0 && i % every == every - 1;
+      if (fence && g_ext) {
+        void* argv[] = {&buf, &iters};
+        hipExtLaunchKernel(reinterpret_cast<const void*>(spin_kernel), dim3(64), dim3(256), argv, 0, a, nullptr, evs[i], 0);
+      } else {
+        spin_kernel<<<64, 256, 0, a>>>(buf, iters);
+      }
+      if (fence) {
+        if (!g_ext) hipEventRecord(evs[i], a);
         hipStreamWaitEvent(b, evs[i], 0);
         if (side_work) spin_kernel<<<64, 256, 0, b>>>(buf2, iters);
       }
@@ -67,6 +76,12 @@ int main() {
         const double t1 = run(a, b, buf, buf2, n, iters, every, plain, sw, &h);
         const double h1 = h;
         const double t2 = run(a, b, buf, buf2, n, iters, every, nosys, sw, &h);
+        g_ext = true;
+        const double t3 = run(a, b, buf, buf2, n, iters, every, nosys, sw, &h);
+        const double h3 = h;
+        g_ext = false;
+        printf("  fence every %d kernel(s)%s: event = the launch's stop event (hipExtLaunchKernel) %.3f ms (+%.2f us per fence, host %.3f ms)\n", every,
+               sw ? " + a kernel on the waiting stream" : "", t3, (t3 - base) * 1e3 / (n / every), h3);
         printf("  fence every %d kernel(s)%s: plain events %.3f ms (+%.2f us per fence, host %.3f ms), no system fence %.3f ms (+%.2f us per fence, host %.3f ms)\n",
                every, sw ? " + a kernel on the waiting stream" : "", t1, (t1 - base) * 1e3 / (n / every), h1, t2, (t2 - base) * 1e3 / (n / every), h);
       }
