@@ -402,6 +402,9 @@ def main():
     ap.add_argument("--system-fences", action="store_true",
                     help="A/B: the launch tape's fences between the main and the weight-gradient streams with the system-scope release HIP events "
                          "carry by default (engine.DEVICE_SCOPE_FENCES = False)")
+    ap.add_argument("--no-loss-fusion", action="store_true",
+                    help="A/B: the masked loss forward as three launches + a fill (loss_functions.FUSE_MASKED_FWD = False) and an owned copy of the "
+                         "gradient autograd seeds the finest head with (engine.BORROW_SEED_GRADS = False)")
     ap.add_argument("--tape-join-every-step", action="store_true",
                     help="A/B: every replay makes the caller's stream wait for the tape's (graph.TapedStep's default; bench.py reads nothing "
                          "between steps and joins once after the timed loop)")
@@ -452,6 +455,10 @@ def main():
     engine.set_compute(args.compute)
     if args.system_fences:
         engine.DEVICE_SCOPE_FENCES = False
+    if args.no_loss_fusion:
+        import supervised_dispnet_amd.loss_functions as _LF
+        _LF.FUSE_MASKED_FWD = False
+        engine.BORROW_SEED_GRADS = False
     if args.no_fold:
         engine.FOLD_FINALIZE = False
     if args.wgrad_streams > 0:

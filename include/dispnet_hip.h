@@ -280,6 +280,8 @@ int32_t dn_reduce_blocks(int64_t rows, int32_t C);   /* rows of `partial` the re
 
 /* g_pre = g * act'(.) in place, using the stored POST-activation tensor y_post; also per-channel partial sums
  * [blocks][C] of g_pre (the conv bias gradient).  act: RELU / LEAKY(p0) / SIGMOID_AFFINE(p0,p1) / NONE. */
+int dn_act_bwd_reduce_from(const float* g_in, float* g_out, const float* y_post, int32_t act, float p0, float p1, int64_t rows, int32_t C,
+                           float* partial, dn_stream_t stream);   /* the same, out of place (g_in is not written) */
 int dn_act_bwd_reduce(float* g, const float* y_post, int32_t act, float p0, float p1, int64_t rows, int32_t C,
                       float* partial, dn_stream_t stream);
 /* out[c] = sum over rows of partial[row][c*stride + offset]  (finishes bias / gamma / beta gradients). */
@@ -366,6 +368,12 @@ enum dn_masked_loss_kind { DN_LOSS_L1 = 0, DN_LOSS_L2 = 1, DN_LOSS_BERHU = 2, DN
 size_t dn_masked_loss_workspace_bytes(int32_t G, int64_t pixels);
 int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, float weight,
                        int32_t accumulate, float* stats, void* workspace, size_t workspace_bytes, float* loss, dn_stream_t stream);
+/* The same forward as ONE launch (kinds L1 / L2 / scale-invariant, G <= 256): the block that arrives last reduces the split partials and
+ * turns them into the loss, in the order of the separate launches -- bit-identical to dn_masked_loss_fwd.  `counter`: one int32 in device
+ * memory, zero before the first call and left zero (calls that may overlap on the device need counters of their own). */
+int dn_masked_loss_fwd_fused(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, float weight,
+                             int32_t accumulate, float* stats, void* workspace, size_t workspace_bytes, float* loss, int32_t* counter,
+                             dn_stream_t stream);
 /* dn_masked_loss_fwd in pieces, for one-process-per-GPU runs of the whole-batch losses (the reference's DataParallel sees the
  * gathered batch on GPU0, loss_functions.py:232-237): pass 0 -> stats[g][0..3] = (sum f, n, sum d, max r) of THIS rank's pixels;
  * the caller all-reduces them (columns 0..2 add, column 3 takes the max); kind berHu then runs pass 1 -> stats[g][0], [2], [4]

@@ -13,7 +13,7 @@ LIB_PATH = pathlib.Path(os.environ.get("DISPNET_HIP_LIB", _PKG / "libdispnet_hip
 # ABI version this binding was written against (include/dispnet_hip.h: dn_version(), bumped on any signature / struct change).
 # load() refuses a library that reports anything else: a stale .so (DISPNET_HIP_LIB, a build that did not re-run) would otherwise
 # read struct fields past the end of what this binding fills in and mis-marshal arguments -- silent memory corruption, not an error.
-EXPECTED_ABI = 16
+EXPECTED_ABI = 17
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
@@ -92,6 +92,7 @@ SIGNATURES = {
     "dn_bn_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp]),
     "dn_reduce_blocks": (_i32, [_i64, _i32]),
     "dn_act_bwd_reduce": (C.c_int, [_vp, _vp, _i32, _f, _f, _i64, _i32, _vp, _vp]),
+    "dn_act_bwd_reduce_from": (C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _i64, _i32, _vp, _vp]),
     "dn_colsum_finalize": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dn_upsample2x_nearest_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "dn_upsample2x_nearest_bwd_nhwc": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
@@ -119,6 +120,7 @@ SIGNATURES = {
     "dn_reciprocal_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "dn_masked_loss_workspace_bytes": (_sz, [_i32, _i64]),
     "dn_masked_loss_fwd": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _f, _i32, _vp, _vp, _sz, _vp, _vp]),
+    "dn_masked_loss_fwd_fused": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _f, _i32, _vp, _vp, _sz, _vp, _vp, _vp]),
     "dn_masked_loss_stats": (C.c_int, [_vp, _vp, _i32, _i64, _f, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dn_masked_loss_finalize": (C.c_int, [_vp, _i32, _i32, _f, _i32, _vp, _vp]),
     "dn_masked_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _f, _i32, _f, _vp, _vp]),

@@ -1,5 +1,6 @@
 // Per-pixel depth losses and metrics (reference: loss_functions.py).  HBM/latency-bound reductions; wavefront (64-lane)
 // shuffles for the spatial reductions, no float atomics (deterministic), no host synchronisation.
+#include "dn_fold.h"
 #include "dn_internal.h"
 
 namespace dn {
@@ -84,6 +85,81 @@ __global__ void __launch_bounds__(256) masked_stats_kernel(const float* __restri
     float* o = partial + ((long long)g * nsp + sp) * 4;
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
     o[3] = fmaxf(fmaxf(lmx[0], lmx[1]), fmaxf(lmx[2], lmx[3]));
+  }
+}
+
+// The three launches of the forward (pass A, the reduction over the splits, the division) as ONE: every block stores its partial with
+// agent-scope stores, the block that arrives last (dn_fold.h) reduces the splits of every group -- thread g walks group g's splits in index
+// order, exactly masked_reduceA_kernel -- and thread 0 turns the groups into the loss in group order, exactly masked_loss_finalize_kernel:
+// bit-identical to the three launches (tests/test_gpu_losses.py).  A 4-image step spends 6-7 us on each of the two small launches and
+// another 7 on the fill of the statistics rows, on its critical stream.  G <= kFoldLossGroups; not berHu (a second pass over the pixels).
+constexpr int kFoldLossGroups = 256;
+
+__global__ void __launch_bounds__(256) masked_stats_fold_kernel(const float* __restrict__ gt, const float* __restrict__ pred, long long pixels,
+                                                                float max_depth, int kind, float* __restrict__ partial, int G,
+                                                                float* __restrict__ stats, float weight, int accumulate, float* __restrict__ loss,
+                                                                int* __restrict__ counter) {
+  const int g = blockIdx.y, sp = blockIdx.x, nsp = gridDim.x;
+  const float* Gp = gt + (long long)g * pixels;
+  const float* P = pred + (long long)g * pixels;
+  float acc[3] = {0.f, 0.f, 0.f};
+  float mx = 0.f;
+  for (long long i = sp * 256ll + threadIdx.x; i < pixels; i += nsp * 256ll) {
+    const float gv = Gp[i];
+    if (gv > 0.f && gv < max_depth) {
+      const float p = clampf(P[i], 1e-3f, max_depth);
+      const float d = gv - p;
+      float f;
+      if (kind == DN_LOSS_L1) f = fabsf(d);
+      else if (kind == DN_LOSS_L2) f = d * d;
+      else if (kind == DN_LOSS_SCALE_INV) { const float e = fabsf(gv) - fabsf(p); f = e * e; }
+      else f = 0.f;
+      acc[0] += f;
+      acc[1] += 1.f;
+      acc[2] += d;
+      mx = fmaxf(mx, fabsf(d));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  __shared__ float lds[3 * 16];
+  __shared__ float lmx[4];
+  __shared__ int last_flag;
+  __shared__ float red[3][kFoldLossGroups];
+  if ((threadIdx.x & 63) == 0) lmx[threadIdx.x >> 6] = mx;
+  block_sum<3>(acc, lds);
+  if (threadIdx.x == 0) {
+    float* o = partial + ((long long)g * nsp + sp) * 4;
+    fold_store(o + 0, acc[0]);
+    fold_store(o + 1, acc[1]);
+    fold_store(o + 2, acc[2]);
+    fold_store(o + 3, fmaxf(fmaxf(lmx[0], lmx[1]), fmaxf(lmx[2], lmx[3])));
+  }
+  if (!fold_last_arrival(counter, (int)(gridDim.x * gridDim.y), &last_flag)) return;
+  const int t = threadIdx.x;
+  if (t < G) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, m = 0.f;
+    for (int k = 0; k < nsp; ++k) {
+      const float* p = partial + ((long long)t * nsp + k) * 4;
+      const float2 a = fold_load2<true>(p), b = fold_load2<true>(p + 2);
+      s0 += a.x; s1 += a.y; s2 += b.x; m = fmaxf(m, b.y);
+    }
+    float* o = stats + t * kStat;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = m; o[4] = 0.f;
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int q = 0; q < G; ++q) {
+      const float n = red[1][q];
+      float L = red[0][q] / n;
+      if (kind == DN_LOSS_SCALE_INV) L = L - (red[2][q] * red[2][q]) * 0.5f / (n * n);
+      stats[q * kStat + 5] = L;
+      s += L;
+    }
+    const float v = weight * (s / (float)G);
+    loss[0] = accumulate ? loss[0] + v : v;
   }
 }
 
@@ -537,6 +613,19 @@ int dn_masked_loss_fwd(const float* gt, const float* pred, int32_t G, int64_t pi
   }
   DN_LAUNCH(masked_loss_finalize_kernel, dim3(1), dim3(64), 0, s, stats, G, kind, weight, accumulate, loss);
   return check_launch("masked_loss_fwd");
+}
+
+int dn_masked_loss_fwd_fused(const float* gt, const float* pred, int32_t G, int64_t pixels, float max_depth, int32_t kind, float weight,
+                             int32_t accumulate, float* stats, void* workspace, size_t workspace_bytes, float* loss, int32_t* counter,
+                             dn_stream_t stream) {
+  DN_REQUIRE(gt && pred && stats && loss && workspace && counter && G > 0 && pixels > 0, DN_ERR_BAD_ARG, "dn_masked_loss_fwd_fused: bad argument");
+  DN_REQUIRE((kind == DN_LOSS_L1 || kind == DN_LOSS_L2 || kind == DN_LOSS_SCALE_INV) && G <= kFoldLossGroups, DN_ERR_BAD_ARG,
+             "dn_masked_loss_fwd_fused: kind %d / %d groups take dn_masked_loss_fwd", kind, G);
+  DN_REQUIRE(workspace_bytes >= dn_masked_loss_workspace_bytes(G, pixels), DN_ERR_WORKSPACE, "dn_masked_loss_fwd_fused: workspace too small");
+  const int nsp = loss_splits(pixels);
+  DN_LAUNCH(masked_stats_fold_kernel, dim3(nsp, G), dim3(256), 0, as_stream(stream), gt, pred, (long long)pixels, max_depth, (int)kind,
+            reinterpret_cast<float*>(workspace), (int)G, stats, weight, (int)accumulate, loss, reinterpret_cast<int*>(counter));
+  return check_launch("masked_stats_fold_kernel");
 }
 
 // The same forward in pieces, for data-parallel runs of the whole-batch (Multiscale_*) losses: pass 0 fills stats[g][0..3]

@@ -385,7 +385,7 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
 
 extern "C" {
 
-int dn_version(void) { return 16; }
+int dn_version(void) { return 17; }
 
 void dn_reload_knobs(void) {
   std::lock_guard<std::mutex> lock(dn::g_knobs_mu);

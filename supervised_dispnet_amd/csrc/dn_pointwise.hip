@@ -353,6 +353,7 @@ struct BnReluBwdOp {
 
 struct ActBwdOp {
   static constexpr int NACC = 1;
+  const float* src;      // == g: in place
   float* g;
   const float* y_post;
   int act;
@@ -361,8 +362,10 @@ struct ActBwdOp {
   template <int V>
   __device__ __forceinline__ void apply(long long row, int c0, float (&acc)[V][1]) const {
     const long long o = row * C + c0;
-    Vec<V> gv = ldv<V>(g + o);
-    if (act != DN_ACT_NONE) {
+    Vec<V> gv = ldv<V>(src + o);
+    if (act == DN_ACT_NONE) {
+      if (src != g) stv<V>(g + o, gv);
+    } else {
       const Vec<V> yv = ldv<V>(y_post + o);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -1155,8 +1158,17 @@ int dn_bn_bwd_apply(float* dz_dy, const float* y, const float* mean, const float
 int dn_act_bwd_reduce(float* g, const float* y_post, int32_t act, float p0, float p1, int64_t rows, int32_t C, float* partial,
                       dn_stream_t stream) {
   DN_REQUIRE(g && partial && rows > 0 && C > 0 && (act == DN_ACT_NONE || y_post), DN_ERR_BAD_ARG, "dn_act_bwd_reduce: bad argument");
-  ActBwdOp op{g, y_post, act, p0, p1, C};
+  ActBwdOp op{g, g, y_post, act, p0, p1, C};
   return launch_colreduce(op, rows, C, partial, as_stream(stream), "act_bwd_reduce");
+}
+
+// out of place: g_out = g_in * act'(.) -- the incoming gradient is the framework's tensor and must not be written (engine.seed_grad used to
+// copy it first: one more launch on the critical stream)
+int dn_act_bwd_reduce_from(const float* g_in, float* g_out, const float* y_post, int32_t act, float p0, float p1, int64_t rows, int32_t C,
+                           float* partial, dn_stream_t stream) {
+  DN_REQUIRE(g_in && g_out && partial && rows > 0 && C > 0 && (act == DN_ACT_NONE || y_post), DN_ERR_BAD_ARG, "dn_act_bwd_reduce_from: bad argument");
+  ActBwdOp op{g_in, g_out, y_post, act, p0, p1, C};
+  return launch_colreduce(op, rows, C, partial, as_stream(stream), "act_bwd_reduce_from");
 }
 
 int dn_colsum_finalize(const float* partial, int32_t rows, int32_t C, int32_t stride, int32_t offset, float* out, dn_stream_t stream) {

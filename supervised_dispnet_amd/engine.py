@@ -123,6 +123,7 @@ def side_stream():
 # alive instead of relying on the caching allocator's event-guarded reuse (whose timing the replay cannot reproduce).
 TAPE = None
 DEVICE_SCOPE_FENCES = True      # A/B: bench.py --system-fences
+BORROW_SEED_GRADS = True        # seed_grad() hands a block that only READS its seeded gradient the framework's tensor instead of a copy
 
 
 def stream_wait(waiter, waitee, device_scope=False):
@@ -407,7 +408,7 @@ class Act:
     """An NHWC fp32 activation [N,H,W,C] plus what the engine needs to know about it."""
     __slots__ = ("t", "N", "H", "W", "C", "scale", "shift", "mean", "invstd", "grad", "grad_is_dz", "partial",
                  "partial_rows", "partial_stride", "partial_offset", "needs_grad", "strides", "no_relu", "planar", "pool_src", "sums_ready",
-                 "recip_t", "bn_owner", "sums_final")
+                 "recip_t", "bn_owner", "sums_final", "seed_borrow", "grad_borrowed")
 
     def __init__(self, t, N, H, W, C, strides=None, needs_grad=True):
         self.t = t
@@ -429,6 +430,9 @@ class Act:
         self.bn_owner = None            # (BatchNorm2d, GradSink) of a pre-BatchNorm activation: where the input-gradient kernel of the layer
                                         # above may put d(gamma), d(beta) when it finishes the sums itself (dn_conv_desc.bnb_dgamma / bnb_dbeta)
         self.sums_final = None          # (dgamma, dbeta) tensors that already hold the two BatchNorm-backward sums
+        self.seed_borrow = False        # the producing block reads a seeded gradient WITHOUT writing it (block_conv_act: out-of-place
+                                        # activation backward): seed_grad() may hand the framework's tensor over instead of a copy
+        self.grad_borrowed = False      # .grad is the framework's tensor: read-only
         self.needs_grad = needs_grad
         self.strides = strides or (H * W * C, W * C, C, 1)   # (n, h, w, c) element strides
 
@@ -458,8 +462,11 @@ class Tape:
     def __init__(self, recording):
         self.recording = recording
         self.steps = []
+        self.last_out = None            # the Act the LAST pushed block produced, when that block can read a seeded gradient without writing it
+                                        # (block_conv_act): nothing after it can have consumed it, so no block accumulates into its gradient
 
-    def push(self, fn):
+    def push(self, fn, out=None):
+        self.last_out = out
         if self.recording:
             self.steps.append(fn)
 
@@ -950,14 +957,19 @@ def colsum(partial, rows, Cn, stride=1, offset=0, out=None):
     return out
 
 
-def act_bwd(g, y_post, act, p0, p1, rows, Cn, out=None, defer=False):
-    """g <- g * act'(y_post) in place; returns the bias gradient (column sums of the result), written into `out` if given.
+def act_bwd(g, y_post, act, p0, p1, rows, Cn, out=None, defer=False, src=None):
+    """g <- g * act'(y_post) in place (`src` given: g <- src * act'(y_post), src is not written); returns the bias gradient (column sums
+    of the result), written into `out` if given.
     `defer`: returns (finish, partial) instead -- finish() runs the second stage of the column sums and returns the bias gradient; only
     the optimizer reads it, so conv_wgrad runs it on the weight-gradient side stream (a 5 us launch per layer off the critical path)."""
     nblk = _lib.load().dn_reduce_blocks(rows, Cn)
     partial = torch.empty((nblk, Cn), dtype=torch.float32, device=g.device)
-    hbm_call("dn::colreduce_kernel<dn::ActBwdOp, %d>" % (4 if Cn % 4 == 0 else 1), rows * Cn * 12, "dn_act_bwd_reduce", g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn,
-             partial.data_ptr(), _stream())
+    kname = "dn::colreduce_kernel<dn::ActBwdOp, %d>" % (4 if Cn % 4 == 0 else 1)
+    if src is not None:
+        hbm_call(kname, rows * Cn * 12, "dn_act_bwd_reduce_from", src.data_ptr(), g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn,
+                 partial.data_ptr(), _stream())
+    else:
+        hbm_call(kname, rows * Cn * 12, "dn_act_bwd_reduce", g.data_ptr(), _ptr(y_post), act, p0, p1, rows, Cn, partial.data_ptr(), _stream())
     if defer:
         return (lambda: colsum(partial, nblk, Cn, out=out)), partial
     return colsum(partial, nblk, Cn, out=out)
@@ -1207,9 +1219,11 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
             if layer.m.bias is not None:
                 sink.put_none(layer.m.bias)
             return
-        g = y.grad
+        g, g_src = y.grad, None
+        if y.grad_borrowed:                  # the framework's tensor (seed_grad): read it, write the result elsewhere
+            g_src, g, y.grad_borrowed = g, torch.empty_like(y.grad), False
         finish_db, db_partial = act_bwd(g, y_t, act, p0, p1, y.rows, layer.Cout,
-                                        out=sink.dest(layer.m.bias) if layer.m.bias is not None else None, defer=True)
+                                        out=sink.dest(layer.m.bias) if layer.m.bias is not None else None, defer=True, src=g_src)
 
         def bias_grad():
             db = finish_db()
@@ -1221,7 +1235,7 @@ def block_conv_act(tape, sink, pieces, layer, act, p0=0.0, p1=0.0, out_hw=None, 
         conv_dgrad(layer, g, a0.N, OH, OW, pieces, in_hw)
         y.grad = None
 
-    tape.push(backward)
+    tape.push(backward, out=y)
     return y
 
 
@@ -1241,7 +1255,9 @@ def seed_grad(act, g):
     else:
         g = g.reshape(act.N, act.H, act.W, act.C) if act.C == 1 else g.permute(0, 2, 3, 1)
     if act.grad is None:
-        if g.is_cuda and g.is_contiguous() and g.dtype == torch.float32:
+        if act.seed_borrow and BORROW_SEED_GRADS and g.is_cuda and g.is_contiguous() and g.dtype == torch.float32:
+            act.grad, act.grad_borrowed = g, True        # read once, out of place, by the producing block's activation backward
+        elif g.is_cuda and g.is_contiguous() and g.dtype == torch.float32:
             act.grad = torch.empty_like(g)       # (this library's copy kernel: on the launch tape, which a framework clone would not be)
             _lib.call("dn_copy", g.data_ptr(), act.grad.data_ptr(), g.numel(), _stream())
         else:

@@ -171,7 +171,9 @@ class TapedStep(object):
             return self.out
         s = self._stream
         cur = torch.cuda.current_stream()
-        s.wait_stream(cur)                # the caller's writes into the static inputs
+        if not (self.lazy_join and cur.query()):
+            s.wait_stream(cur)            # the caller's writes into the static inputs (skipped when the caller's stream is idle: nothing pending there can
+                                          # still be writing them -- with lazy_join that stream does not even hold the previous replay's join)
         t_host = time.perf_counter()
         if not self.host_calls:
             rc = self._lib.dn_tape_replay(self.tape, -1)

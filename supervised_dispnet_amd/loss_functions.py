@@ -24,6 +24,22 @@ def _f32c(t, what):
 
 
 # ------------------------------------------------------------------------------------------------ masked depth losses
+FUSE_MASKED_FWD = True          # A/B + the bitwise test: False = the three launches (+ the fill of the statistics rows)
+_FOLD_COUNTERS = {}             # device -> [zeroed int32 tensor, next slot]: last-arrival counters of the fused forward
+
+
+def _fold_counter(dev):
+    """Address of a zero int32 for one fused launch: 64 slots per device handed out round-robin, so that launches that overlap on the
+    device (other streams) count in different slots; every launch leaves its slot zero."""
+    ent = _FOLD_COUNTERS.get(dev)
+    if ent is None:
+        from .engine import outside_tape_pool
+        with outside_tape_pool():                    # persistent: not from a launch tape's private pool
+            ent = _FOLD_COUNTERS[dev] = [torch.zeros(64, dtype=torch.int32, device=dev), 0]
+    ent[1] = (ent[1] + 1) % 64
+    return ent[0].data_ptr() + 4 * ent[1]
+
+
 class _MaskedLoss(torch.autograd.Function):
     """Sum of terms of the masked-loss family (C entry points dn_masked_loss_fwd/_bwd) as ONE autograd node.
     Term i: `groups[i]` runs of equal length over (gts[i], preds[i]), each with its own mask mean; contributes
@@ -42,7 +58,11 @@ class _MaskedLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         saved, cfg, work = [], [], []
         all_stats = torch.empty((sum(groups[:len(preds)]), _lib.LOSS_STATS), dtype=torch.float32, device=dev)
-        _lib.call("dn_fill", all_stats.data_ptr(), 0.0, all_stats.numel(), _stream())
+        # one launch per term (dn_masked_loss_fwd_fused: the last-arriving block reduces and divides) where the term allows it; the rows it
+        # writes need no zero fill (columns 0-5 are all the backward reads)
+        fused = FUSE_MASKED_FWD and sync <= 1 and kind != _lib.LOSS_BERHU and max(groups[:len(preds)]) <= 256
+        if not fused:
+            _lib.call("dn_fill", all_stats.data_ptr(), 0.0, all_stats.numel(), _stream())
         row = 0
         for i, (gt, pred) in enumerate(zip(gts, preds)):
             require_cuda(pred, "predicted depth")
@@ -60,6 +80,9 @@ class _MaskedLoss(torch.autograd.Function):
                 _lib.call("dn_masked_loss_stats", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, 0, stats.data_ptr(),
                           ws.data_ptr(), nbytes, _stream())
                 work.append((gtc, pc, g, pixels, stats, ws, nbytes))
+            elif fused:
+                hbm_call("dn::masked_stats_fold_kernel", 8 * g * pixels, "dn_masked_loss_fwd_fused", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind,
+                         weights[i], 0 if i == 0 else 1, stats.data_ptr(), ws.data_ptr(), nbytes, loss.data_ptr(), _fold_counter(dev), _stream())
             else:
                 hbm_call("dn::masked_stats_kernel", 8 * g * pixels, "dn_masked_loss_fwd", gtc.data_ptr(), pc.data_ptr(), g, pixels, max_depth, kind, weights[i], 0 if i == 0 else 1,
                           stats.data_ptr(), ws.data_ptr(), nbytes, loss.data_ptr(), _stream())

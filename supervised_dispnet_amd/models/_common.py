@@ -85,6 +85,9 @@ class HipNetFunction(torch.autograd.Function):
                     engine.choose_side_streams(inputs[0].shape[0] * inputs[0].shape[-2] * inputs[0].shape[-1])
                 engine.prepack_all(inputs[0].device)
             outs = net._hip_forward(tape, sink, *in_acts)     # list[Act]
+        last = tape.last_out
+        if last is not None and last.C == 1 and not last.planar and any(a is last for a in outs):
+            last.seed_borrow = True      # the finest head: its seeded gradient is read once, out of place (no owned copy: engine.seed_grad)
         ctx.tape, ctx.sink, ctx.outs, ctx.params, ctx.in_acts = tape, sink, outs, params, in_acts
         results = tuple(a.t if a.planar else (a.t.view(a.N, 1, a.H, a.W) if a.C == 1 else a.t.permute(0, 3, 1, 2)) for a in outs)
         # 1 / disp of the one-channel heads, written by the head kernels themselves: run_net attaches them to the

@@ -123,6 +123,47 @@ def test_per_sample_losses_ragged_vs_oracle():
             close("%s:%dx%d:grad" % (name, h, w), d.grad, od.grad, rtol=2e-4, atol_rel=2e-6)
 
 
+def test_fused_masked_forward_is_bitwise_the_three_launches():
+    """dn_masked_loss_fwd_fused (one launch: the block that arrives last reduces the split partials and divides) against the three launches
+    of dn_masked_loss_fwd: loss, statistics-dependent gradients and the Multiscale accumulation bit for bit -- per-sample groups incl. the
+    metric's 32 x 128 x 416 (64 splits x 32 groups = 2048 blocks), one whole-batch group, a one-block case, an empty mask (NaN)."""
+    cases = ((32, 128, 416, 0.05), (5, 37, 53, 0.7), (1, 8, 8, 1.0), (3, 64, 96, 0.3))
+    try:
+        for (b, h, w, dens) in cases:
+            gt = dev(detgen.sparse_depth(b, h, w, "fuse:gt%d" % h, density=dens, lo=0.5, hi=85.0))
+            p = detgen.uniform((b, 1, h, w), "fuse:p%d" % h, 1e-4, 90.0)
+            for name in ("l1_loss", "l2_loss", "Scale_invariant_loss"):
+                out = {}
+                for fused in (True, False, True):          # (the second fused run reuses the self-resetting counters)
+                    LF.FUSE_MASKED_FWD = fused
+                    d = dev(p).requires_grad_()
+                    v = getattr(LF, name)(gt, [d], "kitti")
+                    v.backward()
+                    torch.cuda.synchronize()
+                    if fused in out:
+                        assert torch.equal(out[fused][0], v.detach()) and torch.equal(out[fused][1], d.grad)
+                    out[fused] = (v.detach().clone(), d.grad.clone())
+                assert torch.equal(out[True][0], out[False][0]), (name, b, h, w, float(out[True][0]), float(out[False][0]))
+                assert torch.equal(out[True][1], out[False][1]), (name, b, h, w)
+        gt = dev(detgen.sparse_depth(3, 32, 64, "fuse:ms", density=0.4, lo=0.5, hi=90.0))
+        res = {}
+        for fused in (True, False):
+            LF.FUSE_MASKED_FWD = fused
+            depth = [dev(detgen.uniform((3, 1, 32 >> i, 64 >> i), "fuse:msp%d" % i, 1e-4, 95.0)).requires_grad_() for i in range(4)]
+            v = LF.Multiscale_L1_loss(gt, depth, "max")
+            v.backward()
+            res[fused] = [v.detach().clone()] + [x.grad.clone() for x in depth]
+        for u, v in zip(res[True], res[False]):
+            assert torch.equal(u, v)
+        gt0 = gt.clone()
+        gt0[1] = 0
+        LF.FUSE_MASKED_FWD = True
+        assert torch.isnan(LF.l1_loss(gt0, [dev(detgen.uniform((3, 1, 32, 64), "fuse:e", 1e-4, 95.0))], "kitti")).item()
+        assert int(LF._FOLD_COUNTERS[DEV][0].abs().sum().item()) == 0           # every launch left its counter zero
+    finally:
+        LF.FUSE_MASKED_FWD = True
+
+
 def test_compute_errors_golden_incl_median(golden):
     g = golden("compute_errors")
     for ds, (b, h, w), hi in (("kitti", (3, 128, 416), 90.0), ("nyu", (2, 48, 64), 11.0)):
