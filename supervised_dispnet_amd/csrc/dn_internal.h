@@ -44,7 +44,12 @@ static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_
       } else {
         std::apply([&](auto&... a) {
           void* argv[] = {static_cast<void*>(&a)...};
-          (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, stream, nullptr, stop, 0);
+          if (hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, stream, nullptr, stop, 0) != hipSuccess) {
+            // never leave the event unrecorded (a wait on it would not wait): the plain launch and an event record of its own
+            (void)hipGetLastError();
+            kernel<<<grid, block, lds, stream>>>(a...);
+            (void)hipEventRecord(stop, stream);
+          }
         }, held);
       }
     }, reinterpret_cast<const void*>(kernel), stream);

@@ -288,6 +288,45 @@ def test_launch_tape_lazy_join_runs_replays_back_to_back_and_joins_on_demand(mon
     assert torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.exp_avg_sq, opt_b.exp_avg_sq)
 
 
+def test_riding_fence_behind_a_kernel_with_140_kb_of_dynamic_lds():
+    """A device-scope tape fence whose waitee's last item is a launch is re-issued as that launch's STOP event (hipExtLaunchKernel).  Here the
+    launch is the 8-wave Winograd kernel (140 KB of dynamic LDS: the attribute the plain launches set must hold for the extended launch
+    too) and the waiting stream copies its output: the replay on NEW input equals a fresh eager convolution bit for bit, twice."""
+    from supervised_dispnet_amd import _lib, engine
+    from supervised_dispnet_amd.graph import TapedStep
+    import torch.nn as nn
+    torch.manual_seed(5)
+    N, H, W, Cc = 4, 64, 208, 128
+    layer = engine.ConvLayer(nn.Conv2d(Cc, Cc, 3, 1, 1).to(DEV))
+    x = torch.randn(N, H, W, Cc, device=DEV)
+    act = engine.Act(x, N, H, W, Cc)
+    out = torch.zeros(N, H, W, Cc, device=DEV)
+    names = []
+
+    def step():
+        with engine.stream_scope():
+            y, _, _ = engine.conv_forward(layer, [engine.Piece(act)])
+            names.append(_lib.load().dn_last_kernel().decode())
+            main, side = torch.cuda.current_stream(), engine.side_stream()["sides"][0]
+            engine.stream_wait(side, main, device_scope=True)
+            _lib.call("dn_copy", y.data_ptr(), out.data_ptr(), y.numel(), side.cuda_stream)
+            engine.cross_stream_use(y, side)
+            engine.stream_wait(main, side, device_scope=True)
+        return out
+
+    ts = TapedStep(step, warmup=1).capture()
+    assert "wino_conv8_kernel" in names[-1], names[-1]
+    assert ts.fences == 2 and ts.riding_fences == 2
+    for seed in (1, 2):
+        x.copy_(torch.randn(N, H, W, Cc, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed)))
+        out.zero_()
+        got = ts().clone()
+        torch.cuda.synchronize()
+        want, _, _ = engine.conv_forward(layer, [engine.Piece(act)])
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
 def test_launch_tape_refuses_framework_side_device_work_and_recovers():
     """A step that does device work outside libdispnet_hip while a tape is recorded (here: a gradient seeded into an activation that
     already holds one -- an ATen add) fails the recording loudly instead of producing a tape that would silently skip it; the recording
