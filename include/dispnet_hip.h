@@ -17,9 +17,13 @@
  *   - re-entrant: no mutable global state (safe from PyTorch's autograd worker threads).
  *   - activations are NHWC fp32 (channels fastest).  Operands carry explicit element strides so NCHW user
  *     tensors (the 3-channel image) can be consumed without a transpose pass.
- *   - arithmetic is fp32 throughout: conv contractions run on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact fp32
- *     FMA chains).  The 3x3 / stride 1 / pad 1 layers with aligned channels use Winograd F(2x2,3x3): fp32 transforms (adds,
- *     halves) around the same fp32 MFMAs, error at the level of the direct contraction (tests/test_gpu_kernels.py).
+ *   - results are fp32 throughout.  The DEFAULT arithmetic of the matrix-core kernels (dn_conv_desc.compute = 0) forms every fp32
+ *     product on the bf16 matrix cores from three exact bf16 pieces per operand (DN_COMPUTE_F32X3: six partial products on
+ *     v_mfma_f32_32x32x16_bf16 / _16x16x32_bf16, fp32 accumulation; error against fp64 <= 1.5x an fp32 FMA chain's,
+ *     tests/test_gpu_f32x3_fp64.py); kernels without a three-piece form, and every kernel under DN_COMPUTE_F32, run exact fp32 FMA
+ *     chains on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32.  The 3x3 / stride 1 / pad 1 layers with aligned channels use
+ *     Winograd F(2x2,3x3): fp32 transforms (adds, halves) around those products, error at the level of the direct contraction
+ *     (tests/test_gpu_kernels.py).
  */
 #ifndef DISPNET_HIP_H_
 #define DISPNET_HIP_H_
@@ -113,9 +117,11 @@ typedef struct dn_conv_desc {
   int32_t pad_mode;                /* 0: zero padding; 1: reflection padding (nn.ReflectionPad2d(pad) in front of the conv,
                                       layers.py:124-136).  Reflection is honoured by DN_CONV_FWD and by the weight gradient;
                                       its input gradient = DN_CONV_DGRAD with pad 0 on the padded extent + dn_reflect_fold. */
-  int32_t compute;                 /* Arithmetic of the matrix-core kernels that offer a choice (today: the Winograd forward / input
-                                      gradient); tensors, statistics, transforms and all other kernels are fp32 in every mode.
-                                      DN_COMPUTE_F32 (0, default): fp32 FMA chain on v_mfma_f32_32x32x2_f32.
+  int32_t compute;                 /* Arithmetic of the matrix-core kernels that offer a choice (the Winograd, tiled and LDS-resident
+                                      convolution kernels); tensors, statistics, transforms and all other kernels are fp32 in every mode.
+                                      DN_COMPUTE_DEFAULT (0, what a zeroed descriptor gets): the library's default = DN_COMPUTE_F32X3.
+                                      DN_COMPUTE_F32 (3): fp32 FMA chain on v_mfma_f32_32x32x2_f32 everywhere (0.74x the default's speed
+                                        on the metric configuration); any unknown value is treated as this one.
                                       DN_COMPUTE_BF16: operands ROUNDED to bf16, fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- the
                                         "mixed precision" mode of BASELINE configs[4]; ~4e-3 relative error per layer.
                                       DN_COMPUTE_F32X3: fp32 products on the bf16 matrix cores: each fp32 operand is split EXACTLY
@@ -175,7 +181,7 @@ typedef struct dn_conv_desc {
   float* bnb_dbeta;
 } dn_conv_desc;
 
-enum { DN_COMPUTE_F32 = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2 };
+enum { DN_COMPUTE_DEFAULT = 0, DN_COMPUTE_BF16 = 1, DN_COMPUTE_F32X3 = 2, DN_COMPUTE_F32 = 3 };
 
 /* Elements of the packed weight buffer for desc->kind (depends on R,S,stride,pad, operand/result channels). */
 int64_t dn_conv_packed_weight_elems(const dn_conv_desc* d);

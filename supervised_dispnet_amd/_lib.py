@@ -17,7 +17,7 @@ EXPECTED_ABI = 17
 
 DN_MAX_OPERANDS = 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SIGMOID_AFFINE = 0, 1, 2, 3, 4
-COMPUTE_F32, COMPUTE_BF16, COMPUTE_F32X3 = 0, 1, 2
+COMPUTE_DEFAULT, COMPUTE_BF16, COMPUTE_F32X3, COMPUTE_F32 = 0, 1, 2, 3      # (0 = the library default = F32X3)
 CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
 LOSS_L1, LOSS_L2, LOSS_BERHU, LOSS_SCALE_INV = 0, 1, 2, 3
 LOSS_STATS = 8

@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     obj_dir.mkdir(exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", str(ROOT / "include"), "-I", str(HERE),
              "-Wall", "-Wno-unused-function"]
-    deps = [HERE / "dn_internal.h", HERE / "dn_wino_common.h", ROOT / "include" / "dispnet_hip.h", pathlib.Path(__file__)]
+    deps = sorted(HERE.glob("*.h")) + sorted((ROOT / "include").glob("*.h")) + [pathlib.Path(__file__)]     # every header: an edit rebuilds all objects
     newest_dep = max(p.stat().st_mtime for p in deps)
     objs, procs = [], []
     for src in SOURCES:

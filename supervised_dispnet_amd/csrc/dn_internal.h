@@ -77,8 +77,15 @@ struct Knobs {
   int wino_nmajor;                       // DN_WINO_NMAJOR (1): Winograd forward/dgrad tile order within an XCD: 1 tile row fastest (one 64-cout weight slice per XCD), 0 cout slice fastest, 2/3 by slice count
   int wino_wg_target;                    // DN_WINO_WG_TARGET (0 = by rule: 128 for small layers, else 256): blocks per round the Winograd weight gradient's tile split aims at
   int wino8;                             // DN_WINO8 (0 never / 1 always / -1 = by rule): 8-wave three-piece Winograd kernel
+  int wino8_var;                         // DN_WINO8_VAR: main-loop variant of the 8-wave kernel (A/B measurements)
 };
 const Knobs& knobs();
+
+// dn_conv_desc.compute as the kernels see it: 0 (DN_COMPUTE_DEFAULT, a zeroed descriptor) is the three-piece arithmetic, unknown values
+// the fp32 matrix instruction
+inline int norm_compute(int c) {
+  return c == DN_COMPUTE_BF16 ? DN_COMPUTE_BF16 : ((c == DN_COMPUTE_F32X3 || c == DN_COMPUTE_DEFAULT) ? DN_COMPUTE_F32X3 : DN_COMPUTE_F32);
+}
 
 #define DN_REQUIRE(cond, code, ...)      \
   do {                                   \

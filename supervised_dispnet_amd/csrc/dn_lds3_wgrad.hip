@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(256, 2) lds3_wgrad_stem_kernel(const IgemmPara
 
 // ------------------------------------------------------------------------------------------------------ dispatch
 static int lds3_wgrad_form(const dn_conv_desc* d, const IgemmParams& p) {     // 0 none, 1 iconv0 (16 -> 16), 2 iconv0 + 1-channel piece, 3 stem
-  if (knobs().no_lds3 || d->compute != DN_COMPUTE_F32X3) return 0;
+  if (knobs().no_lds3 || norm_compute(d->compute) != DN_COMPUTE_F32X3) return 0;
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return 0;
   if (d->IH != d->OH || d->IW != d->OW) return 0;
   if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.g) & 15)) return 0;
@@ -795,7 +795,7 @@ __global__ void __launch_bounds__(512, 2) lds3k_wgrad_kernel(const IgemmParams p
 
 // 0 none, 1 without / 2 with the trailing 1-channel piece
 static int lds3k_wgrad_form(const dn_conv_desc* d, const IgemmParams& p) {
-  if (knobs().no_lds3 || d->compute != DN_COMPUTE_F32X3) return 0;
+  if (knobs().no_lds3 || norm_compute(d->compute) != DN_COMPUTE_F32X3) return 0;
   if (d->kind != DN_CONV_FWD || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->dilation > 1) return 0;
   if (d->IH != d->OH || d->IW != d->OW || p.Ntot > 32 || p.Ntot < 17 || (p.Ntot & 3)) return 0;
   if ((long long)p.M * p.Ntot * 4 + 64 >= (1ll << 31)) return 0;

@@ -108,6 +108,7 @@ static void read_knobs(Knobs* k) {
   k->wino_nmajor = num("DN_WINO_NMAJOR", 1);
   k->no_riding_fences = on("DN_NO_RIDING_FENCES");
   k->wino8 = num("DN_WINO8", -1);
+  k->wino8_var = num("DN_WINO8_VAR", 0);
 }
 
 const Knobs& knobs() {
@@ -367,7 +368,8 @@ int build_plan(const dn_conv_desc* d, bool for_wgrad, IgemmParams* p) {
   }
   (void)n_uniform;
   p->tile_store = false ? 0 : (false ? 1 : 2);
-  p->compute = (d->compute == DN_COMPUTE_BF16 || d->compute == DN_COMPUTE_F32X3) ? d->compute : DN_COMPUTE_F32;
+  // (0 = DN_COMPUTE_DEFAULT = the three-piece arithmetic; unknown values: the fp32 instruction)
+  p->compute = norm_compute(d->compute);
   p->BN = pick_bn(p->Ntot);
   p->Npad = ceil_div(p->Ntot, p->BN) * p->BN;
   long long woff = 0;

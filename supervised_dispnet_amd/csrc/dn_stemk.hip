@@ -521,7 +521,7 @@ static int stemk_form(const dn_conv_desc* d, const IgemmParams& p, SkGeo* geo) {
 
 // the weight-gradient plan of the same layers (p.g = dy, p.in = the images, grid = output pixels)
 static int stemk_wgrad_form(const dn_conv_desc* d, const IgemmParams& p, SkGeo* geo) {
-  if (knobs().no_lds3 || d->compute != DN_COMPUTE_F32X3) return 0;
+  if (knobs().no_lds3 || norm_compute(d->compute) != DN_COMPUTE_F32X3) return 0;
   if (d->kind != DN_CONV_FWD || d->R != 7 || d->S != 7 || d->stride != 2 || d->pad != 3 || d->pad_mode != 0 || d->dilation > 1) return 0;
   if (p.n_in < 1 || p.n_in > 3 || p.ph[0].ntaps != 49) return 0;
   if ((d->IH & 1) || (d->IW & 3) || p.GH * 2 != d->IH || p.GW * 2 != d->IW) return 0;

@@ -34,8 +34,18 @@ static_assert(kLds8 >= WinoCfg<2>::LDS, "the epilogue's exchange area must cover
 static_assert(kLds8 <= 160 * 1024, "one CU has 160 KB of LDS");
 }  // namespace
 
+// Scalar fp32 add / subtract / fma that the SLP vectoriser cannot fuse into v_pk_*_f32 (a packed fp32 instruction beside matrix
+// instructions costs far more than the two scalar ones it replaces: MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+__device__ __forceinline__ float s_sub(float a, float b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_add(float a, float b) { float r; asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Experiment bits of DBG (round 6): 4096 scalar subtractions in the split, 8192 the two cout halves of a unit interleaved (consecutive
+// matrix instructions on different accumulators), 16384 scalar staging arithmetic, 32768 two split chains side by side
 template <bool HA, int DBG>
 __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p) {
+  constexpr bool XS = (DBG & 4096) != 0, XI = (DBG & 8192) != 0, XT = (DBG & 16384) != 0, XL = (DBG & 32768) != 0;   // (XL: the four pairs of a unit's split side by side in two slots)
+  constexpr bool XD = (DBG & 262144) != 0;      // patch loads one chunk deeper: issued in slots 24..39 of chunk c for chunk c + 2, transformed + stored in slots 0..13 of c + 1
   using Cfg = WinoCfg<2>;
   constexpr int BT = BT8, HALFB = Cfg::HALFB, POSB = Cfg::POSB, SUBB = Cfg::SUBB, BUFB = Cfg::BUFB;
   extern __shared__ __align__(16) float smem[];
@@ -72,6 +82,10 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
   const bool split_tile = g1 != 0x7fffffff;
   const int mb = p.nmajor ? q % MT : q / NT, nb = p.nmajor ? q / MT : q % NT;
   long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, te1 = 0, te2 = 0;
+  // DBG & 2048 (with 4): per-wave phase sums over the chunks of the main loop -- head (barrier release -> first matrix instruction), the
+  // four 12-slot quarters, the wait at the chunk's barrier (tools/wino_timing.py prints them per wave)
+  unsigned ph_head = 0, ph_q[4] = {0, 0, 0, 0}, ph_bar = 0, ph_n = 0;
+  long long ph_t = 0;
   if (DBG & 4) t0 = clock64();
 
   // ---- staging role: one 4x4 patch of 2 channels per thread and chunk (64 tiles x 8 channel pairs)
@@ -109,7 +123,8 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
   auto load_b3 = [&](int g) __attribute__((always_inline)) {
     const int ch = g / 12, k = g % 12, posl = k / 6, nn = (k % 6) / 3, piece = 2 - k % 3;
     const size_t off = (size_t)ch * wchunk16B + (size_t)posl * wj16B + (size_t)nn * 3072 + (size_t)piece * 1024;
-    bq[g % WRING] = *reinterpret_cast<const bf16x8*>(wcur16 + off);
+    if constexpr ((DBG & 1048576) != 0) bq[g % WRING] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wcur16 + off));   // (measurement: weights past the L1)
+    else bq[g % WRING] = *reinterpret_cast<const bf16x8*>(wcur16 + off);
   };
 #pragma unroll
   for (int g = 0; g < WRING; ++g) load_b3(g);
@@ -176,13 +191,26 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
         asm volatile("" : "+v"(pm));
         const int msk = __builtin_amdgcn_sbfe((int)pm, i, 1);
         const float cap = __builtin_bit_cast(float, msk & 0x7f800000);
-        const fV t = __builtin_elementwise_fma(v[i], sc4, sh4);
+        fV t;
+        if constexpr (XT) { t[0] = s_fma(v[i][0], sc4[0], sh4[0]); t[1] = s_fma(v[i][1], sc4[1], sh4[1]); }
+        else t = __builtin_elementwise_fma(v[i], sc4, sh4);
 #pragma unroll
         for (int e = 0; e < VW; ++e) v[i][e] = __builtin_amdgcn_fmed3f(t[e], relu_floor, cap);
       }
     };
     auto row_piece = [&](int b) __attribute__((always_inline)) {        // B^T d, in place: rows (0,1,2,3) <- (d0-d2, d1+d2, d2-d1, d1-d3)
       const fV d0 = v[0 + b], d1 = v[4 + b], d2 = v[8 + b];
+      if constexpr (XT) {
+        const fV d3 = v[12 + b];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          v[0 + b][e] = s_sub(d0[e], d2[e]);
+          v[4 + b][e] = s_add(d1[e], d2[e]);
+          v[8 + b][e] = s_sub(d2[e], d1[e]);
+          v[12 + b][e] = s_sub(d1[e], d3[e]);
+        }
+        return;
+      }
       v[0 + b] = d0 - d2;
       v[4 + b] = d1 + d2;
       v[8 + b] = d2 - d1;
@@ -190,6 +218,17 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     };
     auto col_piece = [&](int b2, int i, int half) __attribute__((always_inline)) {    // (B^T d) B and the LDS stores of transform row i
       char* dst = smemB + b2 * BUFB + stA + (4 * i) * POSB;
+      if constexpr (XT) {
+        const fV c0 = v[4 * i + 0], c1 = v[4 * i + 1], c2 = v[4 * i + 2], c3 = v[4 * i + 3];
+        if (half == 0) {
+          *reinterpret_cast<fV*>(dst + 0 * POSB) = fV{s_sub(c0[0], c2[0]), s_sub(c0[1], c2[1])};
+          *reinterpret_cast<fV*>(dst + 1 * POSB) = fV{s_add(c1[0], c2[0]), s_add(c1[1], c2[1])};
+        } else {
+          *reinterpret_cast<fV*>(dst + 2 * POSB) = fV{s_sub(c2[0], c1[0]), s_sub(c2[1], c1[1])};
+          *reinterpret_cast<fV*>(dst + 3 * POSB) = fV{s_sub(c1[0], c3[0]), s_sub(c1[1], c3[1])};
+        }
+        return;
+      }
       if (half == 0) {
         *reinterpret_cast<fV*>(dst + 0 * POSB) = v[4 * i + 0] - v[4 * i + 2];
         *reinterpret_cast<fV*>(dst + 1 * POSB) = v[4 * i + 1] + v[4 * i + 2];
@@ -226,6 +265,13 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
         col_piece(buf, i, 0);
         col_piece(buf, i, 1);
       }
+      if constexpr (XD) {                          // second stage of the fill: the next chunk's patch is in flight when the loop starts
+        cnB = (c_lo + 1 < nch ? c_lo + 1 : c_lo) * (WKC * 4);
+        const unsigned lm0 = scalar1 ? 0u : pmask;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) load_v_t(i, std::false_type{}, lm0);
+        load_aff();
+      }
     }
     __syncthreads();
     if (DBG & 4) t1 = clock64();
@@ -246,9 +292,14 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
         fa3[slot][2][2 * q] = h[0]; fa3[slot][2][2 * q + 1] = h[0];
         return;
       }
-      const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+      f32x2 r1, r2;
+      const f32x2 hf = __builtin_convertvector(h, f32x2);
+      if constexpr (XS) r1 = f32x2{s_sub(x[0], hf[0]), s_sub(x[1], hf[1])};
+      else r1 = x - hf;
       const bf16x2 m = __builtin_convertvector(r1, bf16x2);
-      const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+      const f32x2 mf = __builtin_convertvector(m, f32x2);
+      if constexpr (XS) r2 = f32x2{s_sub(r1[0], mf[0]), s_sub(r1[1], mf[1])};
+      else r2 = r1 - mf;
       const bf16x2 l = __builtin_convertvector(r2, bf16x2);
       fa3[slot][0][2 * q] = h[0]; fa3[slot][0][2 * q + 1] = h[1];
       fa3[slot][1][2 * q] = m[0]; fa3[slot][1][2 * q + 1] = m[1];
@@ -259,15 +310,23 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
     for (int c = c_lo; c < nch; ++c) {
       const bool more = c + 1 < nch;
       cnB = (more ? c + 1 : c) * (WKC * 4);            // the last chunk re-fetches itself into the idle buffer: no branch
+      if constexpr (XD) cnB = (c + 2 < nch ? c + 2 : nch - 1) * (WKC * 4);
       const char* Ab = smemB + buf * BUFB + frA3;
+      if constexpr ((DBG & 2048) != 0) ph_t = clock64();
       if constexpr (!(DBG & 512)) read_raw(Ab, 0);
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) split_pair(0, q4);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((DBG & 2048) != 0) {
+        const long long tn = clock64();
+        ph_head += (unsigned)(tn - ph_t);
+        ph_t = tn;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // slot m = 12 a + 6 nn + t: x0y2, x0y1, x1y1, x0y0, x1y0, x2y0
       static_for<48>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
-        constexpr int a = m / 12, q12 = m % 12, nn = q12 / 6, t = q12 % 6, posl = a >> 1, mm = a & 1;
+        constexpr int a = m / 12, q12 = m % 12, nn = XI ? q12 % 2 : q12 / 6, t = XI ? q12 / 2 : q12 % 6, posl = a >> 1, mm = a & 1;
         constexpr int AS[6] = {0, 0, 1, 0, 1, 2}, BS[6] = {2, 1, 1, 0, 0, 0};
         if constexpr (!(DBG & 256)) {
           acc[posl][mm][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[a & 1][AS[t]], bq[3 * nn + 2 - BS[t]], acc[posl][mm][nn], 0, 0, 0);
@@ -279,11 +338,15 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
           if constexpr (t == 0) load_b3(6 * posl + 3 * nn + 0 + WRING);
           if constexpr (t == 2) load_b3(6 * posl + 3 * nn + 1 + WRING);
           if constexpr (t == 5) load_b3(6 * posl + 3 * nn + 2 + WRING);
-        }
+        }                                                  // (XI: the same release points, two slots apart instead of six)
         if constexpr (a < 3 && q12 == 1 && !(DBG & 512)) read_raw(Ab, a + 1);
-        if constexpr (a < 3 && q12 >= 6 && q12 < 10) split_pair((a + 1) & 1, q12 - 6);
+        if constexpr (!XL && a < 3 && q12 >= 6 && q12 < 10) split_pair((a + 1) & 1, q12 - 6);
+        if constexpr (XL && a < 3 && (q12 == 6 || q12 == 8)) {
+          split_pair((a + 1) & 1, q12 - 6);
+          split_pair((a + 1) & 1, q12 - 5);
+        }
         constexpr bool STG = !(DBG & 64);                 // (DBG 64: ablation without the staging of the next chunk)
-        constexpr int SCHED = (DBG & 1024) ? 0 : 1;   // staging slot schedules (1 = shipped; others: measurements)
+        constexpr int SCHED = XD ? 2 : ((DBG & 1024) ? 0 : 1);   // staging slot schedules (1 = shipped; others: measurements)
         // 0 (DN_WINO_DBG=1028, the round-2 schedule, kept for A/B timing): loads 2..17, clamp 22..29, rows 30..33, cols 34..41
         // 1 (shipped): loads on odd slots 1..31, clamp 34..37 (4 per slot), rows 38..39, cols 40..47: 5686 -> 5354 cycles per chunk.
         // Also measured: loads 0..15 + transform 28..47 (5607), two loads per slot 0..7 (5697), s_setprio asymmetry between the two
@@ -299,7 +362,18 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
           if constexpr (STG && m >= R0 && m < R0 + 4) row_piece(m - R0);
           if constexpr (STG && m >= C0 && m < C0 + 8) col_piece(buf ^ 1, (m - C0) / 2, (m - C0) % 2);
         } else if constexpr (SCHED == 1) {
-          if constexpr (STG && m >= 1 && m < 33 && (m & 1)) load_v_t((m - 1) / 2, std::false_type{}, lmask);
+          // (timing ablations, wrong results: 65536 = only 4 of the 16 patch loads are issued, the others copy them -- what a raw input
+          //  region fetched once per block would leave of the vector-memory instructions; 131072 = 16 extra ds_read_b64 per thread and
+          //  chunk -- what reading the patches from such a region would add)
+          if constexpr (STG && m >= 1 && m < 33 && (m & 1)) {
+            constexpr int li = (m - 1) / 2;
+            if constexpr ((DBG & 65536) != 0 && li >= 4) v[li] = v[li & 3];
+            else load_v_t(li, std::false_type{}, lmask);
+            if constexpr ((DBG & 131072) != 0) {
+              const fV dz = *reinterpret_cast<const fV*>(smemB + buf * BUFB + stA + li * POSB);
+              asm volatile("" :: "v"(dz));
+            }
+          }
           if constexpr (STG && m == 2) load_aff();
           if constexpr (STG && m >= 34 && m < 38) {
 #pragma unroll
@@ -310,11 +384,33 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
             row_piece(2 * (m - 38) + 1);
           }
           if constexpr (STG && m >= 40 && m < 48) col_piece(buf ^ 1, (m - 40) / 2, (m - 40) % 2);
+        } else if constexpr (SCHED == 2) {
+          if constexpr (STG && m < 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) affine_piece(4 * m + u);
+          }
+          if constexpr (STG && m >= 4 && m < 6) {
+            row_piece(2 * (m - 4));
+            row_piece(2 * (m - 4) + 1);
+          }
+          if constexpr (STG && m >= 6 && m < 14) col_piece(buf ^ 1, (m - 6) / 2, (m - 6) % 2);
+          if constexpr (STG && m >= 24 && m < 40) load_v_t(m - 24, std::false_type{}, lmask);
+          if constexpr (STG && m == 40) load_aff();
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((DBG & 2048) != 0 && m % 12 == 11) {
+          const long long tn = clock64();
+          ph_q[m / 12] += (unsigned)(tn - ph_t);
+          ph_t = tn;
+          __builtin_amdgcn_sched_barrier(0);
+        }
       });
       wcur16 += wchunk16B;
       __syncthreads();
+      if constexpr ((DBG & 2048) != 0) {
+        ph_bar += (unsigned)(clock64() - ph_t);
+        ++ph_n;
+      }
       buf ^= 1;
     }
   }
@@ -623,8 +719,14 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
       long long* o = reinterpret_cast<long long*>(p.ws) + (size_t)blockIdx.x * 8;
       o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = te1; o[5] = te2;
     }
+    if constexpr ((DBG & 2048) != 0) {
+      if (lane == 0) {
+        long long* o = reinterpret_cast<long long*>(p.ws) + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = ph_head; o[1] = ph_q[0]; o[2] = ph_q[1]; o[3] = ph_q[2]; o[4] = ph_q[3]; o[5] = ph_bar; o[6] = ph_n; o[7] = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // (HW_ID: SIMD id in bits 5:4)
+      }
+    }
   }
-  if constexpr (DBG == 0) {
+  if constexpr ((DBG & 4095) == 0) {
     __syncthreads();                     // (the LDS of the epilogue is free from here)
     wino_fold_tail(p, nb, MT, smem, tid);
   }
@@ -642,7 +744,7 @@ static int launch_wino8_variant(const IgemmParams& p, hipStream_t stream) {
   IgemmParams q = p;
   q.ksplit = 1;
   int blocks = (tiles + 7) / 8 * 8;
-  if (DBG == 0 && !knobs().no_wino8_tail && p.ks_ws != nullptr) {
+  if ((DBG & 4095) == 0 && !knobs().no_wino8_tail && p.ks_ws != nullptr) {
     // tail split (see the kernel): the last partial round of one-block-per-CU rounds
     const int cus = 256, reg = tiles / cus * cus, tail = tiles - reg;
     int chunks = 0;
@@ -695,11 +797,17 @@ int launch_wino_conv8(const IgemmParams& p, hipStream_t stream) {
     switch (dbg) {
 #define DN_W8_CASE(D) case D: return launch_wino8_variant<false, D>(q, stream);
       DN_W8_CASE(4 + 16) DN_W8_CASE(4 + 32) DN_W8_CASE(4 + 64) DN_W8_CASE(4 + 256) DN_W8_CASE(4 + 512) DN_W8_CASE(4 + 16 + 64) DN_W8_CASE(4 + 16 + 32 + 64)
-      DN_W8_CASE(4 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 256 + 16) DN_W8_CASE(4 + 256 + 64) DN_W8_CASE(4 + 256 + 16 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 1024)
+      DN_W8_CASE(4 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 256 + 16) DN_W8_CASE(4 + 256 + 64) DN_W8_CASE(4 + 256 + 16 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64) DN_W8_CASE(4 + 256 + 16 + 32 + 64 + 512) DN_W8_CASE(4 + 1024) DN_W8_CASE(4 + 2048) DN_W8_CASE(4 + 65536) DN_W8_CASE(4 + 131072) DN_W8_CASE(4 + 65536 + 131072) DN_W8_CASE(4 + 2048 + 262144)
 #undef DN_W8_CASE
       default: break;
     }
     return q.any_affine ? launch_wino8_variant<true, 4>(q, stream) : launch_wino8_variant<false, 4>(q, stream);
+  }
+  switch (dbg == 0 ? knobs().wino8_var : 0) {   // round-6 experiment instantiations (results are right; DN_WINO8_VAR = 4096 | 8192 | 16384 bits)
+#define DN_W8_X(D) case D: return p.any_affine ? launch_wino8_variant<true, D>(p, stream) : launch_wino8_variant<false, D>(p, stream);
+    DN_W8_X(28672 + 32768) DN_W8_X(262144) DN_W8_X(1048576)      // (the single bits and other combinations measured the same: profiles/r06_exp1_wino8_variants.txt)
+#undef DN_W8_X
+    default: break;
   }
   return p.any_affine ? launch_wino8_variant<true, 0>(p, stream) : launch_wino8_variant<false, 0>(p, stream);
 }

@@ -218,11 +218,12 @@ def test_weight_layout_follows_the_geometry(lib):
 def test_compute_field_selects_the_packed_layout(lib):
     """dn_conv_desc.compute (host only): the Winograd layers pack their weights per arithmetic -- 1 fp32 fragments (DN_COMPUTE_F32),
     2 bf16-rounded (DN_COMPUTE_BF16), 3 three exact bf16 pieces (DN_COMPUTE_F32X3, 6 bytes per weight = 1.5 floats); layers on the
-    implicit-GEMM path ignore the field; unknown values mean fp32."""
-    from supervised_dispnet_amd._lib import COMPUTE_BF16, COMPUTE_F32, COMPUTE_F32X3
+    implicit-GEMM path ignore the field; 0 (a zeroed descriptor) is the library default = the three-piece arithmetic, unknown values mean fp32."""
+    from supervised_dispnet_amd._lib import COMPUTE_BF16, COMPUTE_DEFAULT, COMPUTE_F32, COMPUTE_F32X3
+    assert (COMPUTE_DEFAULT, COMPUTE_BF16, COMPUTE_F32X3, COMPUTE_F32) == (0, 1, 2, 3)
     L = lambda d: lib.dn_conv_weight_layout(C.byref(d))
     n32 = None
-    for mode, layout in ((COMPUTE_F32, 1), (COMPUTE_BF16, 2), (COMPUTE_F32X3, 3), (77, 1)):
+    for mode, layout in ((COMPUTE_F32, 1), (COMPUTE_BF16, 2), (COMPUTE_F32X3, 3), (77, 1), (COMPUTE_DEFAULT, 3)):
         d = _desc3x3(32, 64, 208, (128,), 128)
         d.compute = mode
         assert L(d) == layout
