@@ -413,6 +413,11 @@ def main():
     ap.add_argument("--watchdog-s", type=float, default=0.0,
                     help="N > 1: if the line has not been printed after this many seconds (default 900 at N > 1, 0 = off at N = 1) rank 0 "
                          "prints a line with value null and the reason, and every rank exits non-zero")
+    ap.add_argument("--extras", default="auto", choices=["auto", "0", "1"],
+                    help="N = 1, default workload: after the headline's timed region, also time BASELINE configs[2..4] + the 480x640 VGG step "
+                         "(10 steps each) and the 4 / 8 / 16-image steps of the metric's model (launch tape; + the data-parallel machinery on a "
+                         "single-rank own-RCCL communicator), each as a nested run of this script, and carry them in the SAME line as "
+                         "`other_configs` / `strong_1gpu` (auto: on for the plain `python bench.py [--gpus 1]` call)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only plumbing check of the N>1 path: build the net, the arena, the buckets, one fake all-reduce cycle, tear down")
     args = ap.parse_args()
@@ -741,6 +746,10 @@ def main():
                                   ("launch tape: %d launches + %d stream fences (%d as the stop event of the launch in front) of one recorded step re-issued by dn_tape_replay, %d segment(s)"
                                    % (taped.launches, taped.fences, taped.riding_fences, taped.segments)) if taped is not None else "eager launches"),
                        "tape_replay_host_ms": (round(taped.host_s / max(taped.replays, 1) * 1e3, 4) if taped is not None else None),
+                       "tape_join": (None if taped is None else
+                                     ("lazy: the replays follow each other on the tape's stream, one join after the timed steps (train.py joins and reads "
+                                      "the loss every step: about +25 us per step; --tape-join-every-step measures that)" if taped.lazy_join
+                                      else "the caller's stream joins the tape's after every replay")),
                        "tape_verified": (None if tape_verified is None else
                                          ("replay == eager step, bit for bit" if tape_verified[0] else "MISMATCH: max |diff| %.3g" % tape_verified[1])),
                        "graph_fallback": graph_note, "adam": "per bucket, under the backward pass" if overlap_adam else "one pass after the backward",
@@ -761,6 +770,10 @@ def main():
         line = None
     if world > 1 and args.rccl_selfcheck != "0" and os.environ.get("DN_DIST_BACKEND", "nccl") == "nccl":
         rccl_selfcheck(line, dev, rank, world)
+    plain_call = (world == 1 and args.config == "vggbn128" and args.batch == 0 and args.launch == "auto" and args.reducer == "auto" and
+                  args.compute == "f32x3" and not args.no_cpu_baseline and "DN_BENCH_NESTED" not in os.environ)
+    if line is not None and (args.extras == "1" or (args.extras == "auto" and plain_call)):
+        line["other_configs"], line["strong_1gpu"] = run_extras(args)
     if watchdog is not None:
         watchdog.cancel()
     try:
@@ -775,6 +788,51 @@ def main():
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _nested(flags, timeout_s=420):
+    """One nested run of this script on the same GPU (its own process: its own allocator, tape and knobs); returns its JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env["DN_BENCH_NESTED"] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--profile-steps", "0", "--alt-steps", "0",
+           "--extras", "0"] + flags
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout after %d s" % timeout_s}
+    rows = [x for x in out.stdout.splitlines() if x.startswith("{")]
+    if out.returncode != 0 or not rows:
+        return {"error": "exit %d: %s" % (out.returncode, (out.stderr or "")[-300:])}
+    return json.loads(rows[-1])
+
+
+def run_extras(args):
+    """What SURVEY.md section 8(d) / north_star ask beside the headline, timed by the SAME command the driver runs (round-5 verdict, item 3):
+    `other_configs` = BASELINE configs[2], [4], [3] and the 480 x 640 step of the metric's model, 10 timed steps each;
+    `strong_1gpu`   = the metric's step at 4 / 8 / 16 images (what one GPU of an 8 / 4 / 2-GPU data-parallel run of the literal metric,
+    global batch 32, would compute) through the launch tape, and the same with the data-parallel machinery live on a single-rank own-RCCL
+    communicator (gradient buckets, tape cuts, event fences, ncclAllReduce; only the wire is missing).  ONE-GPU figures, not a scaling
+    curve.  Each entry: ms_per_step, img/s, the step's credited fraction of the 157.3 TFLOP/s fp32 matrix peak (BASELINE.md section 2
+    FLOPs), or the error of that nested run."""
+    def brief(l, extra=()):
+        if "error" in l:
+            return l
+        r = {"img_per_s": l["value"], "ms_per_step": l["ms_per_step"], "ms_per_step_median": l.get("ms_per_step_median"),
+             "steps": l["steps"], "step_credited_frac": l.get("step_credited_frac"), "step_executed_frac": l.get("step_executed_frac"),
+             "workload": l["config"]["workload"], "launch": l["config"]["launch"].split(":")[0], "final_loss": l["config"].get("final_loss")}
+        for k in extra:
+            r[k] = l["config"].get(k)
+        return r
+    other = {}
+    for cfg in ("photo128", "dorn128", "res50_480", "vggbn480"):
+        other[cfg] = brief(_nested(["--config", cfg, "--steps", "10", "--warmup", "3"]))
+    strong = {"note": "one GPU computing 32 / N images per step (global batch 32 over N ranks): a bound, not a measured scaling curve"}
+    for b in (4, 8, 16):
+        strong["b%d_tape" % b] = brief(_nested(["--batch", str(b), "--steps", "40", "--warmup", "8", "--launch", "tape"]))
+        strong["b%d_tape_rccl1" % b] = brief(_nested(["--batch", str(b), "--steps", "40", "--warmup", "8", "--launch", "tape", "--reducer", "rccl1"]),
+                                             extra=("comm", "comm_buckets"))
+    return other, strong
 
 
 def start_watchdog(args, world, rank):

@@ -543,7 +543,8 @@ int dn_copy(const float* src, float* dst, int64_t n, dn_stream_t stream);
  *                                        (hipExtLaunchKernel) -- the dispatch's own completion signal, no marker packet behind the kernel
  *   dn_tape_mark(tape)                   cut: returns the number of the segment that starts here; the caller replays segment by
  *                                        segment and does its own host work in between (a gradient bucket's all-reduce)
- *   dn_tape_pause(tape, 1 / 0)           launches in between are executed but not recorded (such host work, when it is live at replay)
+ *   dn_tape_pause(tape, 1 / 0)           launches in between are executed but not recorded (such host work, when it is live at replay);
+ *                                        a later dn_tape_fence_device never rides on a launch recorded in front of the pause
  *   dn_tape_replay(tape, segment)        segment -1: the whole tape
  * ------------------------------------------------------------------------------------------------------------ */
 void* dn_tape_begin(void);

@@ -13,6 +13,9 @@
 // up to kFoldMaxRows partial rows) and the folded epilogues, so a folded reduction is bit-identical to the separate kernel
 // (tests/test_gpu_kernels.py::test_folded_reductions_are_bitwise_the_separate_kernels).
 #pragma once
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "dn_fold.h relies on gfx950 behaviour (write-through sc1 stores + s_waitcnt vmcnt(0), relaxed agent-scope atomics served by the L2): probe before porting (dn_last_arrival_probe)"
+#endif
 #include "dn_internal.h"
 
 namespace dn {

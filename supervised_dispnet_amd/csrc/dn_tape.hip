@@ -41,6 +41,7 @@ struct LaunchTape {
   std::vector<hipEvent_t> events;
   std::mutex mu;                       // forward is recorded on the caller's thread, backward on autograd's
   size_t launches = 0, fences = 0, riding = 0;
+  size_t no_ride_before = 0;         // ops in front of the last dn_tape_pause(.., 1): unrecorded work may sit behind them on their streams
 };
 
 std::atomic<LaunchTape*> g_tape_rec{nullptr};
@@ -91,6 +92,12 @@ int dn_tape_pause(void* tape, int32_t paused) {
     dn::set_error("dn_tape_pause: the tape is not in the state this call expects");
     return DN_ERR_BAD_ARG;
   }
+  if (paused) {
+    // Work enqueued while the tape is paused is live at replay too but invisible here: a later device-scope fence must not ride on a
+    // launch recorded BEFORE the pause (its stop event would not cover the unrecorded work behind it)
+    std::lock_guard<std::mutex> lock(t->mu);
+    t->no_ride_before = t->ops.size();
+  }
   return DN_OK;
 }
 
@@ -122,7 +129,7 @@ static int tape_fence(void* tape, dn_stream_t waiter, dn_stream_t waitee, unsign
       dn::TapeOp& o = t->ops[i];
       if (o.launch) {
         if (o.stream != s) continue;
-        if (t->marks.empty() || i >= t->marks.back()) {      // (within the current segment)
+        if ((t->marks.empty() || i >= t->marks.back()) && i >= t->no_ride_before) {      // (within the current segment, not across a pause)
           if (o.stop == nullptr) o.stop = ev;
           f.ev = o.stop;                                     // (a second fence behind the same launch shares its stop event)
           f.record = false;

@@ -198,9 +198,25 @@ class TapedStep(object):
         return self.out
 
     def join(self):
-        """The caller's current stream waits for everything replayed so far (needed with lazy_join before the outputs are read there)."""
+        """The caller's current stream waits for everything replayed so far (needed with lazy_join before the outputs are read there,
+        and before the static inputs are overwritten from there)."""
         if self.tape is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+
+    def write_inputs(self, *srcs):
+        """Refill the static inputs for the next replay: static_inputs[i].copy_(srcs[i]) ON THE TAPE'S STREAM, after whatever the caller's
+        stream has pending for `srcs`.  Stream order puts the copies behind the previous replay's reads of the inputs and in front of
+        the next replay's -- safe with lazy_join without a join (a copy_ issued on the caller's stream would race with the tail of the
+        previous replay: write after read)."""
+        if len(srcs) != len(self.inputs):
+            raise ValueError("write_inputs: %d tensors for %d static inputs" % (len(srcs), len(self.inputs)))
+        s = self._stream
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for dst, src in zip(self.inputs, srcs):
+                dst.copy_(src, non_blocking=True)
+                if src.is_cuda:
+                    src.record_stream(s)
 
     def verify(self, state):
         """Replay once and run the SAME step eagerly once from the same state (`state`: the tensors the step reads and updates --

@@ -31,6 +31,20 @@ _FOLD_COUNTERS = {}             # device -> [zeroed int32 tensor, next slot]: la
 def _fold_counter(dev):
     """Address of a zero int32 for one fused launch: 64 slots per device handed out round-robin, so that launches that overlap on the
     device (other streams) count in different slots; every launch leaves its slot zero."""
+    from . import engine
+    rec = engine.TAPE
+    if rec is not None and not rec.get("paused"):
+        # a launch tape bakes the address in for good: it gets counters of its own (kept alive with the tape), never shared with the eager
+        # launches that keep cycling through the 64 slots below -- validation, a second model's loss -- and may overlap with a replay
+        ent = rec.get("fold_counters")
+        if ent is None:
+            with engine.outside_tape_pool():
+                ent = rec["fold_counters"] = [torch.zeros(256, dtype=torch.int32, device=dev), 0]
+            rec["keep"].append(ent[0])
+        if ent[1] >= 256:
+            raise RuntimeError("more than 256 fused loss launches in one recorded step")
+        ent[1] += 1
+        return ent[0].data_ptr() + 4 * (ent[1] - 1)
     ent = _FOLD_COUNTERS.get(dev)
     if ent is None:
         from .engine import outside_tape_pool

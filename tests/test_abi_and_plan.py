@@ -172,8 +172,9 @@ def test_plan_describes_conv_transpose_and_its_input_gradient(lib, k, s, p, op, 
 
 
 def _desc3x3(N, H, W, cins, cout, kind=None, strides_ok=True, ups=None):
-    from supervised_dispnet_amd._lib import CONV_FWD, ConvDesc
+    from supervised_dispnet_amd._lib import COMPUTE_F32, CONV_FWD, ConvDesc
     d = ConvDesc()
+    d.compute = COMPUTE_F32                      # (the geometry tests below were written for the fp32 layouts; 0 = the library default = F32X3)
     d.kind = CONV_FWD if kind is None else kind
     d.N, d.IH, d.IW, d.OH, d.OW, d.R, d.S, d.stride, d.pad = N, H, W, H, W, 3, 3, 1, 1
     d.n_in = len(cins)

@@ -212,12 +212,14 @@ def test_train_cli_from_uint8_shards(tmp_path):
 
 @pytest.mark.parametrize("loss", ["L1", "Multi_L1"])
 def test_train_cli_launch_tape_equals_the_eager_run(tmp_path, capsys, loss):
-    """train.py --tape: the supervised step through the launch tape (recorded on the first batch, checked bit for bit against the eager
+    """train.py (the launch tape is the DEFAULT for the supervised losses since round 6; --no-tape = eager launches): the supervised step
+    through the launch tape (recorded on the first batch, checked bit for bit against the eager
     step on the second, replayed from the third on) logs the same per-step losses and ends with the same weights as the eager run of the
     same command line -- up to the last bit of Adam's step size (device-side vs host-side pow() of the bias corrections)."""
     args = ["--network", "disp_vgg_BN", "--with-gt", "--loss", loss, "--seed", "3"]
-    ve, sde, _ = _run_train(tmp_path / "eager", args, epochs=2, n=16, b=4)
-    vt, sdt, _ = _run_train(tmp_path / "tape", args + ["--tape"], epochs=2, n=16, b=4)
+    ve, sde, _ = _run_train(tmp_path / "eager", args + ["--no-tape"], epochs=2, n=16, b=4)
+    assert "--tape:" not in capsys.readouterr().out
+    vt, sdt, _ = _run_train(tmp_path / "tape", args, epochs=2, n=16, b=4)                 # (no flag: the default)
     out = capsys.readouterr().out
     assert "--tape:" in out and "bit for bit" in out, out[-600:]
     assert "eager launches (" not in out

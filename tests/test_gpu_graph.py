@@ -274,13 +274,15 @@ def test_launch_tape_lazy_join_runs_replays_back_to_back_and_joins_on_demand(mon
         f.join()
         lb.append(out.clone())
         la.append(step_a(x, y).clone())
-    # back to back, one join at the end
+    # back to back, one join at the end: the inputs are refilled ON THE TAPE'S STREAM (write_inputs) -- a copy_ on the caller's stream
+    # here would race with the previous replay's reads of img / gt (its weight gradient and loss read them last), nothing orders the two
     for x, y in batches[:2]:
-        img.copy_(x)
-        gt.copy_(y)
+        f.write_inputs(x, y)
         out = f()
         step_a(x, y)
     f.join()
+    with pytest.raises(ValueError):
+        f.write_inputs(x)
     torch.cuda.synchronize()
     for u, v in zip(la[1:], lb):
         assert torch.equal(u, v)
