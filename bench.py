@@ -818,8 +818,10 @@ def run_extras(args):
     def brief(l, extra=()):
         if "error" in l:
             return l
+        gf = l.get("baseline_md_gflop_per_img")           # conv multiply-accumulates x 2 x 3 (forward + two gradients) per image
         r = {"img_per_s": l["value"], "ms_per_step": l["ms_per_step"], "ms_per_step_median": l.get("ms_per_step_median"),
-             "steps": l["steps"], "step_credited_frac": l.get("step_credited_frac"), "step_executed_frac": l.get("step_executed_frac"),
+             "steps": l["steps"],
+             "step_credited_frac": (gf * l["value"] / 1e3 / PEAK_FP32_MFMA_TFLOPS) if gf else None,     # of the 157.3 TFLOP/s fp32 matrix peak
              "workload": l["config"]["workload"], "launch": l["config"]["launch"].split(":")[0], "final_loss": l["config"].get("final_loss")}
         for k in extra:
             r[k] = l["config"].get(k)

@@ -123,8 +123,7 @@ __global__ void __launch_bounds__(512, 1) wino_conv8_kernel(const IgemmParams p)
   auto load_b3 = [&](int g) __attribute__((always_inline)) {
     const int ch = g / 12, k = g % 12, posl = k / 6, nn = (k % 6) / 3, piece = 2 - k % 3;
     const size_t off = (size_t)ch * wchunk16B + (size_t)posl * wj16B + (size_t)nn * 3072 + (size_t)piece * 1024;
-    if constexpr ((DBG & 1048576) != 0) bq[g % WRING] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wcur16 + off));   // (measurement: weights past the L1)
-    else bq[g % WRING] = *reinterpret_cast<const bf16x8*>(wcur16 + off);
+    bq[g % WRING] = *reinterpret_cast<const bf16x8*>(wcur16 + off);     // (round 6: as __builtin_nontemporal_load the kernel is 8-12 % SLOWER, profiles/r06_exp5)
   };
 #pragma unroll
   for (int g = 0; g < WRING; ++g) load_b3(g);
@@ -805,7 +804,7 @@ int launch_wino_conv8(const IgemmParams& p, hipStream_t stream) {
   }
   switch (dbg == 0 ? knobs().wino8_var : 0) {   // round-6 experiment instantiations (results are right; DN_WINO8_VAR = 4096 | 8192 | 16384 bits)
 #define DN_W8_X(D) case D: return p.any_affine ? launch_wino8_variant<true, D>(p, stream) : launch_wino8_variant<false, D>(p, stream);
-    DN_W8_X(28672 + 32768) DN_W8_X(262144) DN_W8_X(1048576)      // (the single bits and other combinations measured the same: profiles/r06_exp1_wino8_variants.txt)
+    DN_W8_X(28672 + 32768) DN_W8_X(262144)      // (the single bits and other combinations measured the same: profiles/r06_exp1_wino8_variants.txt)
 #undef DN_W8_X
     default: break;
   }
