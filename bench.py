@@ -884,8 +884,8 @@ def rccl_selfcheck(line, dev, rank, world, timeout_s=90.0):
     """N > 1 only, AFTER every timed region: one 20 MB gradient-bucket-sized buffer is summed over the ranks through this library's own
     RCCL communicator (rccl.Communicator: ncclCommInitRank from a unique id passed through torch.distributed's store, ncclAllReduce
     on a library stream, event fences) and through torch.distributed.all_reduce, and the two results are compared bit for bit; both
-    paths are also timed (10 all-reduces each).  Recorded as config.rccl_selfcheck -- the evidence DN_COMM=rccl's default-off status
-    is waiting for.  A watchdog prints the line (rank 0) and ends the process if the own path blocks, so the headline never depends
+    paths are also timed (10 all-reduces each).  Recorded as config.rccl_selfcheck -- since round 6 the own communicator IS the default
+    beyond one rank (behind distributed.open_rccl_communicator's preflight); this is the same comparison at bucket size, with timings.  A watchdog prints the line (rank 0) and ends the process if the own path blocks, so the headline never depends
     on it."""
     import threading
     import torch.distributed as dist

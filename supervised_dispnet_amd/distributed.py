@@ -68,17 +68,55 @@ def open_rccl_communicator(device, strict=False):
         print("supervised_dispnet_amd: own RCCL communicator not available on every rank (%s); all ranks use torch.distributed" % (err,),
               file=sys.stderr)
         return None
+    if comm.world > 1:
+        # Preflight (round 6: the own communicator is the DEFAULT beyond one rank): one 1 MB sum through it against the same sum through
+        # torch.distributed, waited for with a deadline -- a communicator that does not answer, or answers differently, is dropped on ALL
+        # ranks before a gradient ever depends on it.
+        why = _preflight(comm, device)
+        if not agree_all_ranks(why is None, device=device):
+            if strict:
+                raise RuntimeError("own RCCL communicator failed its preflight on some rank (%s)" % (why,))
+            print("supervised_dispnet_amd: own RCCL communicator failed its preflight (%s); all ranks use torch.distributed" % (why,), file=sys.stderr)
+            if why is None or "deadline" not in why:
+                comm.destroy()                # (one that never answered is left alone: destroying it would wait for it)
+            return None
     return comm
 
 
+def _preflight(comm, device, seconds=30.0):
+    """None if a 1 MB fp32 sum over the ranks through `comm` completes within `seconds` and equals torch.distributed's (to summation
+    order); otherwise the reason."""
+    import time
+    try:
+        n = (1 << 20) // 4
+        g = torch.Generator().manual_seed(4321 + comm.rank)
+        src = torch.randn(n, generator=g).to(device)
+        a, b = src.clone(), src.clone()
+        comm.all_reduce_sum_(a, [torch.cuda.current_stream(device)])
+        t0 = time.perf_counter()
+        while not comm.stream.query():
+            if time.perf_counter() - t0 > seconds:
+                return "no answer within the %.0f s deadline" % seconds
+            time.sleep(0.002)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(device)
+        if not torch.allclose(a, b, rtol=1e-5, atol=1e-5):
+            return "sum differs from torch.distributed's: max |diff| %.3g" % float((a - b).abs().max())
+        return None
+    except Exception as e:                       # noqa: BLE001
+        return "%s: %s" % (type(e).__name__, str(e)[:160])
+
+
 class GradReducer(object):
-    """`comm`: "torch" = torch.distributed.all_reduce(async_op=True) on the launcher's process group (backend "nccl" IS RCCL on ROCm;
-    gloo on CPU in the tests) -- the DEFAULT whenever there is more than one rank; "rccl" = this library's own communicator and HIP
-    stream (rccl.Communicator: ncclCommInitRank / ncclAllReduce + event fences) -- the default at world == 1 (where it is exercised
-    bit-for-bit by tests/test_gpu_rccl.py) and opt-in (DN_COMM=rccl) beyond, because no multi-GPU node has been available to this
-    build to validate it against the torch path (bench.py --gpus N records exactly that comparison as config.rccl_selfcheck); or a
-    ready rccl.Communicator.  Whatever is chosen is chosen by ALL ranks together (open_rccl_communicator).  `self.path` names the
-    data path that actually runs ("rccl-own" / "torch.distributed:<backend>" / "none")."""
+    """`comm`: "rccl" = this library's own communicator and HIP stream (rccl.Communicator: ncclCommInitRank / ncclAllReduce + event
+    fences, the exchange launched as buckets complete, no host fence in between) -- the DEFAULT for device arenas at every world size
+    since round 6: at world == 1 it is exercised bit for bit by tests/test_gpu_rccl.py; beyond one rank open_rccl_communicator takes it
+    only if it initialises on EVERY rank and passes a preflight there (a 1 MB sum against torch.distributed's, with a deadline), and
+    bench.py --gpus N compares and times the two paths once more after the timed region (config.rccl_selfcheck).  "torch" =
+    torch.distributed.all_reduce(async_op=True) on the launcher's process group (backend "nccl" IS RCCL on ROCm; gloo on CPU in the
+    tests): DN_COMM=torch, CPU arenas, a non-default process group, or the silent fall-back when the own communicator is refused.
+    Or a ready rccl.Communicator.  Whatever is chosen is chosen by ALL ranks together.  `self.path` names the data path that actually
+    runs ("rccl-own" / "torch.distributed:<backend>" / "none")."""
 
     def __init__(self, arena, bucket_bytes=20 << 20, process_group=None, comm=None, tail_bytes=1 << 20):
         self.arena = arena
@@ -86,7 +124,7 @@ class GradReducer(object):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         import os
         env = os.environ.get("DN_COMM")
-        default = "rccl" if (arena.flat_g.is_cuda and self.world == 1) else "torch"
+        default = "rccl" if (arena.flat_g.is_cuda and process_group is None) else "torch"
         choice = comm if comm is not None else (env or default)
         self.comm = None
         if choice == "rccl":
